@@ -1,0 +1,191 @@
+"""Functional (state_dict-driven) CPU restatement of the reference network.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+The reference builds the network from nn.Module classes; this restatement is a
+set of pure functions over a flat ``state`` dict whose keys are exactly the
+reference's ``state_dict()`` keys (``baseModel.inc.double_conv.0.weight`` ...
+``last_layer.upper.bias``), so the same weights can be fed to the reference,
+to this oracle and to the HIP path.  All arithmetic is PyTorch-CPU fp32, the
+same substrate the reference's CPU path runs on.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5       # torch.nn.BatchNorm2d default, core/models/trunks/unet_parts.py:17
+BN_MOMENTUM = 0.1   # idem
+
+# (prefix, Cin, Cmid, Cout) for the nine DoubleConv blocks of the fixed
+# 4-level UNet, core/models/trunks/unet.py:20-30 with bilinear=True.
+def unet_blocks(n_in: int) -> List[Tuple[str, int, int, int]]:
+    return [
+        ("inc", n_in, 64, 64),
+        ("down1.maxpool_conv.1", 64, 128, 128),
+        ("down2.maxpool_conv.1", 128, 256, 256),
+        ("down3.maxpool_conv.1", 256, 512, 512),
+        ("down4.maxpool_conv.1", 512, 512, 512),
+        ("up1.conv", 1024, 512, 256),
+        ("up2.conv", 512, 256, 128),
+        ("up3.conv", 256, 128, 64),
+        ("up4.conv", 128, 64, 64),
+    ]
+
+
+def state_spec(n_in: int = 1, n_out: int = 1, n_mid: int = 32) -> List[Tuple[str, Tuple[int, ...]]]:
+    """(key, shape) list in the reference's state_dict order
+    (unet.py:20-31, unet_parts.py:15-22,90, quantile_layer.py:15-17)."""
+    spec: List[Tuple[str, Tuple[int, ...]]] = []
+    for prefix, cin, cmid, cout in unet_blocks(n_in):
+        p = f"baseModel.{prefix}.double_conv"
+        for idx, (ci, co) in ((0, (cin, cmid)), (3, (cmid, cout))):
+            spec.append((f"{p}.{idx}.weight", (co, ci, 3, 3)))
+            spec.append((f"{p}.{idx}.bias", (co,)))
+            spec.append((f"{p}.{idx + 1}.weight", (co,)))
+            spec.append((f"{p}.{idx + 1}.bias", (co,)))
+            spec.append((f"{p}.{idx + 1}.running_mean", (co,)))
+            spec.append((f"{p}.{idx + 1}.running_var", (co,)))
+            spec.append((f"{p}.{idx + 1}.num_batches_tracked", ()))
+    spec.append(("baseModel.out.conv.weight", (n_mid, 64, 1, 1)))
+    spec.append(("baseModel.out.conv.bias", (n_mid,)))
+    for head in ("lower", "prediction", "upper"):
+        spec.append((f"last_layer.{head}.weight", (n_out, n_mid, 3, 3)))
+        spec.append((f"last_layer.{head}.bias", (n_out,)))
+    return spec
+
+
+def is_param(key: str) -> bool:
+    return not (key.endswith("running_mean") or key.endswith("running_var")
+                or key.endswith("num_batches_tracked"))
+
+
+def double_conv(x, state, prefix, training):
+    """(conv3x3 pad1 + bias -> BatchNorm2d -> ReLU) x 2, unet_parts.py:15-25."""
+    p = f"baseModel.{prefix}.double_conv"
+    for idx in (0, 3):
+        x = F.conv2d(x, state[f"{p}.{idx}.weight"], state[f"{p}.{idx}.bias"], padding=1)
+        x = F.batch_norm(x, state[f"{p}.{idx + 1}.running_mean"], state[f"{p}.{idx + 1}.running_var"],
+                         state[f"{p}.{idx + 1}.weight"], state[f"{p}.{idx + 1}.bias"],
+                         training=training, momentum=BN_MOMENTUM, eps=BN_EPS)
+        if training:
+            state[f"{p}.{idx + 1}.num_batches_tracked"] += 1
+        x = F.relu(x)
+    return x
+
+
+def up_block(x_deep, x_skip, state, prefix, training):
+    """bilinear x2 (align_corners=True) -> zero-pad to skip -> cat([skip, up]) -> DoubleConv,
+    unet_parts.py:58-69."""
+    u = F.interpolate(x_deep, scale_factor=2, mode="bilinear", align_corners=True)
+    dy = x_skip.shape[2] - u.shape[2]
+    dx = x_skip.shape[3] - u.shape[3]
+    u = F.pad(u, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+    return double_conv(torch.cat([x_skip, u], dim=1), state, prefix, training)
+
+
+def unet_forward(x, state, training: bool):
+    """core/models/trunks/unet.py:33-46."""
+    x1 = double_conv(x, state, "inc", training)
+    skips = [x1]
+    h = x1
+    for i in range(1, 5):
+        h = double_conv(F.max_pool2d(h, 2), state, f"down{i}.maxpool_conv.1", training)  # unet_parts.py:33-40
+        skips.append(h)
+    for i in range(1, 5):
+        h = up_block(h, skips[4 - i], state, f"up{i}.conv", training)
+    return F.conv2d(h, state["baseModel.out.conv.weight"], state["baseModel.out.conv.bias"])  # unet_parts.py:90-94
+
+
+def quantile_heads(feat, state):
+    """three 3x3 heads stacked on a new dim 1 -> [B,3,C,H,W], quantile_layer.py:19-21."""
+    outs = [F.conv2d(feat, state[f"last_layer.{h}.weight"], state[f"last_layer.{h}.bias"], padding=1)
+            for h in ("lower", "prediction", "upper")]
+    return torch.stack(outs, dim=1)
+
+
+def model_forward(x, state, training: bool = False):
+    """ModelWithUncertainty.forward, core/models/add_uncertainty.py:25-27."""
+    return quantile_heads(unet_forward(x, state, training), state)
+
+
+def pinball(output, target, q: float):
+    """core/models/losses/pinball.py:12-26 (mean reduction).
+    loss_i = q*|e| if e<0 ; (1-q)*|e| if e>0 ; 0 if e==0, e = output-target."""
+    err = output - target
+    a = err.abs()
+    loss = torch.where(err < 0, q * a, torch.where(err > 0, (1 - q) * a, torch.zeros_like(a)))
+    return loss.mean()
+
+
+def quantile_loss(pred, target, params):
+    """quantile_regression_loss_fn, quantile_layer.py:23-32.  pred [B,3,C,H,W], target [B,C,H,W]."""
+    t = target.squeeze()
+    return (params["q_lo_weight"] * pinball(pred[:, 0].squeeze(), t, params["q_lo"])
+            + params["q_hi_weight"] * pinball(pred[:, 2].squeeze(), t, params["q_hi"])
+            + params["mse_weight"] * F.mse_loss(pred[:, 1].squeeze(), t))
+
+
+# ----------------------------------------------------------------------------
+# deterministic closed-form initialisation shared by the golden generator, the
+# oracle tests and the HIP tests (so 69 MB of weights never need storing).
+def det_fill(key: str, shape: Tuple[int, ...]) -> torch.Tensor:
+    n = 1
+    for s in shape:
+        n *= s
+    seed = sum((i + 1) * ord(c) for i, c in enumerate(key)) % 9973
+    idx = torch.arange(n, dtype=torch.float64)
+    if key.endswith("num_batches_tracked"):
+        return torch.zeros((), dtype=torch.int64)
+    if key.endswith("running_mean"):
+        v = 0.05 * torch.sin(0.91 * idx + seed)
+    elif key.endswith("running_var"):
+        v = 1.0 + 0.25 * torch.cos(0.53 * idx + seed)
+    elif len(shape) == 4:  # conv weight: ~kaiming-uniform scale 1/sqrt(fan_in)
+        fan_in = shape[1] * shape[2] * shape[3]
+        v = math.sqrt(3.0 / fan_in) * torch.sin(0.618 * idx * (1 + (idx % 7)) + seed)
+    elif ".double_conv.1." in key or ".double_conv.4." in key:
+        if key.endswith("weight"):   # BN gamma
+            v = 1.0 + 0.2 * torch.cos(1.3 * idx + seed)
+        else:                        # BN beta
+            v = 0.1 * torch.sin(0.7 * idx + seed)
+    else:  # conv bias
+        v = 0.05 * torch.cos(0.37 * idx + seed)
+    return v.to(torch.float32).reshape(shape)
+
+
+def det_state(n_in: int = 1, n_out: int = 1) -> Dict[str, torch.Tensor]:
+    return {k: det_fill(k, shp) for k, shp in state_spec(n_in, n_out)}
+
+
+def det_images(n: int, c: int, h: int, w: int, salt: int = 0):
+    """deterministic (input, target) pair: target in [0,1], input = target + structured noise."""
+    idx = torch.arange(n * c * h * w, dtype=torch.float64).reshape(n, c, h, w)
+    y = 0.5 + 0.5 * torch.sin(0.013 * idx + 0.7 * salt) * torch.cos(0.0071 * idx * (1 + salt))
+    x = y + 0.1 * torch.sin(1.7 * idx + salt)
+    return x.to(torch.float32), y.to(torch.float32)
+
+
+# ----------------------------------------------------------------------------
+def train_steps(state, batches, params, lr: float):
+    """The inner loop of train_net, core/scripts/train.py:141-165: Adam with torch
+    defaults (train.py:120), loss -> zero_grad -> backward -> step.  ``state`` is
+    updated in place; returns the list of per-step losses."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in state.items() if is_param(k)}
+    work = dict(state)
+    work.update(leaves)
+    opt = torch.optim.Adam(list(leaves.values()), lr=lr)
+    losses = []
+    for x, y in batches:
+        pred = model_forward(x, work, training=True)
+        loss = quantile_loss(pred, y, params)
+        losses.append(float(loss.item()))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    for k, v in leaves.items():
+        state[k] = v.detach()
+    return losses
