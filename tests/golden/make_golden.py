@@ -1,0 +1,351 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz by IMPORTING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference); the reference never
+travels to the GPU box -- only the small .npz files written here do.  Each
+fixture holds inputs and the reference's outputs for one reference call site.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Fixture ids follow SURVEY.md section 8(c): G1..G11.
+"""
+import os
+import sys
+import types
+import io
+import contextlib
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("IM2IM_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+# wandb is absent in the image: in-memory no-op stub so core.scripts.{train,eval} import.
+wandb = types.ModuleType("wandb")
+wandb.init = lambda *a, **k: None
+wandb.log = lambda *a, **k: None
+wandb.watch = lambda *a, **k: None
+wandb.Image = lambda x: x
+wandb.config = {}
+sys.modules["wandb"] = wandb
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.utils.data import TensorDataset
+
+from core.models.losses.pinball import PinballLoss
+from core.models.finallayers.quantile_layer import quantile_regression_loss_fn
+from core.models.trunks.unet_parts import DoubleConv, Down, Up, OutConv
+from core.models.trunks.unet import UNet
+from core.models.add_uncertainty import add_uncertainty, ModelWithUncertainty
+from core.models.finallayers.quantile_layer import quantile_regression_nested_sets_from_output
+from core.calibration.calibrate_model import (calibrate_model, fraction_missed_loss,
+                                              get_rcps_metrics_from_outputs, get_rcps_losses_from_outputs)
+from core.calibration.bounds import HB_mu_plus
+from core.utils import fix_randomness
+import core.scripts.train as ref_train
+import core.scripts.eval as ref_eval
+
+from oracle import model as om
+from oracle import calibration as oc
+
+PARAMS = dict(uncertainty_type="quantiles", q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1,
+              alpha=0.1, delta=0.1, num_lambdas=50, rcps_loss="fraction_missed", minimum_lambda=0,
+              maximum_lambda=6, device="cpu", dataset="synthetic", batch_size=8, lr=1e-3,
+              input_normalization="standard", output_normalization="min-max", num_validation_images=2)
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path} ({os.path.getsize(path)} B)")
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+# ---------------------------------------------------------------- G1 / G2
+def g1_g2():
+    fix_randomness(0)
+    out = torch.randn(4, 16, 16)
+    tgt = torch.rand(4, 16, 16)
+    out[0, 0, :8] = tgt[0, 0, :8]           # exact ties e == 0
+    res = {"output": out, "target": tgt}
+    for q in (0.05, 0.95):
+        o = out.clone().requires_grad_(True)
+        l = PinballLoss(quantile=q)(o, tgt)
+        l.backward()
+        tag = str(q).replace(".", "")
+        res[f"loss_{tag}"] = l.detach()
+        res[f"grad_{tag}"] = o.grad
+    save("g1_pinball", **res)
+
+    pred = torch.randn(4, 3, 1, 16, 16) * 0.3 + 0.5
+    y = torch.rand(4, 1, 16, 16)
+    pred[1, 0, 0, 3, :5] = y[1, 0, 3, :5]
+    p = pred.clone().requires_grad_(True)
+    l = quantile_regression_loss_fn(p, y, PARAMS)
+    l.backward()
+    w = dict(PARAMS, q_lo_weight=0.5, q_hi_weight=2.0, mse_weight=3.0, q_lo=0.1, q_hi=0.8)
+    p2 = pred.clone().requires_grad_(True)
+    l2 = quantile_regression_loss_fn(p2, y, w)
+    l2.backward()
+    save("g2_quantile_loss", pred=pred, target=y, loss=l.detach(), grad=p.grad,
+         loss_w=l2.detach(), grad_w=p2.grad, w=np.array([0.5, 2.0, 3.0, 0.1, 0.8]))
+
+
+# ---------------------------------------------------------------- G3 parts
+def run_part(mod, inputs, train):
+    mod.train(train)
+    ins = [t.clone().requires_grad_(True) for t in inputs]
+    y = mod(*ins)
+    g = torch.cos(torch.arange(y.numel(), dtype=torch.float32).reshape(y.shape) * 0.37)  # fixed upstream grad
+    y.backward(g)
+    rec = {"y": y.detach(), "gy": g}
+    for i, t in enumerate(ins):
+        rec[f"x{i}"] = inputs[i]
+        rec[f"gx{i}"] = t.grad
+    for k, v in mod.state_dict().items():
+        rec["state_after." + k] = v.clone()
+    for k, v in mod.named_parameters():
+        rec["grad." + k] = v.grad.clone()
+    return rec
+
+
+def g3():
+    fix_randomness(0)
+    parts = {
+        "doubleconv": (DoubleConv(3, 8, 6), [torch.randn(2, 3, 16, 16)]),
+        "down": (Down(8, 16), [torch.randn(2, 8, 16, 16)]),
+        "up_bilinear": (Up(16, 8, True), [torch.randn(2, 8, 8, 8), torch.randn(2, 8, 16, 16)]),
+        "up_bilinear_pad": (Up(16, 8, True), [torch.randn(2, 8, 5, 6), torch.randn(2, 8, 11, 13)]),
+        "up_convT": (Up(16, 8, False), [torch.randn(2, 16, 8, 8), torch.randn(2, 8, 16, 16)]),
+        "outconv": (OutConv(8, 4), [torch.randn(2, 8, 16, 16)]),
+    }
+    for name, (mod, ins) in parts.items():
+        # non-trivial BN affine + running stats
+        with torch.no_grad():
+            for k, v in mod.state_dict().items():
+                if "running_var" in k:
+                    v.copy_(1 + 0.3 * torch.rand_like(v))
+                elif "running_mean" in k:
+                    v.copy_(0.2 * torch.randn_like(v))
+            for k, p in mod.named_parameters():
+                if p.dim() == 1:
+                    p.add_(0.2 * torch.randn_like(p))
+        init = {"state_before." + k: v.clone() for k, v in mod.state_dict().items()}
+        rec = dict(init)
+        for train in (True, False):
+            mod.load_state_dict({k[len("state_before."):]: v for k, v in init.items()})
+            mod.zero_grad()
+            r = run_part(mod, ins, train)
+            rec.update({("train." if train else "eval.") + k: v for k, v in r.items()})
+        save("g3_" + name, **rec)
+
+
+# ---------------------------------------------------------------- G4 / G5
+def build_ref_model(n_in=1):
+    model = add_uncertainty(UNet(n_in, 1), dict(PARAMS))
+    st = om.det_state(n_in, 1)
+    missing = model.load_state_dict(st, strict=True)
+    return model, st
+
+
+def g4():
+    for n_in, hw in ((1, 32), (2, 48)):
+        model, st = build_ref_model(n_in)
+        x, y = om.det_images(2, n_in, hw, hw, salt=1)
+        model.eval()
+        with torch.no_grad():
+            out_eval = model(x)
+        model.train()
+        out_train = model(x)
+        sd = model.state_dict()
+        save(f"g4_model_fwd_nin{n_in}", x=x, out_eval=out_eval, out_train=out_train.detach(),
+             rm_inc1=sd["baseModel.inc.double_conv.1.running_mean"],
+             rv_inc1=sd["baseModel.inc.double_conv.1.running_var"],
+             rm_up4=sd["baseModel.up4.conv.double_conv.4.running_mean"],
+             rv_up4=sd["baseModel.up4.conv.double_conv.4.running_var"],
+             nbt=sd["baseModel.inc.double_conv.1.num_batches_tracked"])
+
+
+def g5():
+    model, st = build_ref_model(1)
+    lr = 1e-3
+    opt = torch.optim.Adam(model.parameters(), lr=lr)     # train.py:120
+    model.train()
+    losses = []
+    xs, ys = [], []
+    for step in range(5):
+        x, y = om.det_images(4, 1, 32, 32, salt=step)
+        y = y[:, :1]
+        xs.append(x); ys.append(y)
+        pred = model(x)                                    # train.py:152
+        loss = model.loss_fn(pred, y)                      # train.py:153
+        losses.append(loss.item())
+        opt.zero_grad(); loss.backward(); opt.step()       # train.py:158-162
+    model.eval()
+    xp, _ = om.det_images(2, 1, 32, 32, salt=9)
+    with torch.no_grad():
+        probe = model(xp)
+    sd = model.state_dict()
+    keys = ["baseModel.inc.double_conv.0.weight", "baseModel.down4.maxpool_conv.1.double_conv.3.weight",
+            "baseModel.up1.conv.double_conv.0.weight", "baseModel.up4.conv.double_conv.4.weight",
+            "baseModel.up4.conv.double_conv.4.bias", "baseModel.out.conv.weight", "baseModel.out.conv.bias",
+            "last_layer.lower.weight", "last_layer.prediction.bias", "last_layer.upper.weight",
+            "baseModel.inc.double_conv.1.running_mean", "baseModel.up4.conv.double_conv.4.running_var"]
+    rec = {"losses": np.array(losses), "probe_x": xp, "probe_out": probe, "lr": np.array(lr)}
+    for k in keys:   # big tensors: float64 checksums + a strided sample, not the full 9 MB
+        flat = sd[k].flatten().double()
+        stride = max(1, flat.numel() // 512)
+        rec["sum." + k] = flat.sum()
+        rec["l2." + k] = flat.pow(2).sum().sqrt()
+        rec["sample." + k] = sd[k].flatten()[::stride][:512]
+    save("g5_adam_trajectory", **rec)
+
+
+# ---------------------------------------------------------------- G6
+def identity_model():
+    return ModelWithUncertainty(nn.Identity(), nn.Identity(), quantile_regression_loss_fn,
+                                quantile_regression_nested_sets_from_output, dict(PARAMS))
+
+
+def g6():
+    out, y = oc.synth_outputs(3, 1, 16, 16, seed=3)
+    out[0, 0, 0, 0, :4] = out[0, 1, 0, 0, :4] + 0.01      # lower above pred -> clamp path
+    out[0, 2, 0, 1, :4] = out[0, 1, 0, 1, :4] - 0.01      # upper below pred -> clamp path
+    m = identity_model()
+    lams = torch.tensor([-0.1224, 0.0, 1e-3, 0.5, 1.0, 2.5, 6.0, 40.0])
+    lows, ups = [], []
+    for lam in lams:
+        lo, mid, hi = m.nested_sets_from_output(out.clone(), lam)
+        lows.append(lo); ups.append(hi)
+    save("g6_nested_sets", output=out, lams=lams, lower=torch.stack(lows), upper=torch.stack(ups))
+
+
+# ---------------------------------------------------------------- G7
+def run_calib(out, y, cfg):
+    m = identity_model()
+    ds = TensorDataset(out.clone(), y.clone())
+    with quiet():
+        m, table = calibrate_model(m, ds, cfg)
+    # per-lambda trace (Rhat, RhatPlus) recomputed with the reference's own functions
+    lambdas = torch.linspace(cfg["minimum_lambda"], cfg["maximum_lambda"], cfg["num_lambdas"])
+    dl = lambdas[1] - lambdas[0]
+    trace = []
+    for j in range(len(lambdas) - 1, -1, -1):
+        with quiet():
+            losses = get_rcps_losses_from_outputs(m, TensorDataset(out.clone(), y.clone()), fraction_missed_loss,
+                                                  lambdas[j] - dl, "cpu")
+            rp = HB_mu_plus(losses.mean().item(), losses.shape[0], cfg["delta"])
+        trace.append((j, losses.mean().item(), rp))
+        if losses.mean() >= cfg["alpha"] or rp > cfg["alpha"]:
+            break
+    return m.lhat, table, np.array(trace, dtype=np.float64)
+
+
+def g7():
+    cases = {}
+    out, y = oc.synth_outputs(128, 1, 16, 16, seed=1)
+    cases["mid"] = (out, y, dict(PARAMS, batch_size=32, num_lambdas=100, maximum_lambda=20))
+    out, y = oc.synth_outputs(130, 1, 16, 16, seed=2)
+    cases["n130"] = (out, y, dict(PARAMS, batch_size=64, num_lambdas=50, maximum_lambda=6))
+    out, y = oc.synth_outputs(32, 1, 16, 16, seed=4, width=0.05)
+    y2 = out[:, 1].clone()                       # labels == pred: zero risk at every lambda (Q3)
+    cases["zero_risk"] = (out, y2, dict(PARAMS, batch_size=16, num_lambdas=20, maximum_lambda=6))
+    out, y = oc.synth_outputs(48, 1, 16, 16, seed=5)
+    cases["no_stop"] = (out, y, dict(PARAMS, batch_size=16, num_lambdas=10, minimum_lambda=50.0,
+                                     maximum_lambda=60.0, alpha=0.5, delta=0.5))
+    out, y = oc.synth_outputs(40, 2, 12, 20, seed=6)  # multi-channel, non-square
+    cases["c2"] = (out, y, dict(PARAMS, batch_size=16, num_lambdas=64, maximum_lambda=8))
+    for name, (out, y, cfg) in cases.items():
+        lhat, table, trace = run_calib(out, y, cfg)
+        save("g7_calibrate_" + name, output=out, label=y, lhat=lhat, table=table, trace=trace,
+             cfg=np.array([cfg["alpha"], cfg["delta"], cfg["num_lambdas"], cfg["minimum_lambda"],
+                           cfg["maximum_lambda"], cfg["batch_size"]], dtype=np.float64))
+
+
+# ---------------------------------------------------------------- G8
+def g8():
+    rows = []
+    with quiet():
+        for muhat, n, delta in [(0.1, 10000, 0.1), (0.05, 100, 0.1), (0.08, 347, 0.1), (0.5, 10, 0.1),
+                                (0.099, 3474, 0.1), (0.0, 50, 0.1), (1.0, 50, 0.1), (0.999, 200, 0.1)]:
+            rows.append((muhat, n, delta, HB_mu_plus(muhat, n, delta)))
+        rng = np.random.RandomState(0)
+        for n in (16, 128, 434, 3474, 27794):
+            for delta in (0.1, 0.01, 0.5):
+                for muhat in np.concatenate([rng.rand(6), rng.rand(4) * 0.12, [1.0 / n, 0.1, 0.0999]]):
+                    # muhat as the fp32-rounded value Rhat.item() would be
+                    mh = float(np.float32(muhat))
+                    rows.append((mh, n, delta, HB_mu_plus(mh, n, delta)))
+    save("g8_hb_bound", rows=np.array(rows, dtype=np.float64))
+
+
+# ---------------------------------------------------------------- G9 / G10
+class _Wrap(torch.utils.data.Dataset):
+    """map-style dataset of (model_output, label): with nn.Identity as the model this drives
+    get_loss_table / eval_set_metrics through their forward loops unchanged."""
+    def __init__(self, out, y):
+        self.out, self.y = out, y
+    def __len__(self):
+        return self.out.shape[0]
+    def __getitem__(self, i):
+        return self.out[i], self.y[i]
+
+
+def g9_g10():
+    out, y = oc.synth_outputs(22, 1, 16, 16, seed=7)
+    cfg = dict(PARAMS, num_lambdas=40, maximum_lambda=6)
+    m = identity_model()
+    with quiet():
+        table = ref_eval.get_loss_table(m, _Wrap(out.clone(), y), cfg)
+    save("g9_loss_table", output=out, label=y, table=table,
+         cfg=np.array([cfg["num_lambdas"], cfg["minimum_lambda"], cfg["maximum_lambda"]], dtype=np.float64))
+
+    out, y = oc.synth_outputs(70, 1, 16, 16, seed=8)
+    m = identity_model()
+    lhat = torch.tensor(1.25)
+    m.set_lhat(lhat)
+    fix_randomness(0)
+    with quiet():
+        losses, sizes, spearman, strat, mse, spatial = get_rcps_metrics_from_outputs(
+            m, TensorDataset(out.clone(), y), fraction_missed_loss, "cpu")
+    save("g10_metrics", output=out, label=y, lhat=lhat, losses=losses, spatial=spatial,
+         rng_sizes=sizes, rng_spearman=np.array(spearman), rng_strat=strat, rng_mse=np.array(mse))
+
+
+# ---------------------------------------------------------------- G11 end-to-end (config 1)
+def g11():
+    fix_randomness(0)
+    n_train, n_cal, n_val, hw = 8, 16, 4, 32
+    x, y = om.det_images(n_train + n_cal + n_val, 1, hw, hw, salt=3)
+    cfg = dict(PARAMS, batch_size=8, lr=1e-3, num_lambdas=50, maximum_lambda=6)
+    model, st = build_ref_model(1)
+    tr = TensorDataset(x[:n_train], y[:n_train])
+    ca = TensorDataset(x[n_train:n_train + n_cal], y[n_train:n_train + n_cal])
+    va = TensorDataset(x[n_train + n_cal:], y[n_train + n_cal:])
+    with quiet(), contextlib.redirect_stderr(io.StringIO()):
+        model = ref_train.train_net(model, tr, va, "cpu", 2, 8, 1e-3, False, None, 100, 100, cfg)
+        model.eval()
+        with torch.no_grad():
+            val_table = ref_eval.get_loss_table(model, va, cfg)
+            model, cal_table = calibrate_model(model, ca, cfg)
+            lo, mid, hi = model.nested_sets((x[n_train + n_cal:],))
+    save("g11_end_to_end", x=x, y=y, lhat=model.lhat, cal_table=cal_table, val_table=val_table,
+         lower=lo, pred=mid, upper=hi, split=np.array([n_train, n_cal, n_val]))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    g1_g2(); g3(); g4(); g5(); g6(); g7(); g8(); g9_g10(); g11()

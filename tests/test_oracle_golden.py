@@ -1,0 +1,155 @@
+"""Pin the CPU oracle (oracle/) against fixtures produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import calibration as oc
+from oracle import model as om
+from conftest import load_golden
+
+PARAMS = dict(q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1)
+T = torch.from_numpy
+
+
+def test_g1_pinball():
+    g = load_golden("g1_pinball")
+    for q, tag in ((0.05, "005"), (0.95, "095")):
+        o = T(g["output"]).clone().requires_grad_(True)
+        loss = om.pinball(o, T(g["target"]), q)
+        loss.backward()
+        assert loss.item() == pytest.approx(float(g[f"loss_{tag}"]), rel=1e-6)
+        np.testing.assert_allclose(o.grad.numpy(), g[f"grad_{tag}"], rtol=1e-6, atol=0)
+        assert (o.grad[0, 0, :8] == 0).all()          # exact ties contribute no gradient
+
+
+def test_g2_quantile_loss():
+    g = load_golden("g2_quantile_loss")
+    for params, lk, gk in ((PARAMS, "loss", "grad"),
+                           (dict(q_lo_weight=0.5, q_hi_weight=2.0, mse_weight=3.0, q_lo=0.1, q_hi=0.8), "loss_w", "grad_w")):
+        p = T(g["pred"]).clone().requires_grad_(True)
+        loss = om.quantile_loss(p, T(g["target"]), params)
+        loss.backward()
+        assert loss.item() == pytest.approx(float(g[lk]), rel=1e-6)
+        np.testing.assert_allclose(p.grad.numpy(), g[gk], rtol=1e-5, atol=1e-9)
+
+
+def _part_state(g, prefix):
+    st = {}
+    for k, v in g.items():
+        if k.startswith("state_before."):
+            st[k[len("state_before."):]] = T(v).clone()
+    return st
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_g3_doubleconv_down_up(mode):
+    training = mode == "train"
+    # DoubleConv
+    g = load_golden("g3_doubleconv")
+    st = {"baseModel.blk." + k: v for k, v in _part_state(g, "").items()}
+    y = om.double_conv(T(g[f"{mode}.x0"]), st, "blk", training)
+    np.testing.assert_allclose(y.numpy(), g[f"{mode}.y"], rtol=1e-4, atol=1e-5)
+    if training:
+        np.testing.assert_allclose(st["baseModel.blk.double_conv.1.running_mean"].numpy(),
+                                   g["train.state_after.double_conv.1.running_mean"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(st["baseModel.blk.double_conv.4.running_var"].numpy(),
+                                   g["train.state_after.double_conv.4.running_var"], rtol=1e-5, atol=1e-6)
+    # Down = maxpool + DoubleConv
+    g = load_golden("g3_down")
+    st = {"baseModel.blk." + k[len("maxpool_conv.1."):]: v for k, v in _part_state(g, "").items()}
+    y = om.double_conv(torch.nn.functional.max_pool2d(T(g[f"{mode}.x0"]), 2), st, "blk", training)
+    np.testing.assert_allclose(y.numpy(), g[f"{mode}.y"], rtol=1e-4, atol=1e-5)
+    # Up (bilinear), with and without odd-size padding
+    for name in ("g3_up_bilinear", "g3_up_bilinear_pad"):
+        g = load_golden(name)
+        st = {"baseModel.blk." + k[len("conv."):]: v for k, v in _part_state(g, "").items()}
+        y = om.up_block(T(g[f"{mode}.x0"]), T(g[f"{mode}.x1"]), st, "blk", training)
+        np.testing.assert_allclose(y.numpy(), g[f"{mode}.y"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("n_in", [1, 2])
+def test_g4_full_model_forward(n_in):
+    g = load_golden(f"g4_model_fwd_nin{n_in}")
+    st = om.det_state(n_in, 1)
+    x = T(g["x"])
+    with torch.no_grad():
+        out = om.model_forward(x, st, training=False)
+    np.testing.assert_allclose(out.numpy(), g["out_eval"], rtol=1e-4, atol=1e-5)
+    with torch.no_grad():
+        out = om.model_forward(x, st, training=True)
+    np.testing.assert_allclose(out.numpy(), g["out_train"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(st["baseModel.inc.double_conv.1.running_mean"].numpy(), g["rm_inc1"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(st["baseModel.up4.conv.double_conv.4.running_var"].numpy(), g["rv_up4"], rtol=1e-5, atol=1e-6)
+    assert int(st["baseModel.inc.double_conv.1.num_batches_tracked"]) == int(g["nbt"])
+
+
+def test_g4_state_spec_matches_reference_param_count():
+    n = sum(int(np.prod(s)) for k, s in om.state_spec(1, 1) if om.is_param(k))
+    assert n == 17_269_123          # BASELINE.md section 2, measured on the reference model
+
+
+def test_g5_adam_trajectory():
+    g = load_golden("g5_adam_trajectory")
+    st = om.det_state(1, 1)
+    batches = []
+    for step in range(5):
+        x, y = om.det_images(4, 1, 32, 32, salt=step)
+        batches.append((x, y))
+    losses = om.train_steps(st, batches, PARAMS, lr=float(g["lr"]))
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-4)
+    with torch.no_grad():
+        probe = om.model_forward(T(g["probe_x"]), st, training=False)
+    np.testing.assert_allclose(probe.numpy(), g["probe_out"], rtol=0, atol=5e-3)
+    k = "last_layer.upper.weight"
+    np.testing.assert_allclose(st[k].flatten().numpy()[::max(1, st[k].numel() // 512)][:512], g["sample." + k], atol=2e-4)
+
+
+def test_g6_nested_sets():
+    g = load_golden("g6_nested_sets")
+    out = T(g["output"])
+    for i, lam in enumerate(T(g["lams"])):
+        lo, mid, hi = oc.nested_sets(out, lam)
+        assert np.array_equal(lo.numpy(), g["lower"][i])
+        assert np.array_equal(hi.numpy(), g["upper"][i])
+
+
+def _cfg(v):
+    return dict(alpha=float(v[0]), delta=float(v[1]), num_lambdas=int(v[2]), minimum_lambda=float(v[3]),
+                maximum_lambda=float(v[4]), batch_size=int(v[5]))
+
+
+@pytest.mark.parametrize("case", ["mid", "n130", "zero_risk", "no_stop", "c2"])
+def test_g7_calibrate(case):
+    g = load_golden("g7_calibrate_" + case)
+    cfg = _cfg(g["cfg"])
+    lhat, table, trace = oc.calibrate_from_outputs(T(g["output"]), T(g["label"]), cfg)
+    assert np.array_equal(table.numpy(), g["table"])           # bit-exact, incl. zero columns (Q2)
+    assert float(lhat) == float(g["lhat"])
+    ref_trace = g["trace"]
+    assert len(trace) == len(ref_trace)
+    for (j, r, rp), (j2, r2, rp2) in zip(trace, ref_trace):
+        assert j == int(j2) and r == r2 and rp == pytest.approx(rp2, abs=1e-12)
+
+
+def test_g8_hb_bound():
+    rows = load_golden("g8_hb_bound")["rows"]
+    for muhat, n, delta, expect in rows:
+        got = oc.hb_mu_plus(muhat, int(n), delta)
+        assert got == pytest.approx(expect, abs=1e-12), (muhat, n, delta)
+    # the reference's only known-answer style check, core/calibration/bounds.py:46
+    assert oc.hb_mu_plus(0.1, 10000, 0.1) == pytest.approx(0.10551758004098838, abs=1e-12)
+
+
+def test_g9_loss_table():
+    g = load_golden("g9_loss_table")
+    cfg = dict(num_lambdas=int(g["cfg"][0]), minimum_lambda=float(g["cfg"][1]), maximum_lambda=float(g["cfg"][2]))
+    table = oc.loss_table_from_outputs(T(g["output"]), T(g["label"]), cfg)
+    assert np.array_equal(table.numpy(), g["table"])
+
+
+def test_g10_metrics():
+    g = load_golden("g10_metrics")
+    losses, spatial = oc.risk_and_miscoverage(T(g["output"]), T(g["label"]), T(g["lhat"]))
+    assert np.array_equal(losses.numpy(), g["losses"])
+    np.testing.assert_allclose(spatial, g["spatial"], rtol=1e-6, atol=1e-7)
