@@ -1,0 +1,70 @@
+"""ctypes binding of libim2im_uq.so (the C ABI in include/im2im_uq.h).
+
+There is no CPU fallback: if the library is missing, import of the product path fails loudly.
+PyTorch is used only as plumbing here (device memory, the current HIP stream).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libim2im_uq.so")
+
+
+class Im2ImError(RuntimeError):
+    pass
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP kernel library is not built. Run `python -m im2im_uq_amd.build` "
+            "(or __graft_entry__.build()). There is deliberately no CPU/PyTorch fallback.")
+    return ctypes.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+_i32, _i64, _f32, _f64, _ptr = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/im2im_uq.h declares (tests/test_abi.py)
+SIGNATURES = {
+    "im2im_abi_version": (_i32, []),
+    "im2im_last_error": (ctypes.c_char_p, []),
+    "im2im_rcps_loss_table": (_i32, [_ptr, _ptr, _i64, _i64, _ptr, _i32, _ptr, _ptr, _ptr, _ptr]),
+    "im2im_rcps_miscoverage": (_i32, [_ptr, _ptr, _i64, _i32, _i64, _f32, _ptr, _ptr]),
+    "im2im_nested_sets": (_i32, [_ptr, _i64, _i64, _f32, _ptr, _ptr, _i32, _ptr]),
+    "im2im_fraction_missed": (_i32, [_ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr]),
+    "im2im_hb_mu_plus": (_f64, [_f64, _i64, _f64, _i32]),
+}
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise Im2ImError(f"{what} failed (rc={rc}): {lib.im2im_last_error().decode()}")
+
+
+def stream_ptr(device=None) -> int:
+    """hipStream_t of torch's current stream (so torch ops and our kernels are stream-ordered)."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def dptr(t: torch.Tensor | None) -> int | None:
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def require_gpu(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise Im2ImError(f"{name}: expected a tensor on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if t.dtype != dtype:
+        raise Im2ImError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()

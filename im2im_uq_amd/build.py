@@ -1,0 +1,81 @@
+"""Build libim2im_uq.so (gfx950 HIP kernels + host C++ behind the C ABI in include/im2im_uq.h).
+
+In-tree build with explicit hipcc calls: objects under im2im_uq_amd/build/, the shared library at
+im2im_uq_amd/lib/libim2im_uq.so (git-ignored, but shipped to the GPU box by gpurun).
+hipcc cross-compiles for gfx950 without a GPU.
+
+    python -m im2im_uq_amd.build [--force]
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(PKG, "build")
+LIB = os.path.join(PKG, "lib", "libim2im_uq.so")
+ARCH = "gfx950"
+
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+# per-source extra flags.  rcps.hip: the reference's CPU path never fuses mul+add.
+SOURCES = {
+    "common.cpp": [],
+    "hb_bound.cpp": ["-ffp-contract=off"],
+    "rcps.hip": ["-ffp-contract=off"],
+}
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _deps_mtime() -> float:
+    t = os.path.getmtime(os.path.join(os.path.dirname(PKG), "include", "im2im_uq.h"))
+    for f in os.listdir(CSRC):
+        if f.endswith(".h"):
+            t = max(t, os.path.getmtime(os.path.join(CSRC, f)))
+    return max(t, os.path.getmtime(os.path.abspath(__file__)))
+
+
+def _compile(src: str, flags, force: bool, hdr_t: float) -> str:
+    path = os.path.join(CSRC, src)
+    obj = os.path.join(OBJ, src + ".o")
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), hdr_t):
+        return obj
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", *COMMON, *flags, "-c", path, "-o", obj]
+    if src.endswith(".cpp"):
+        cmd.insert(1, "-x"); cmd.insert(2, "hip")
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    hdr_t = _deps_mtime()
+    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+        objs = list(ex.map(lambda kv: _compile(kv[0], kv[1], force, hdr_t), SOURCES.items()))
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[im2im_uq_amd.build] linked {LIB}")
+    elif verbose:
+        print(f"[im2im_uq_amd.build] up to date: {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

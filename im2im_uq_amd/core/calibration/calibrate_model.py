@@ -1,0 +1,256 @@
+"""RCPS calibration on MI355X -- drop-in for the reference's core/calibration/calibrate_model.py.
+
+Same public functions and return conventions as the reference; what changes is where the
+arithmetic runs:
+
+  * model outputs of the calibration set stay resident in HBM (the reference round-trips them
+    through host memory and re-uploads 16 B/pixel for every lambda, calibrate_model.py:111-123,
+    :21-29);
+  * the whole [N, num_lambdas] loss table comes from ONE pass of the HIP scoring kernel
+    (csrc/rcps.hip) instead of one elementwise pass per lambda;
+  * the descending Hoeffding-Bentkus scan (calibrate_model.py:134-144) then runs on the host over
+    that table, with the reference's quirks kept: the `lam - dlambda` shift, zero columns left of
+    the break, `Rhat >= alpha or RhatPlus > alpha`, default lhat = last + dlambda - 1e-9;
+  * with torch.distributed initialised the calibration set is sharded by contiguous index range
+    per rank and the table rows are all-gathered (RCCL) so every rank runs the identical scan and
+    lands on the identical lhat.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from scipy.stats import spearmanr
+from torch.utils.data import DataLoader, Subset, TensorDataset
+
+from .. import _pkg  # noqa: F401
+from ... import hip_ops
+from .bounds import HB_mu_plus
+
+
+# ------------------------------------------------------------------ distributed helpers
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist
+    return None
+
+
+def shard_bounds(n: int, rank: int, world: int):
+    """contiguous index range of `rank` (row order of the gathered table == dataset order)."""
+    per = (n + world - 1) // world
+    lo = min(rank * per, n)
+    return lo, min(lo + per, n)
+
+
+def gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
+    """all-gather [n_local, ...] row blocks (contiguous shards, possibly ragged) -> [n_total, ...]."""
+    dist = _dist()
+    if dist is None:
+        return local
+    world = dist.get_world_size()
+    per = (n_total + world - 1) // world
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    rows = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_total, r, world)
+        rows.append(parts[r][: hi - lo])
+    return torch.cat(rows, dim=0)
+
+
+# ------------------------------------------------------------------ losses
+def fraction_missed_loss(pset, label):
+    """Per-image fraction of pixels outside [lower, upper] (reference :76-80).  pset = (lower, pred, upper).
+    A batch of one image returns shape [1] (the reference's squeeze returns [H] there)."""
+    lower, upper = pset[0], pset[2]
+    return hip_ops.fraction_missed(lower, upper, label.to(lower.device, torch.float32))
+
+
+def get_rcps_loss_fn(config):
+    string = config['rcps_loss']
+    if string == 'fraction_missed':
+        return fraction_missed_loss
+    else:
+        raise NotImplementedError
+
+
+def _as_device_pair(out_dataset, device):
+    outputs, labels = out_dataset.tensors
+    return (outputs.to(device=device, dtype=torch.float32).contiguous(),
+            labels.to(device=device, dtype=torch.float32).contiguous())
+
+
+def get_rcps_losses_from_outputs(model, out_dataset, rcps_loss_fn, lam, device):
+    """Losses [N] (cpu) of every image at ONE lambda (reference :21-29)."""
+    outputs, labels = _as_device_pair(out_dataset, device)
+    if rcps_loss_fn is fraction_missed_loss:
+        lam_t = torch.as_tensor(lam, dtype=torch.float32).reshape(1)
+        return hip_ops.rcps_loss_table(outputs, labels, lam_t)[:, 0].cpu()
+    model = model.to(device)
+    losses = []
+    for s in range(0, outputs.shape[0], 64):          # user-supplied loss: same batching as the reference
+        sets = model.nested_sets_from_output(outputs[s:s + 64].clone(), lam)
+        losses.append(rcps_loss_fn(sets, labels[s:s + 64]).cpu())
+    return torch.cat(losses, dim=0)
+
+
+def get_rcps_losses(model, dataset, rcps_loss_fn, lam, device):
+    """The reference's version of this (:13-19) is dead code referencing an undefined name; this one
+    runs the model over (input, label) pairs and scores them at `lam`."""
+    outputs, labels = collect_outputs(model, dataset, {'batch_size': 64, 'dataset': None}, device, shard=False)
+    return get_rcps_losses_from_outputs(model, TensorDataset(outputs, labels), rcps_loss_fn, lam, device)
+
+
+def get_rcps_metrics_from_outputs(model, out_dataset, rcps_loss_fn, device):
+    """Metrics at the model's calibrated lhat (reference :31-60).  Returns
+    (losses[N], sizes[N], spearman, stratified_risks[4], mse, spatial_miscoverage[H,W]).
+    numpy/torch RNG is consumed in the reference's order (one np.random.choice per batch of 64, then one
+    torch.rand), so with the same seed the sampled-pixel statistics are the reference's."""
+    outputs, labels = _as_device_pair(out_dataset, device)
+    model = model.to(device)
+    if model.lhat is None:
+        raise Exception("You have to specify lambda unless your model is already calibrated.")
+    lhat = float(model.lhat)
+    n = outputs.shape[0]
+    losses = hip_ops.rcps_loss_table(outputs, labels, torch.tensor([lhat], dtype=torch.float32))[:, 0]
+    # one random pixel per image: interval size and |residual| (reference :43-46)
+    p = outputs[0, 0].numel()
+    idx = np.concatenate([np.random.choice(p, size=min(64, n - s)) for s in range(0, n, 64)]) if n else np.zeros(0, int)
+    idx_t = torch.from_numpy(idx).to(device)
+    rows = torch.arange(n, device=device)
+    picked = outputs.flatten(start_dim=2)[rows, :, idx_t].reshape(n, 3, 1).contiguous()        # [N,3,1]
+    lo, mid, up = hip_ops.nested_sets(picked, lhat)
+    sizes = (up - lo).reshape(n).cpu()
+    residuals = (labels.flatten(start_dim=1)[rows, idx_t] - mid.reshape(n)).abs()
+    # the reference iterates one DataLoader here, whose iterator draws its base seed from torch's default
+    # generator (one int64 random_()); consume the same draw so the jitter below is the reference's.
+    torch.empty((), dtype=torch.int64).random_()
+    sizes = sizes + torch.rand(size=sizes.shape).to(sizes.device) * 1e-6
+    residuals = residuals.detach().cpu().numpy()
+    spearman = spearmanr(residuals, sizes)[0]
+    mse = (residuals * residuals).mean().item()
+    c = outputs.shape[2]
+    counts = hip_ops.rcps_miscoverage(outputs, labels, lhat).reshape((c,) + tuple(outputs.shape[3:]))
+    # reference: float32 mean over images, then float32 mean over the channel axis (:55)
+    spatial_miscoverage = (counts.cpu().numpy().astype(np.float32) / np.float32(n)).mean(axis=0)
+    size_bins = torch.tensor([0, torch.quantile(sizes, 0.25), torch.quantile(sizes, 0.5), torch.quantile(sizes, 0.75)])
+    buckets = torch.bucketize(sizes, size_bins) - 1
+    losses_cpu = losses.cpu()
+    stratified_risks = torch.tensor([losses_cpu[buckets == bucket].mean() for bucket in range(size_bins.shape[0])])
+    return losses_cpu, sizes, spearman, stratified_risks, mse, spatial_miscoverage
+
+
+def evaluate_from_loss_table(loss_table, n, alpha, delta):
+    """Monte-Carlo re-split of a saved loss table (reference :62-74; note it compares against `delta`)."""
+    with torch.no_grad():
+        perm = torch.randperm(loss_table.shape[0])
+        loss_table = loss_table[perm]
+        calib_table, val_table = loss_table[:n], loss_table[n:]
+        Rhats = calib_table.mean(dim=0)
+        RhatPlus = torch.tensor([HB_mu_plus(Rhat, n, delta) for Rhat in Rhats])
+        try:
+            idx_lambda = (RhatPlus <= delta).nonzero()[0]
+        except Exception:
+            print("No rejections made!")
+            idx_lambda = 0
+        return val_table[:, idx_lambda].mean()
+
+
+# ------------------------------------------------------------------ phase A: outputs into HBM
+def collect_outputs(model, dataset, config, device, shard=True):
+    """Eval-mode forward over `dataset`; returns (outputs [n,K,C,H,W], labels [n,C,H,W]) resident on
+    `device`.  With torch.distributed active and shard=True only this rank's contiguous slice is run."""
+    dist = _dist() if shard else None
+    if config.get('dataset') == 'temca':                      # iterable dataset, one sample at a time (:106-109)
+        samples = [s for s in iter(dataset)]
+        if dist is not None:
+            lo, hi = shard_bounds(len(samples), dist.get_rank(), dist.get_world_size())
+            samples = samples[lo:hi]
+        labels = torch.cat([s[1].unsqueeze(0) for s in samples], dim=0).to(device, torch.float32)
+        outputs = torch.cat([model(s[0].unsqueeze(0).to(device, torch.float32)) for s in samples], dim=0)
+        return outputs.contiguous(), labels.contiguous()
+    n_total = len(dataset)
+    if dist is not None:
+        lo, hi = shard_bounds(n_total, dist.get_rank(), dist.get_world_size())
+        dataset = Subset(dataset, range(lo, hi))
+    n = len(dataset)
+    outputs = labels = None
+    counter = 0
+    loader = DataLoader(dataset, num_workers=0, batch_size=config['batch_size'], pin_memory=True)
+    for batch in loader:
+        out = model(batch[0].to(device=device, dtype=torch.float32))
+        if outputs is None:
+            outputs = torch.empty((n,) + tuple(out.shape[1:]), dtype=torch.float32, device=device)
+            labels = torch.empty((n,) + tuple(batch[1].shape[1:]), dtype=torch.float32, device=device)
+        b = out.shape[0]
+        outputs[counter:counter + b] = out
+        labels[counter:counter + b] = batch[1].to(device=device, dtype=torch.float32)
+        counter += b
+    if outputs is None:
+        raise ValueError("calibration dataset (shard) is empty")
+    return outputs, labels
+
+
+def lambda_grid(config):
+    if config["uncertainty_type"] == "softmax":
+        return torch.linspace(config['minimum_lambda_softmax'], config['maximum_lambda_softmax'], config['num_lambdas'])
+    return torch.linspace(config['minimum_lambda'], config['maximum_lambda'], config['num_lambdas'])
+
+
+def scan_loss_table(table_cpu, lambdas, alpha, delta):
+    """Host half of the reference's lambda loop (:130-144) over a full [N,L] table whose column j holds
+    the losses at lambdas[j] - dlambda.  Returns (lhat, calib_loss_table with unvisited columns zero, trace)."""
+    n, L = table_cpu.shape
+    dlambda = lambdas[1] - lambdas[0]
+    lhat = lambdas[-1] + dlambda - 1e-9
+    cols = table_cpu.t().contiguous()                         # row j = contiguous [N] losses, as torch.cat builds them
+    calib_loss_table = torch.zeros((n, L))
+    trace = []
+    for j in range(L - 1, -1, -1):
+        lam = lambdas[j]
+        losses = cols[j]
+        calib_loss_table[:, j] = losses
+        Rhat = losses.mean()
+        RhatPlus = HB_mu_plus(Rhat.item(), n, delta)
+        trace.append((j, Rhat.item(), RhatPlus))
+        if Rhat >= alpha or RhatPlus > alpha:
+            lhat = lam
+            break
+    return lhat, calib_loss_table, trace
+
+
+def calibrate_model(model, dataset, config):
+    """model, calib_loss_table[N, num_lambdas] = calibrate_model(model, dataset, config)  (reference :89-145)."""
+    with torch.no_grad():
+        print("Calibrating...")
+        model.eval()
+        alpha = config['alpha']
+        delta = config['delta']
+        device = config['device']
+        lambdas = lambda_grid(config)
+        rcps_loss_fn = get_rcps_loss_fn(config)
+        model = model.to(device)
+        n_total = len(dataset) if config.get('dataset') != 'temca' else None
+        outputs, labels = collect_outputs(model, dataset, config, device)
+        dlambda = lambdas[1] - lambdas[0]
+        model.set_lhat(lambdas[-1] + dlambda - 1e-9)
+        if rcps_loss_fn is fraction_missed_loss:
+            table = hip_ops.rcps_loss_table(outputs, labels, lambdas - dlambda)       # one pass, all lambdas
+        else:                                                 # plugin loss: per-lambda, still device-resident
+            ds = TensorDataset(outputs, labels)
+            table = torch.stack([get_rcps_losses_from_outputs(model, ds, rcps_loss_fn, lam - dlambda, device)
+                                 for lam in lambdas], dim=1).to(device)
+        if _dist() is not None:
+            if n_total is None:
+                cnt = torch.tensor([table.shape[0]], device=table.device)
+                _dist().all_reduce(cnt)
+                n_total = int(cnt.item())
+            table = gather_rows(table, n_total)
+        lhat, calib_loss_table, trace = scan_loss_table(table.cpu(), lambdas, alpha, delta)
+        model.set_lhat(lhat)
+        j, rhat, rhat_plus = trace[-1]
+        print(f"Lambda: {float(lambdas[j]):.4f}  |  Rhat: {rhat:.4f}  |  RhatPlus: {rhat_plus:.4f}")
+        print(f"Model's lhat set to {model.lhat}")
+        return model, calib_loss_table

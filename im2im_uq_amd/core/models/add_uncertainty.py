@@ -1,0 +1,73 @@
+"""Plugin boundary -- drop-in for the reference's core/models/add_uncertainty.py.
+
+`add_uncertainty(trunk, params)` wraps a trunk (needs `n_channels_middle`, `n_channels_out`) with a
+final layer chosen by params["uncertainty_type"] and returns a ModelWithUncertainty exposing the same
+API as the reference (:15-49): forward, loss_fn, nested_sets_from_output, nested_sets, set_lhat,
+buffer `lhat`, attributes baseModel / last_layer / params.  state_dict keys are the reference's.
+
+Scope of this build: "quantiles" is implemented on HIP kernels; the other six
+heuristics are out of scope for now and raise NotImplementedError naming themselves.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _pkg  # noqa: F401
+from ... import hip_ops
+from .finallayers.quantile_layer import (QuantileRegressionLayer, quantile_regression_loss_fn,
+                                         quantile_regression_nested_sets_from_output)
+
+
+class ModelWithUncertainty(nn.Module):
+    def __init__(self, baseModel, last_layer, in_train_loss_fn, in_nested_sets_from_output_fn, params):
+        super(ModelWithUncertainty, self).__init__()
+        self.baseModel = baseModel
+        self.last_layer = last_layer
+        self.register_buffer('lhat', None)
+        self.in_train_loss_fn = in_train_loss_fn
+        self.in_nested_sets_from_output_fn = in_nested_sets_from_output_fn
+        self.params = params
+
+    def forward(self, x):
+        x = self.baseModel(x)
+        return self.last_layer(x)
+
+    def loss_fn(self, pred, target):
+        return self.in_train_loss_fn(pred, target, self.params)
+
+    def nested_sets_from_output(self, output, lam=None):
+        """(lower_edge, prediction, upper_edge) with the +-1e-6 floor (reference :33-38)."""
+        if self.in_nested_sets_from_output_fn is quantile_regression_nested_sets_from_output and output.is_cuda:
+            # fused HIP path: clamp, scale and floor in one kernel (identical fp32 op order)
+            return quantile_regression_nested_sets_from_output(self, output, lam, _floor=True)
+        lower_edge, prediction, upper_edge = self.in_nested_sets_from_output_fn(self, output, lam)
+        upper_edge = torch.maximum(upper_edge, prediction + 1e-6)
+        lower_edge = torch.minimum(lower_edge, prediction - 1e-6)
+        return lower_edge, prediction, upper_edge
+
+    def nested_sets(self, x, lam=None):
+        if lam == None:
+            if self.lhat == None:
+                raise Exception("You have to specify lambda unless your model is already calibrated.")
+            lam = self.lhat
+        output = self(*x)
+        return self.nested_sets_from_output(output, lam=lam)
+
+    def set_lhat(self, lhat):
+        self.lhat = lhat
+
+
+_OUT_OF_SCOPE = ("quantiles_l1", "gaussian", "residual_magnitude", "residual_magnitude_l1", "softmax", "inn")
+
+
+def add_uncertainty(model, params):
+    if params["uncertainty_type"] == "quantiles":
+        last_layer = QuantileRegressionLayer(model.n_channels_middle, model.n_channels_out, params)
+        train_loss_fn = quantile_regression_loss_fn
+        nested_sets_from_output_fn = quantile_regression_nested_sets_from_output
+    elif params["uncertainty_type"] in _OUT_OF_SCOPE:
+        raise NotImplementedError(
+            f"uncertainty_type={params['uncertainty_type']!r} is outside this build's hot-path scope "
+            "(SURVEY.md section 8f, rank 1); only 'quantiles' runs on the HIP kernels so far")
+    else:
+        raise NotImplementedError
+    return ModelWithUncertainty(model, last_layer, train_loss_fn, nested_sets_from_output_fn, params)

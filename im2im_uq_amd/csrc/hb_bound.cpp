@@ -1,0 +1,136 @@
+// Hoeffding-Bentkus upper confidence bound on a [0,1] mean, host float64.
+//
+// Replaces HB_mu_plus (core/calibration/bounds.py:17-29) and its helpers h1 (:6-7),
+// hoeffding_plus (:10-11), bentkus_plus (:13-14).  The reference reaches scipy for the two
+// non-trivial pieces; both are restated here from their published algorithms:
+//   * binom.cdf(k, n, p) = I_{1-p}(n-k, k+1), the regularised incomplete beta function,
+//     evaluated by the modified-Lentz continued fraction (DLMF 8.17.22) with an lgamma prefactor;
+//   * scipy.optimize.brentq = Brent's 1973 bracketing root finder (inverse quadratic / secant /
+//     bisection) with scipy's default xtol = 2e-12, rtol = 4*eps.
+// Python-level semantics that matter are kept: builtin min/max NaN behaviour, and "any solver
+// exception -> 1.0" (NaN function value, same-sign bracket, no convergence).
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include "../../include/im2im_uq.h"
+
+namespace {
+
+// continued fraction for I_x(a,b), valid/fast for x < (a+1)/(a+b+2)
+double betacf(double a, double b, double x) {
+  const double tiny = 1e-300, eps = 1e-16;
+  double qab = a + b, qap = a + 1.0, qam = a - 1.0;
+  double c = 1.0, d = 1.0 - qab * x / qap;
+  if (std::fabs(d) < tiny) d = tiny;
+  d = 1.0 / d;
+  double h = d;
+  for (int m = 1; m <= 100000; ++m) {
+    double m2 = 2.0 * m;
+    double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+    d = 1.0 + aa * d; if (std::fabs(d) < tiny) d = tiny;
+    c = 1.0 + aa / c; if (std::fabs(c) < tiny) c = tiny;
+    d = 1.0 / d; h *= d * c;
+    aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+    d = 1.0 + aa * d; if (std::fabs(d) < tiny) d = tiny;
+    c = 1.0 + aa / c; if (std::fabs(c) < tiny) c = tiny;
+    d = 1.0 / d;
+    double del = d * c;
+    h *= del;
+    if (std::fabs(del - 1.0) < eps) break;
+  }
+  return h;
+}
+
+// regularised incomplete beta I_x(a,b), a,b > 0, 0 <= x <= 1
+double ibeta(double a, double b, double x) {
+  if (x <= 0.0) return 0.0;
+  if (x >= 1.0) return 1.0;
+  double lbt = std::lgamma(a + b) - std::lgamma(a) - std::lgamma(b) + a * std::log(x) + b * std::log1p(-x);
+  double bt = std::exp(lbt);
+  if (x < (a + 1.0) / (a + b + 2.0)) return bt * betacf(a, b, x) / a;
+  return 1.0 - bt * betacf(b, a, 1.0 - x) / b;
+}
+
+// scipy.stats.binom.cdf(k, n, p) for real k (already floored), integer n
+double binom_cdf(double k, double n, double p) {
+  if (std::isnan(k) || std::isnan(p)) return std::numeric_limits<double>::quiet_NaN();
+  if (k < 0) return 0.0;
+  if (k >= n) return 1.0;
+  if (p <= 0.0) return 1.0;
+  if (p >= 1.0) return 0.0;
+  return ibeta(n - k, k + 1.0, 1.0 - p);
+}
+
+inline double py_min(double a, double b) { return (b < a) ? b : a; }  // builtin min(a, b)
+inline double py_max(double a, double b) { return (b > a) ? b : a; }  // builtin max(a, b)
+
+struct Tail {
+  double muhat, n, log_delta;
+  // _tailprob, bounds.py:18-21
+  double operator()(double mu) const {
+    double y = std::fmin(mu, muhat);                       // np.minimum(mu, x)  (bounds.py:11)
+    if (std::isnan(mu) || std::isnan(muhat)) y = std::numeric_limits<double>::quiet_NaN();
+    double h1 = y * std::log(y / mu) + (1.0 - y) * std::log((1.0 - y) / (1.0 - mu));   // bounds.py:7
+    double hoeffding = -n * h1;
+    double bentkus = std::log(py_max(binom_cdf(std::floor(n * muhat), n, mu), 1e-10)) + 1.0;  // bounds.py:14
+    return py_min(hoeffding, bentkus) - log_delta;
+  }
+};
+
+// Brent's method as scipy.optimize.brentq runs it; ok=false stands for "scipy raised".
+double brentq(const Tail& f, double xa, double xb, double xtol, double rtol, int maxiter, bool& ok) {
+  ok = false;
+  double xpre = xa, xcur = xb, xblk = 0.0, fblk = 0.0, spre = 0.0, scur = 0.0;
+  double fpre = f(xpre), fcur = f(xcur);
+  if (std::isnan(fpre) || std::isnan(fcur)) return 0.0;     // "function value is NaN; solver cannot continue"
+  if (fpre == 0.0) { ok = true; return xpre; }
+  if (fcur == 0.0) { ok = true; return xcur; }
+  if (std::signbit(fpre) == std::signbit(fcur)) return 0.0;  // "f(a) and f(b) must have different signs"
+  for (int i = 0; i < maxiter; ++i) {
+    if (fpre != 0.0 && fcur != 0.0 && std::signbit(fpre) != std::signbit(fcur)) {
+      xblk = xpre; fblk = fpre; spre = scur = xcur - xpre;
+    }
+    if (std::fabs(fblk) < std::fabs(fcur)) {
+      xpre = xcur; xcur = xblk; xblk = xpre;
+      fpre = fcur; fcur = fblk; fblk = fpre;
+    }
+    double delta = (xtol + rtol * std::fabs(xcur)) / 2.0;
+    double sbis = (xblk - xcur) / 2.0;
+    if (fcur == 0.0 || std::fabs(sbis) < delta) { ok = true; return xcur; }
+    if (std::fabs(spre) > delta && std::fabs(fcur) < std::fabs(fpre)) {
+      double stry;
+      if (xpre == xblk) {
+        stry = -fcur * (xcur - xpre) / (fcur - fpre);                       // secant
+      } else {
+        double dpre = (fpre - fcur) / (xpre - xcur);                        // inverse quadratic
+        double dblk = (fblk - fcur) / (xblk - xcur);
+        stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+      }
+      if (2.0 * std::fabs(stry) < std::fmin(std::fabs(spre), 3.0 * std::fabs(sbis) - delta)) {
+        spre = scur; scur = stry;
+      } else {
+        spre = sbis; scur = sbis;
+      }
+    } else {
+      spre = sbis; scur = sbis;
+    }
+    xpre = xcur; fpre = fcur;
+    if (std::fabs(scur) > delta) xcur += scur;
+    else xcur += (sbis > 0 ? delta : -delta);
+    fcur = f(xcur);
+    if (std::isnan(fcur)) return 0.0;
+  }
+  return 0.0;  // "Failed to converge"
+}
+
+}  // namespace
+
+extern "C" double im2im_hb_mu_plus(double muhat, int64_t n, double delta, int32_t maxiters) {
+  Tail f{muhat, (double)n, std::log(delta)};
+  const double hi = 1.0 - 1e-10;
+  double fhi = f(hi);
+  if (fhi > 0.0) return 1.0;                                 // bounds.py:22-23 (NaN > 0 is False)
+  bool ok = false;
+  double root = brentq(f, muhat, hi, 2e-12, 4.0 * std::numeric_limits<double>::epsilon(), maxiters, ok);
+  return ok ? root : 1.0;                                    // bounds.py:25-29
+}

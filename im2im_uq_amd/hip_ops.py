@@ -1,0 +1,89 @@
+"""Thin tensor-level wrappers over the C ABI (include/im2im_uq.h).
+
+Each wrapper validates device/dtype/contiguity, allocates outputs with torch (plumbing), and
+launches the HIP kernel on torch's current stream.  No wrapper has a non-HIP fallback.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import check, dptr, lib, require_gpu, stream_ptr
+
+F32 = torch.float32
+
+
+# ------------------------------------------------------------------ calibration (K11-K14)
+def rcps_loss_table(outputs: torch.Tensor, labels: torch.Tensor, lam: torch.Tensor, want_counts: bool = False):
+    """outputs [N,3,C,H,W] fp32, labels [N,C,H,W] fp32 (GPU); lam [L] fp32 ascending (any device).
+    Returns table [N,L] fp32 on the GPU (and int32 counts if asked): one pass over HBM for all lambdas."""
+    outputs = require_gpu(outputs, F32, "outputs")
+    labels = require_gpu(labels, F32, "labels")
+    if outputs.dim() < 3 or outputs.shape[1] != 3:
+        raise _lib.Im2ImError(f"outputs must be [N,3,...], got {tuple(outputs.shape)}")
+    n = outputs.shape[0]
+    p = outputs[0, 0].numel() if n else int(torch.tensor(outputs.shape[2:]).prod())
+    if labels.numel() != n * p:
+        raise _lib.Im2ImError(f"labels {tuple(labels.shape)} do not match outputs {tuple(outputs.shape)}")
+    lam_cpu = lam.detach().to("cpu", F32).contiguous()
+    if lam_cpu.dim() != 1 or lam_cpu.numel() < 1:
+        raise _lib.Im2ImError("lam must be a non-empty 1-D grid")
+    if lam_cpu.numel() > 1 and bool((lam_cpu[1:] < lam_cpu[:-1]).any()):
+        raise _lib.Im2ImError("lam grid must be ascending (the one-pass scoring relies on monotone edges)")
+    L = lam_cpu.numel()
+    dev = outputs.device
+    lam_dev = lam_cpu.to(dev)
+    hist = torch.empty((n, L + 1), dtype=torch.int32, device=dev)
+    table = torch.empty((n, L), dtype=F32, device=dev)
+    counts = torch.empty((n, L), dtype=torch.int32, device=dev) if want_counts else None
+    with torch.cuda.device(dev):
+        check(lib.im2im_rcps_loss_table(dptr(outputs), dptr(labels), n, p, dptr(lam_dev), L, dptr(hist), dptr(table),
+                                        dptr(counts), stream_ptr(dev)), "im2im_rcps_loss_table")
+    return (table, counts) if want_counts else table
+
+
+def rcps_miscoverage(outputs: torch.Tensor, labels: torch.Tensor, lam: float) -> torch.Tensor:
+    """int32 [C, H*W] counts of (label > upper) + (label < lower) over images at one lambda."""
+    outputs = require_gpu(outputs, F32, "outputs")
+    labels = require_gpu(labels, F32, "labels")
+    n, three, c = outputs.shape[0], outputs.shape[1], outputs.shape[2]
+    hw = outputs[0, 0, 0].numel()
+    out = torch.empty((c, hw), dtype=torch.int32, device=outputs.device)
+    with torch.cuda.device(outputs.device):
+        check(lib.im2im_rcps_miscoverage(dptr(outputs), dptr(labels), n, c, hw, float(lam), dptr(out),
+                                         stream_ptr(outputs.device)), "im2im_rcps_miscoverage")
+    return out
+
+
+def nested_sets(output: torch.Tensor, lam: float, clamp_inplace: bool = True):
+    """output [N,3,...] fp32 GPU -> (lower_edge, prediction view, upper_edge), each [N,...]."""
+    if not output.is_contiguous():
+        raise _lib.Im2ImError("nested_sets: output must be contiguous (it is clamped in place like the reference)")
+    require_gpu(output, F32, "output")
+    n = output.shape[0]
+    p = output[0, 0].numel()
+    lower = torch.empty(output.shape[:1] + output.shape[2:], dtype=F32, device=output.device)
+    upper = torch.empty_like(lower)
+    with torch.cuda.device(output.device):
+        check(lib.im2im_nested_sets(dptr(output), n, p, float(lam), dptr(lower), dptr(upper), int(clamp_inplace),
+                                    stream_ptr(output.device)), "im2im_nested_sets")
+    return lower, output[:, 1], upper
+
+
+def fraction_missed(lower: torch.Tensor, upper: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+    lower = require_gpu(lower, F32, "lower")
+    upper = require_gpu(upper, F32, "upper")
+    label = require_gpu(label, F32, "label")
+    n = lower.shape[0]
+    p = lower[0].numel()
+    if upper.numel() != n * p or label.numel() != n * p:
+        raise _lib.Im2ImError("fraction_missed: shape mismatch")
+    loss = torch.empty((n,), dtype=F32, device=lower.device)
+    with torch.cuda.device(lower.device):
+        check(lib.im2im_fraction_missed(dptr(lower), dptr(upper), dptr(label), n, p, dptr(loss), stream_ptr(lower.device)),
+              "im2im_fraction_missed")
+    return loss
+
+
+def hb_mu_plus(muhat: float, n: int, delta: float, maxiters: int = 1000) -> float:
+    return float(lib.im2im_hb_mu_plus(float(muhat), int(n), float(delta), int(maxiters)))

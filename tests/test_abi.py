@@ -1,0 +1,64 @@
+"""CPU checks on the C-ABI boundary: the library builds/loads, exports every symbol the header
+declares, the ctypes table covers the header, and the product package never imports the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "im2im_uq.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(im2im_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from im2im_uq_amd import _lib
+    syms = declared_symbols()
+    assert len(syms) >= 6
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), f"{s} declared in include/im2im_uq.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} missing from the ctypes signature table"
+    assert sorted(_lib.SIGNATURES) == syms
+    assert _lib.lib.im2im_abi_version() == 1
+
+
+def test_argument_validation_needs_no_gpu():
+    """entry points reject bad arguments before touching the device (error convention: rc<0 + message)."""
+    from im2im_uq_amd import _lib
+    rc = _lib.lib.im2im_rcps_loss_table(None, None, 4, 16, None, 8, None, None, None, None)
+    assert rc == -1
+    assert b"invalid argument" in _lib.lib.im2im_last_error()
+
+
+def test_product_never_imports_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "im2im_uq_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(base, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "oracle/" in txt and f.endswith(".py"):
+                    bad.append(os.path.join(base, f))
+    assert not bad, f"product code must not reference oracle/: {bad}"
+    for f in ("bench.py",):
+        p = os.path.join(ROOT, f)
+        if os.path.exists(p):
+            txt = open(p).read()
+            # bench.py may import the oracle only inside its cpu_baseline leg
+            for m in re.finditer(r"^\s*(from|import)\s+oracle\b.*$", txt, flags=re.M):
+                head = txt[:m.start()]
+                assert "def cpu_baseline" in head, "bench.py imports oracle outside cpu_baseline()"
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    import importlib
+    from im2im_uq_amd import _lib
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU/PyTorch fallback"):
+        _lib._load()

@@ -1,0 +1,124 @@
+"""GPU parity of the calibration path: HIP kernels + host scan vs the CPU oracle and the golden
+fixtures produced by the reference.  Integer/indicator work -> bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+from torch.utils.data import TensorDataset
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = "cuda:0"
+BASE = dict(uncertainty_type="quantiles", rcps_loss="fraction_missed", device=DEV, dataset="synthetic",
+            q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1)
+
+
+def _identity_model():
+    from im2im_uq_amd.core.models.add_uncertainty import ModelWithUncertainty
+    from im2im_uq_amd.core.models.finallayers.quantile_layer import quantile_regression_nested_sets_from_output
+    return ModelWithUncertainty(nn.Identity(), nn.Identity(), None, quantile_regression_nested_sets_from_output, dict(BASE))
+
+
+def _cfg(v):
+    return dict(BASE, alpha=float(v[0]), delta=float(v[1]), num_lambdas=int(v[2]), minimum_lambda=float(v[3]),
+                maximum_lambda=float(v[4]), batch_size=int(v[5]))
+
+
+@pytest.mark.parametrize("case", ["mid", "n130", "zero_risk", "no_stop", "c2"])
+def test_calibrate_model_matches_reference_golden(case):
+    from im2im_uq_amd.core.calibration.calibrate_model import calibrate_model
+    g = load_golden("g7_calibrate_" + case)
+    model = _identity_model()
+    model, table = calibrate_model(model, TensorDataset(T(g["output"]).clone(), T(g["label"]).clone()), _cfg(g["cfg"]))
+    assert np.array_equal(table.numpy(), g["table"])           # bit-exact incl. zero columns (Q2)
+    assert float(model.lhat) == float(g["lhat"])
+
+
+def test_loss_table_kernel_vs_oracle_random_grid():
+    """full un-shifted table, odd sizes (P % 4 != 0 -> scalar path, N not multiple of anything)."""
+    from im2im_uq_amd import hip_ops
+    from oracle import calibration as oc
+    for (n, c, h, w, L, lmax, seed) in [(5, 1, 7, 9, 17, 3.0, 0), (33, 2, 12, 20, 64, 8.0, 1), (3, 1, 64, 64, 1000, 6.0, 2),
+                                         (2, 1, 33, 31, 1, 1.0, 3)]:
+        out, y = oc.synth_outputs(n, c, h, w, seed=seed)
+        # degenerate pixels: y == pred, tiny widths, inverted bounds
+        out[0, 1, 0, 0, :3] = y[0, 0, 0, :3]
+        out[0, 2, 0, 1, :3] = out[0, 1, 0, 1, :3] + 1e-7
+        out[0, 0, 0, 2, :3] = out[0, 1, 0, 2, :3] + 0.3
+        cfg = dict(num_lambdas=L, minimum_lambda=0.0 if L > 1 else 1.0, maximum_lambda=lmax)
+        if L > 1:
+            lambdas = oc.lambda_grid(cfg)
+        else:
+            lambdas = torch.tensor([lmax])
+        table = hip_ops.rcps_loss_table(out.to(DEV), y.to(DEV), lambdas).cpu()
+        ref = torch.stack([oc.fraction_missed(*oc.nested_sets(out, lam)[::2], y) for lam in lambdas], dim=1)
+        assert np.array_equal(table.numpy(), ref.numpy()), (n, c, h, w, L)
+        dl = lambdas[1] - lambdas[0] if L > 1 else torch.tensor(0.25)
+        table = hip_ops.rcps_loss_table(out.to(DEV), y.to(DEV), lambdas - dl).cpu()     # shifted grid incl. negative lambda
+        ref = torch.stack([oc.fraction_missed(*oc.nested_sets(out, lam - dl)[::2], y) for lam in lambdas], dim=1)
+        assert np.array_equal(table.numpy(), ref.numpy()), (n, c, h, w, L, "shifted")
+
+
+def test_loss_table_golden_g9():
+    from im2im_uq_amd import hip_ops
+    g = load_golden("g9_loss_table")
+    lambdas = torch.linspace(float(g["cfg"][1]), float(g["cfg"][2]), int(g["cfg"][0]))
+    table = hip_ops.rcps_loss_table(T(g["output"]).to(DEV), T(g["label"]).to(DEV), lambdas).cpu()
+    assert np.array_equal(table.numpy(), g["table"])
+
+
+def test_nested_sets_golden_g6():
+    g = load_golden("g6_nested_sets")
+    model = _identity_model()
+    for i, lam in enumerate(T(g["lams"])):
+        out = T(g["output"]).to(DEV).clone()
+        lo, mid, hi = model.nested_sets_from_output(out, lam)
+        assert np.array_equal(lo.cpu().numpy(), g["lower"][i])
+        assert np.array_equal(hi.cpu().numpy(), g["upper"][i])
+        # in-place clamp like the reference (Q5)
+        ref = T(g["output"]).clone()
+        assert np.array_equal(out[:, 0].cpu().numpy(), torch.minimum(ref[:, 0], ref[:, 1] - 1e-6).numpy())
+        assert np.array_equal(out[:, 2].cpu().numpy(), torch.maximum(ref[:, 2], ref[:, 1] + 1e-6).numpy())
+
+
+def test_metrics_golden_g10():
+    from im2im_uq_amd.core.calibration.calibrate_model import get_rcps_metrics_from_outputs, fraction_missed_loss
+    import random
+    g = load_golden("g10_metrics")
+    model = _identity_model()
+    model.set_lhat(T(g["lhat"]))
+    np.random.seed(0); torch.manual_seed(0); random.seed(0)     # fix_randomness(0), core/utils.py:15-19
+    losses, sizes, spearman, strat, mse, spatial = get_rcps_metrics_from_outputs(
+        model, TensorDataset(T(g["output"]), T(g["label"])), fraction_missed_loss, DEV)
+    assert np.array_equal(losses.numpy(), g["losses"])
+    assert np.array_equal(spatial, g["spatial"])
+    # RNG-dependent parts: same RNG call order as the reference -> same sampled pixels
+    np.testing.assert_allclose(sizes.numpy(), g["rng_sizes"], rtol=0, atol=1e-7)
+    assert spearman == pytest.approx(float(g["rng_spearman"]), abs=1e-6)
+    assert mse == pytest.approx(float(g["rng_mse"]), rel=1e-6)
+    np.testing.assert_allclose(strat.numpy(), g["rng_strat"], rtol=1e-6)
+
+
+def test_fraction_missed_and_large_image_properties():
+    """size-independent properties at BASELINE size 320x320: monotone in lambda, table[:, j] equals the
+    single-lambda call, counts are integers in [0, P], sum over shards == whole."""
+    from im2im_uq_amd import hip_ops
+    from oracle import calibration as oc
+    out, y = oc.synth_outputs(6, 1, 320, 320, seed=11)
+    lambdas = torch.linspace(0, 6, 1000)
+    o, l = out.to(DEV), y.to(DEV)
+    table, counts = hip_ops.rcps_loss_table(o, l, lambdas, want_counts=True)
+    assert (table[:, 1:] <= table[:, :-1]).all()
+    assert int(counts.min()) >= 0 and int(counts.max()) <= 320 * 320
+    for j in (0, 1, 499, 999):
+        lo, mid, hi = hip_ops.nested_sets(o.clone(), float(lambdas[j]))
+        single = hip_ops.fraction_missed(lo, hi, l)
+        assert torch.equal(single, table[:, j])
+    # oracle on one full-size image at three lambdas
+    for j in (0, 250, 999):
+        ref = oc.fraction_missed(*oc.nested_sets(out[:1], lambdas[j])[::2], y[:1])
+        assert torch.equal(ref, table[:1, j].cpu())
+    mis = hip_ops.rcps_miscoverage(o, l, float(lambdas[300]))
+    assert int(mis.sum()) == int(counts[:, 300].sum())

@@ -1,0 +1,50 @@
+"""Host float64 Hoeffding-Bentkus bound (C++ behind the C ABI) vs the reference's values (G8) and the
+scipy-based oracle on a dense sweep.  CPU only (pure host code)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+
+def test_hb_golden_g8():
+    from im2im_uq_amd.core.calibration.bounds import HB_mu_plus
+    for muhat, n, delta, expect in load_golden("g8_hb_bound")["rows"]:
+        assert HB_mu_plus(muhat, int(n), delta) == pytest.approx(expect, abs=1e-9), (muhat, n, delta)
+    assert HB_mu_plus(0.1, 10000, 0.1, 1000) == pytest.approx(0.10551758004098838, abs=1e-9)   # bounds.py:46
+    assert HB_mu_plus(0.0, 50, 0.1) == 1.0                                                      # Q3 exception path
+
+
+def test_hb_dense_sweep_vs_oracle():
+    import warnings
+    from oracle import calibration as oc
+    from im2im_uq_amd.core.calibration.bounds import HB_mu_plus
+    rng = np.random.RandomState(1)
+    worst = 0.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for n in (2, 7, 64, 1000, 3474, 34742):
+            for delta in (0.1, 0.05, 0.9):
+                for muhat in list(rng.rand(12)) + [k / n for k in (0, 1, n // 2, n - 1, n)]:
+                    a, b = HB_mu_plus(muhat, n, delta), oc.hb_mu_plus(muhat, n, delta)
+                    worst = max(worst, abs(a - b))
+                    assert a == pytest.approx(b, abs=1e-9), (muhat, n, delta)
+    assert worst < 1e-9
+
+
+def test_scan_quirks_on_host_table():
+    """Q1-Q4 of the descending scan, driven from a hand-made table (no GPU needed)."""
+    import torch
+    from im2im_uq_amd.core.calibration.calibrate_model import scan_loss_table
+    lambdas = torch.linspace(0, 6, 13)
+    n = 200
+    risk = torch.linspace(0.5, 0.0, 13)                   # column j: loss at lambdas[j]-dlambda
+    table = risk.repeat(n, 1)
+    lhat, out, trace = scan_loss_table(table, lambdas, alpha=0.1, delta=0.1)
+    j_stop = trace[-1][0]
+    assert float(lhat) == float(lambdas[j_stop])
+    assert (out[:, :j_stop] == 0).all() and (out[:, j_stop:] == table[:, j_stop:]).all()       # Q2
+    assert trace[0][0] == 12 and trace[0][2] == 1.0      # Rhat == 0 at the largest lambda -> RhatPlus = 1.0 (Q3)
+    assert j_stop == 12                                   # ... so the scan stops immediately (Q3)
+    table2 = torch.full((n, 13), 0.01)
+    lhat2, out2, trace2 = scan_loss_table(table2, lambdas, alpha=0.5, delta=0.5)
+    assert len(trace2) == 13 and float(lhat2) == float(lambdas[-1] + (lambdas[1] - lambdas[0]) - 1e-9)  # Q4
