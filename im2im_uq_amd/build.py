@@ -25,6 +25,9 @@ SOURCES = {
     "common.cpp": [],
     "hb_bound.cpp": ["-ffp-contract=off"],
     "rcps.hip": ["-ffp-contract=off"],
+    "conv_mfma.hip": [],
+    "elementwise.hip": ["-ffp-contract=off"],
+    "smallconv.hip": [],
 }
 
 

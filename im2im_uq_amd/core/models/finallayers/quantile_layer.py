@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 
 from ... import _pkg  # noqa: F401
-from .... import hip_ops
+from .... import hip_ops, nn_ops
 
 
 def _lam_value(model, lam):
@@ -42,10 +42,38 @@ def quantile_regression_nested_sets_from_output(model, output, lam=None, _floor=
 
 
 class QuantileRegressionLayer(nn.Module):
+    """lower / prediction / upper 3x3 heads -> [B,3,C,H,W] fp32 (reference :8-21); the three nn.Conv2d are
+    parameter containers (reference names and initialisation), the forward is one fused HIP kernel."""
+
     def __init__(self, n_channels_middle, n_channels_out, params):
-        super().__init__()
-        raise NotImplementedError("filled in with the conv kernels")
+        super(QuantileRegressionLayer, self).__init__()
+        self.q_lo = params["q_lo"]
+        self.q_hi = params["q_hi"]
+        self.params = params
+
+        self.lower = nn.Conv2d(n_channels_middle, n_channels_out, kernel_size=3, padding=1)
+        self.prediction = nn.Conv2d(n_channels_middle, n_channels_out, kernel_size=3, padding=1)
+        self.upper = nn.Conv2d(n_channels_middle, n_channels_out, kernel_size=3, padding=1)
+        self.compute_dtype = None
+
+    def forward(self, x):
+        cdt = self.compute_dtype if self.compute_dtype is not None else nn_ops.get_compute_dtype()
+        if x.dtype in (torch.float32, torch.bfloat16) and x.permute(0, 2, 3, 1).is_contiguous():
+            cdt = x.dtype                      # consume the trunk's channels-last feature map zero-copy
+        return nn_ops.QuantileHeads.apply(x, self.lower.weight, self.lower.bias, self.prediction.weight,
+                                          self.prediction.bias, self.upper.weight, self.upper.bias, cdt)
 
 
 def quantile_regression_loss_fn(pred, target, params):
-    raise NotImplementedError
+    """w_lo*pinball_{q_lo}(pred[:,0]) + w_hi*pinball_{q_hi}(pred[:,2]) + w_mse*MSE(pred[:,1])  (reference :23-32),
+    one fused reduction kernel forward, one elementwise kernel backward."""
+    if not pred.is_cuda:
+        raise RuntimeError("quantile_regression_loss_fn: tensors must be on the GPU; the HIP path has no CPU fallback")
+    if pred.dim() != 5 or pred.shape[1] != 3:
+        raise ValueError(f"pred must be [B,3,C,H,W], got {tuple(pred.shape)}")
+    p = pred if (pred.dtype == torch.float32 and pred.is_contiguous()) else pred.to(torch.float32).contiguous()
+    t = target.detach().to(device=pred.device, dtype=torch.float32).contiguous()
+    if t.numel() != p.shape[0] * p[0, 0].numel():
+        raise ValueError("target shape does not match pred")
+    return nn_ops.QuantileLossPacked.apply(p, t, float(params["q_lo"]), float(params["q_hi"]), float(params["q_lo_weight"]),
+                                           float(params["q_hi_weight"]), float(params["mse_weight"]))

@@ -1,0 +1,115 @@
+"""UNet building blocks on the HIP kernels -- same class names, constructor arguments, sub-module
+names and state_dict keys as the reference's core/models/trunks/unet_parts.py, so reference
+checkpoints load unchanged.
+
+The nn.Conv2d / nn.BatchNorm2d objects inside `double_conv` are parameter containers (same default
+initialisation as the reference); their own forward is never called.  DoubleConv.forward drives fused
+kernels instead: conv (+BatchNorm partial statistics in the epilogue) -> BN finalize -> BN+ReLU apply in
+training, or a single conv with BatchNorm folded into its epilogue in eval.
+
+Activations between blocks are logically NCHW but stored channels-last in the compute dtype
+(bf16 by default; `compute_dtype` / im2im_uq_amd.set_compute_dtype('fp32') for tight parity).
+Supported channel counts: conv inputs with <= 8 channels (network input) or a multiple of 32;
+outputs a multiple of 32 (the reference UNet uses 64..1024).
+"""
+import torch
+import torch.nn as nn
+
+from ... import _pkg  # noqa: F401
+from .... import nn_ops
+
+
+def _cdt(module):
+    dt = getattr(module, "compute_dtype", None)
+    return dt if dt is not None else nn_ops.get_compute_dtype()
+
+
+class DoubleConv(nn.Module):
+    """(convolution => [BN] => ReLU) * 2   (reference :8-25)"""
+
+    def __init__(self, in_channels, out_channels, mid_channels=None):
+        super().__init__()
+        if not mid_channels:
+            mid_channels = out_channels
+        self.double_conv = nn.Sequential(
+            nn.Conv2d(in_channels, mid_channels, kernel_size=3, padding=1),
+            nn.BatchNorm2d(mid_channels),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(mid_channels, out_channels, kernel_size=3, padding=1),
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True)
+        )
+        self.compute_dtype = None
+
+    def forward(self, x):
+        cdt = _cdt(self)
+        for ci, bi in ((0, 1), (3, 4)):
+            conv, bn = self.double_conv[ci], self.double_conv[bi]
+            if self.training:
+                momentum = bn.momentum if bn.momentum is not None else 0.1
+                x = nn_ops.ConvBnReluTrain.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
+                                                 bn.running_var, momentum, bn.eps, cdt)
+                bn.num_batches_tracked += 1
+            else:
+                if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad and False):
+                    raise NotImplementedError("eval-mode backward through the fused conv+BN kernel is not implemented")
+                x = nn_ops.conv_bn_relu_eval(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
+                                             bn.running_var, bn.eps, cdt)
+        return x
+
+
+class _MaxPool2(nn.Module):
+    def forward(self, x):
+        return nn_ops.MaxPool2.apply(x)
+
+
+class Down(nn.Module):
+    """Downscaling with maxpool then double conv   (reference :28-40)"""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.maxpool_conv = nn.Sequential(
+            _MaxPool2(),
+            DoubleConv(in_channels, out_channels)
+        )
+
+    def forward(self, x):
+        return self.maxpool_conv(x)
+
+
+class _BilinearUp(nn.Module):
+    """placeholder for nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True); the interpolation is
+    fused with the pad + concat in Up.forward."""
+    scale_factor = 2
+    mode = 'bilinear'
+    align_corners = True
+
+
+class Up(nn.Module):
+    """Upscaling then double conv   (reference :42-69)"""
+
+    def __init__(self, in_channels, out_channels, bilinear=True):
+        super().__init__()
+        if bilinear:
+            self.up = _BilinearUp()
+            self.conv = DoubleConv(in_channels, out_channels, in_channels // 2)
+        else:
+            raise NotImplementedError("bilinear=False (ConvTranspose2d upsampling) is not built yet; router.py and the "
+                                      "experiment configs only ever use the bilinear default (SURVEY D2)")
+
+    def forward(self, x1, x2):
+        # x1: deep feature map, x2: skip connection.  upsample + zero-pad + cat([x2, x1]) in one kernel.
+        x = nn_ops.UpsampleConcat.apply(x1, x2)
+        return self.conv(x)
+
+
+class OutConv(nn.Module):
+    """1x1 convolution   (reference :87-94)"""
+
+    def __init__(self, in_channels, out_channels):
+        super(OutConv, self).__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+        self.compute_dtype = None
+
+    def forward(self, x):
+        return nn_ops.Conv1x1.apply(x, self.conv.weight, self.conv.bias, _cdt(self))

@@ -1,0 +1,561 @@
+// MFMA implicit-GEMM convolution for gfx950: NHWC activations, 3x3 pad-1 or 1x1.
+//
+// Replaces the nn.Conv2d calls of the reference UNet (core/models/trunks/unet_parts.py:16,19,90)
+// and, through the same kernels, their autograd backward (dgrad = forward kernel on tap-flipped,
+// transposed weights; wgrad = its own kernel).
+//
+// GEMM view:  M = output pixels (a TH x TW patch of one image per workgroup), N = output channels,
+// K = taps * Cin.  Per workgroup (256 threads = 4 waves):
+//   * the input halo patch (TH+2)x(TW+2) x 32 channels is staged once per Cin-chunk into LDS and
+//     re-used by all 9 taps (a tap is just an LDS address offset);
+//   * the weight tile [BN][32] of one (tap, Cin-chunk) is double-buffered in LDS, the next one is
+//     prefetched into registers while the MFMAs of the current one issue;
+//   * v_mfma_f32_32x32x16_bf16 (bf16 in, fp32 accumulate) or v_mfma_f32_32x32x2_f32 (exact fp32,
+//     parity mode); operand/result lane maps verified on hardware (tools/hwprobe).
+//   * epilogue: + bias, optional folded-BN affine + ReLU (eval), store, and per-channel partial
+//     sums / sums of squares for train-mode BatchNorm (deterministic, no atomics).
+// LDS rows are padded by 16 B so ds_read_b128 operand fetches are (nearly) conflict free.
+#include "common.h"
+#include "dtypes.h"
+
+namespace {
+
+using namespace im2im;
+
+struct ConvArgs {
+  const void* x;        // [B][H][W][Ci]  T
+  const void* w;        // [Co][TAPS][Ci] T
+  const float* bias;    // [Co] or null
+  const float* scale;   // [Co] or null  (mode affine)
+  const float* shift;   // [Co] or null
+  void* y;              // [B][H][W][Co]  T
+  float* stats;         // [mtiles][2][Co] or null
+  int B, H, W, Ci, Co, tilesY, tilesX;
+  int relu;             // apply ReLU after affine
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> {
+  using AB = short8;
+  static constexpr int KSTEPS = 2;            // 32 channels / 16 per MFMA
+  static __device__ __forceinline__ AB load(const char* base, int ks, int half) {
+    return *reinterpret_cast<const AB*>(base + ks * 32 + half * 16);
+  }
+  static __device__ __forceinline__ f32x16 mfma(AB a, AB b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
+  }
+};
+template <> struct Frag<float> {
+  using AB = float;
+  static constexpr int KSTEPS = 16;           // 32 channels / 2 per MFMA
+  static __device__ __forceinline__ AB load(const char* base, int ks, int half) {
+    return *reinterpret_cast<const float*>(base + (ks * 2 + half) * 4);
+  }
+  static __device__ __forceinline__ f32x16 mfma(AB a, AB b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename T, int TH, int TW, int BN, int WM, int WN, int TAPS>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int PAD = (TAPS == 9) ? 1 : 0;
+  constexpr int HH = TH + 2 * PAD, HWD = TW + 2 * PAD, HPX = HH * HWD;
+  constexpr int KC = 32;
+  constexpr int EPP = 16 / (int)sizeof(T);          // elements per 16-B piece
+  constexpr int PPR = KC / EPP;                     // pieces per row
+  constexpr int ROWB = KC * (int)sizeof(T) + 16;    // padded LDS row pitch (bytes)
+  constexpr int M = TH * TW;
+  constexpr int MT = M / (32 * WM), NT = BN / (32 * WN);
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(MT >= 1 && NT >= 1 && M % (32 * WM) == 0 && BN % (32 * WN) == 0, "tile split");
+  constexpr int A_ROUNDS = (HPX * PPR + 255) / 256;
+  constexpr int B_ROUNDS = (BN * PPR + 255) / 256;
+  constexpr int A_BYTES = HPX * ROWB, B_BYTES = BN * ROWB;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsA = smem;
+  char* ldsB = smem + A_BYTES;                      // two buffers
+  float* ldsS = reinterpret_cast<float*>(smem);     // stats scratch, re-uses A after the main loop
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  int mt_id = blockIdx.x;
+  const int tx_id = mt_id % a.tilesX; mt_id /= a.tilesX;
+  const int ty_id = mt_id % a.tilesY;
+  const int b = mt_id / a.tilesY;
+  const int y0 = ty_id * TH, x0 = tx_id * TW;
+  const int n0 = blockIdx.y * BN;
+
+  const T* __restrict__ xg = reinterpret_cast<const T*>(a.x) + (size_t)b * a.H * a.W * a.Ci;
+  const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
+
+  // per-lane LDS byte offsets of this lane's A rows / B rows
+  int aoff[MT], boff[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = (wm * MT + mt) * 32 + l31;
+    aoff[mt] = ((m / TW) * HWD + (m % TW)) * ROWB;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) boff[nt] = ((wn * NT + nt) * 32 + l31) * ROWB;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  uint4 ra[A_ROUNDS], rb[B_ROUNDS];
+
+  auto gload_A = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < A_ROUNDS; ++i) {
+      const int p = i * 256 + tid;
+      const int px = p / PPR, part = p % PPR;
+      const int hy = px / HWD, hx = px % HWD;
+      const int yy = y0 + hy - PAD, xx = x0 + hx - PAD;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (px < HPX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
+        v = *reinterpret_cast<const uint4*>(xg + ((size_t)yy * a.W + xx) * a.Ci + chunk * KC + part * EPP);
+      ra[i] = v;
+    }
+  };
+  auto swrite_A = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_ROUNDS; ++i) {
+      const int p = i * 256 + tid;
+      const int px = p / PPR, part = p % PPR;
+      if (px < HPX) *reinterpret_cast<uint4*>(ldsA + px * ROWB + part * 16) = ra[i];
+    }
+  };
+  auto gload_B = [&](int chunk, int tap) {
+#pragma unroll
+    for (int i = 0; i < B_ROUNDS; ++i) {
+      const int p = i * 256 + tid;
+      const int n = p / PPR, part = p % PPR;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (n < BN)
+        v = *reinterpret_cast<const uint4*>(wg + ((size_t)(n0 + n) * TAPS + tap) * a.Ci + chunk * KC + part * EPP);
+      rb[i] = v;
+    }
+  };
+  auto swrite_B = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < B_ROUNDS; ++i) {
+      const int p = i * 256 + tid;
+      const int n = p / PPR, part = p % PPR;
+      if (n < BN) *reinterpret_cast<uint4*>(ldsB + buf * B_BYTES + n * ROWB + part * 16) = rb[i];
+    }
+  };
+
+  const int nchunks = a.Ci / KC;
+  const int niter = nchunks * TAPS;
+  gload_A(0);
+  gload_B(0, 0);
+  int chunk = 0, tap = 0;
+  for (int it = 0; it < niter; ++it) {
+    if (tap == 0) {
+      if (it) __syncthreads();                     // everyone done reading the previous halo
+      swrite_A();
+    }
+    swrite_B(it & 1);
+    __syncthreads();
+    int ntap = tap + 1, nchunk = chunk;
+    if (ntap == TAPS) { ntap = 0; ++nchunk; }
+    if (it + 1 < niter) {
+      gload_B(nchunk, ntap);
+      if (ntap == 0) gload_A(nchunk);
+    }
+    const int toff = (TAPS == 9) ? ((tap / 3) * HWD + (tap % 3)) * ROWB : 0;
+    const char* pa = ldsA + toff;
+    const char* pb = ldsB + (it & 1) * B_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < Frag<T>::KSTEPS; ++ks) {
+      typename Frag<T>::AB fa[MT], fb[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) fa[mt] = Frag<T>::load(pa + aoff[mt], ks, half);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) fb[nt] = Frag<T>::load(pb + boff[nt], ks, half);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Frag<T>::mfma(fa[mt], fb[nt], acc[mt][nt]);
+    }
+    tap = ntap; chunk = nchunk;
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  T* __restrict__ yg = reinterpret_cast<T*>(a.y) + (size_t)b * a.H * a.W * a.Co;
+  const bool want_stats = a.stats != nullptr;
+  if (want_stats) __syncthreads();                 // LDS (A region) is re-used for the stats scratch
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int nl = (wn * NT + nt) * 32 + l31;      // channel within the block tile
+    const int n = n0 + nl;
+    const float bias_v = a.bias ? a.bias[n] : 0.f;
+    const float sc = a.scale ? a.scale[n] : 1.f;
+    const float sh = a.shift ? a.shift[n] : 0.f;
+    float s = 0.f, sq = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int yy = y0 + m / TW, xx = x0 + m % TW;
+        float v = acc[mt][nt][r] + bias_v;
+        v = v * sc + sh;
+        if (a.relu) v = fmaxf(v, 0.f);
+        const T tv = from_float<T>(v);
+        if (yy < a.H && xx < a.W) {
+          yg[((size_t)yy * a.W + xx) * a.Co + n] = tv;
+          const float fv = to_float(tv);
+          s += fv; sq += fv * fv;
+        }
+      }
+    }
+    if (want_stats) {
+      s += __shfl_xor(s, 32, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      if (half == 0) { ldsS[(wm * BN + nl) * 2 + 0] = s; ldsS[(wm * BN + nl) * 2 + 1] = sq; }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f, sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) { s += ldsS[(i * BN + tid) * 2 + 0]; sq += ldsS[(i * BN + tid) * 2 + 1]; }
+      float* st = a.stats + (size_t)blockIdx.x * 2 * a.Co;
+      st[n0 + tid] = s;
+      st[a.Co + n0 + tid] = sq;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad:  dW[co][tap][ci] = sum over pixels of dz[p][co] * x[p + tap][ci]
+// Block = 64 co x 64 ci x all taps; K runs over pixel tiles (TH x TW), split across blockIdx.y.
+// bf16: both operands need k (= pixel) contiguous per lane but live channel-contiguous in LDS, so
+// they are fetched with ds_read_b64_tr_b16 (hardware 4x16 transpose, semantics verified by
+// tools/hwprobe): lane q of a 16-lane group supplies row q>>2, 8-byte quad q&3 and receives column
+// l&15.  fp32: v_mfma_f32_32x32x2_f32 takes one scalar per lane, read directly.
+struct WgradArgs {
+  const void* x;     // [B][H][W][Ci] T  (layer input)
+  const void* dz;    // [B][H][W][Co] T
+  float* partial;    // [nsplit][Co][TAPS][Ci] fp32
+  int B, H, W, Ci, Co, tilesY, tilesX, ntiles, tiles_per_split;
+};
+
+template <typename T> struct WFrag;
+template <> struct WFrag<bf16_t> {
+  using AB = short8;
+  static constexpr int KPX = 16;                    // pixels per MFMA k-step
+  // rowbase: LDS byte address of pixel-row 0 of this k-step's 16-pixel run for this lane's half;
+  // rows[i] = byte offset of pixel i (0..7) of the half relative to lds; col_b = byte offset of channel
+  static __device__ __forceinline__ AB load(const char* p0, const char* p1) {
+    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(lds_char*)p0);
+    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(lds_char*)p1);
+    AB r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
+  static __device__ __forceinline__ f32x16 mfma(AB a, AB b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
+  }
+};
+
+template <typename T, int TH, int TW, int TAPS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int PAD = (TAPS == 9) ? 1 : 0;
+  constexpr int HH = TH + 2 * PAD, HWD = TW + 2 * PAD, HPX = HH * HWD;
+  constexpr int M = TH * TW;
+  constexpr int CT = 64;                            // channels per tile (both co and ci)
+  constexpr bool IS_BF16 = sizeof(T) == 2;
+  constexpr int EPP = 16 / (int)sizeof(T);
+  constexpr int PPR = CT / EPP;                     // 8 (bf16) or 16 (fp32)
+  constexpr int PB = IS_BF16 ? 192 : 272;           // LDS row pitch (bytes)
+  constexpr int A_BYTES = M * PB;
+  constexpr int A_ROUNDS = (M * PPR + 255) / 256, B_ROUNDS = (HPX * PPR + 255) / 256;
+  constexpr int KPX = IS_BF16 ? 16 : 2;
+  constexpr int KSTEPS = M / KPX;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsA = smem;                                // dz tile  [M][64 co]
+  char* ldsB = smem + A_BYTES;                      // x halo   [HPX][64 ci]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wco = wave >> 1, wci = wave & 1;        // 2 x 2 waves, 32 co x 32 ci each
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ci_tiles = a.Ci / CT;
+  const int co0 = (blockIdx.x / ci_tiles) * CT, ci0 = (blockIdx.x % ci_tiles) * CT;   // Co may be 32 mod 64: masked
+  const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ dzg = reinterpret_cast<const T*>(a.dz);
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // lane-constant pieces of the operand addresses
+  //   bf16 tr-read: group g = lane>>4 -> channel sub-block (g&1)*16; lane q = lane&15 supplies
+  //   pixel row (q>>2) of its 4-row block and the 8-byte quad (q&3).
+  const int q = lane & 15;
+  const int tr_col_b = (((lane >> 4) & 1) * 16 + (q & 3) * 4) * 2;   // byte offset of the quad's first channel
+  const int tr_row = q >> 2;
+
+  const int t_begin = blockIdx.y * a.tiles_per_split;
+  const int t_end = min(t_begin + a.tiles_per_split, a.ntiles);
+  for (int t = t_begin; t < t_end; ++t) {
+    int tt = t;
+    const int tx_id = tt % a.tilesX; tt /= a.tilesX;
+    const int ty_id = tt % a.tilesY;
+    const int b = tt / a.tilesY;
+    const int y0 = ty_id * TH, x0 = tx_id * TW;
+    const T* xb = xg + (size_t)b * a.H * a.W * a.Ci;
+    const T* dzb = dzg + (size_t)b * a.H * a.W * a.Co;
+    if (t != t_begin) __syncthreads();
+    // stage dz tile
+#pragma unroll
+    for (int i = 0; i < A_ROUNDS; ++i) {
+      const int p = i * 256 + tid;
+      const int px = p / PPR, part = p % PPR;
+      const int yy = y0 + px / TW, xx = x0 + px % TW;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (px < M && yy < a.H && xx < a.W && co0 + part * EPP < a.Co)
+        v = *reinterpret_cast<const uint4*>(dzb + ((size_t)yy * a.W + xx) * a.Co + co0 + part * EPP);
+      if (px < M) *reinterpret_cast<uint4*>(ldsA + px * PB + part * 16) = v;
+    }
+    // stage x halo
+#pragma unroll
+    for (int i = 0; i < B_ROUNDS; ++i) {
+      const int p = i * 256 + tid;
+      const int px = p / PPR, part = p % PPR;
+      const int yy = y0 + px / HWD - PAD, xx = x0 + px % HWD - PAD;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (px < HPX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
+        v = *reinterpret_cast<const uint4*>(xb + ((size_t)yy * a.W + xx) * a.Ci + ci0 + part * EPP);
+      if (px < HPX) *reinterpret_cast<uint4*>(ldsB + px * PB + part * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      if constexpr (IS_BF16) {
+        // this lane's two 4-pixel row groups of the k-step: pixels m = ks*16 + half*8 + {0..3, 4..7} (+ tr_row)
+        const int m0 = ks * 16 + half * 8 + tr_row, m1 = m0 + 4;
+        const char* pa0 = ldsA + m0 * PB + wco * 64 + tr_col_b;
+        const char* pa1 = ldsA + m1 * PB + wco * 64 + tr_col_b;
+        const short8 fa = WFrag<bf16_t>::load(pa0, pa1);
+        const int h0 = ((m0 / TW) * HWD + (m0 % TW)) * PB + wci * 64 + tr_col_b;
+        const int h1 = ((m1 / TW) * HWD + (m1 % TW)) * PB + wci * 64 + tr_col_b;
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) {
+          const int toff = (TAPS == 9) ? ((tp / 3) * HWD + (tp % 3)) * PB : 0;
+          const short8 fb = WFrag<bf16_t>::load(ldsB + h0 + toff, ldsB + h1 + toff);
+          acc[tp] = WFrag<bf16_t>::mfma(fa, fb, acc[tp]);
+        }
+      } else {
+        const int m = ks * 2 + half;
+        const float fa = *reinterpret_cast<const float*>(ldsA + m * PB + (wco * 32 + l31) * 4);
+        const int hb = ((m / TW) * HWD + (m % TW)) * PB + (wci * 32 + l31) * 4;
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) {
+          const int toff = (TAPS == 9) ? ((tp / 3) * HWD + (tp % 3)) * PB : 0;
+          const float fb = *reinterpret_cast<const float*>(ldsB + hb + toff);
+          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[tp], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // partial[split][co][tap][ci]
+  float* out = a.partial + (size_t)blockIdx.y * a.Co * TAPS * a.Ci;
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int ci = ci0 + wci * 32 + l31;
+      if (co < a.Co) out[((size_t)co * TAPS + tp) * a.Ci + ci] = acc[tp][r];
+    }
+}
+
+// sum partial[nsplit][Co][TAPS][Ci] over splits and write torch layout dw[Co][Ci][TAPS]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int Co, int Ci,
+                                                            int taps, float* __restrict__ dw) {
+  const size_t total = (size_t)Co * taps * Ci;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * total + i];
+    const int ci = (int)(i % Ci);
+    const size_t r = i / Ci;
+    const int tp = (int)(r % taps);
+    const size_t co = r / taps;
+    dw[(co * Ci + ci) * taps + tp] = s;
+  }
+}
+
+// w[Co][Ci][taps] fp32 -> wf[Co][taps][Ci] T and (optional) wd[Ci][taps flipped][Co] T
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, int Co, int Ci, int taps,
+                                                           T* __restrict__ wf, T* __restrict__ wd) {
+  const size_t total = (size_t)Co * Ci * taps;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    // i indexes wf: (co, tp, ci)
+    const int ci = (int)(i % Ci);
+    const size_t r = i / Ci;
+    const int tp = (int)(r % taps);
+    const size_t co = r / taps;
+    const T v = from_float<T>(w[(co * Ci + ci) * taps + tp]);
+    wf[i] = v;
+    if (wd) wd[((size_t)ci * taps + (taps - 1 - tp)) * Co + co] = v;
+  }
+}
+
+template <typename T, int TH, int TW, int BN, int WM, int WN, int TAPS>
+int launch_conv(const ConvArgs& a_in, hipStream_t stream) {
+  ConvArgs a = a_in;
+  a.tilesY = (int)cdiv(a.H, TH);
+  a.tilesX = (int)cdiv(a.W, TW);
+  constexpr int PAD = (TAPS == 9) ? 1 : 0;
+  constexpr int ROWB = 32 * (int)sizeof(T) + 16;
+  constexpr size_t smem = (size_t)((TH + 2 * PAD) * (TW + 2 * PAD) + 2 * BN) * ROWB;
+  static_assert(smem >= (size_t)WM * BN * 2 * 4, "stats scratch fits");
+  auto kern = conv_igemm_kernel<T, TH, TW, BN, WM, WN, TAPS>;
+  static bool attr_set = false;
+  if (!attr_set && smem > 64 * 1024) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)((size_t)a.B * a.tilesY * a.tilesX), (unsigned)(a.Co / BN));
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, a);
+  return check_launch("conv_igemm_kernel");
+}
+
+// pixel-tile shape per problem: 16x16 for the large-extent levels, 8x8 (8x16 when Cout == 32) for the
+// deep, small-extent ones (40x40, 20x20) so that little of a tile hangs over the image edge.
+struct TileChoice { int th, tw, bn; };
+inline TileChoice pick_tile(int H, int W, int Co) {
+  const bool small = (H < 64 || W < 64);
+  const int bn = (Co % 128 == 0) ? 128 : (Co % 64 == 0) ? 64 : 32;
+  if (!small) return {16, 16, bn};
+  return bn == 32 ? TileChoice{8, 16, 32} : TileChoice{8, 8, bn};
+}
+
+template <typename T, int TAPS>
+int dispatch_conv(const ConvArgs& a, hipStream_t stream) {
+  const TileChoice t = pick_tile(a.H, a.W, a.Co);
+  if (t.th == 16) {
+    if (t.bn == 128) return launch_conv<T, 16, 16, 128, 2, 2, TAPS>(a, stream);
+    if (t.bn == 64) return launch_conv<T, 16, 16, 64, 4, 1, TAPS>(a, stream);
+    return launch_conv<T, 16, 16, 32, 4, 1, TAPS>(a, stream);
+  }
+  if (t.bn == 128) return launch_conv<T, 8, 8, 128, 1, 4, TAPS>(a, stream);
+  if (t.bn == 64) return launch_conv<T, 8, 8, 64, 2, 2, TAPS>(a, stream);
+  return launch_conv<T, 8, 16, 32, 4, 1, TAPS>(a, stream);
+}
+
+}  // namespace
+
+extern "C" int64_t im2im_conv_stats_rows(int32_t B, int32_t H, int32_t W, int32_t Co) {
+  const TileChoice t = pick_tile(H, W, Co);
+  return (int64_t)B * im2im::cdiv(H, t.th) * im2im::cdiv(W, t.tw);
+}
+
+extern "C" int im2im_conv_fwd(const void* x, const void* w, const float* bias, const float* scale, const float* shift,
+                              void* y, float* stats, int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                              int32_t taps, int32_t relu, int32_t dtype, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(x && w && y);
+  IM2IM_REQUIRE(B > 0 && H > 0 && W > 0);
+  IM2IM_REQUIRE(Ci > 0 && Ci % 32 == 0);
+  IM2IM_REQUIRE(Co > 0 && Co % 32 == 0);
+  IM2IM_REQUIRE(taps == 9 || taps == 1);
+  IM2IM_REQUIRE(dtype == IM2IM_F32 || dtype == IM2IM_BF16);
+  IM2IM_REQUIRE((scale == nullptr) == (shift == nullptr));
+  ConvArgs a{x, w, bias, scale, shift, y, stats, B, H, W, Ci, Co, 0, 0, relu};
+  if (dtype == IM2IM_BF16) return taps == 9 ? dispatch_conv<bf16_t, 9>(a, stream) : dispatch_conv<bf16_t, 1>(a, stream);
+  return taps == 9 ? dispatch_conv<float, 9>(a, stream) : dispatch_conv<float, 1>(a, stream);
+}
+
+namespace {
+template <typename T, int TAPS>
+int launch_wgrad(const void* x, const void* dz, float* partial, int64_t partial_bytes, float* dw, int B, int H, int W,
+                 int Ci, int Co, hipStream_t stream) {
+  constexpr int TH = 8, TW = 16;
+  constexpr int PAD = (TAPS == 9) ? 1 : 0;
+  constexpr bool IS_BF16 = sizeof(T) == 2;
+  constexpr int PB = IS_BF16 ? 192 : 272;
+  constexpr size_t smem = (size_t)(TH * TW + (TH + 2 * PAD) * (TW + 2 * PAD)) * PB;
+  WgradArgs a{x, dz, partial, B, H, W, Ci, Co, (int)cdiv(H, TH), (int)cdiv(W, TW), 0, 0};
+  a.ntiles = B * a.tilesY * a.tilesX;
+  const int cblocks = (int)cdiv(Co, 64) * (Ci / 64);
+  const size_t wsz = (size_t)Co * TAPS * Ci * sizeof(float);
+  int64_t max_split = partial_bytes / (int64_t)wsz;
+  if (max_split < 1) return fail_invalid("wgrad: workspace smaller than one weight-sized slab");
+  int64_t nsplit = cdiv(1024, cblocks);
+  if (nsplit > a.ntiles) nsplit = a.ntiles;
+  if (nsplit > max_split) nsplit = max_split;
+  if (nsplit < 1) nsplit = 1;
+  a.tiles_per_split = (int)cdiv(a.ntiles, nsplit);
+  nsplit = cdiv(a.ntiles, a.tiles_per_split);
+  auto kern = conv_wgrad_kernel<T, TH, TW, TAPS>;
+  static bool attr_set = false;
+  if (!attr_set && smem > 64 * 1024) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)cblocks, (unsigned)nsplit), dim3(256), smem, stream, a);
+  if (int rc = check_launch("conv_wgrad_kernel")) return rc;
+  const size_t total = (size_t)Co * TAPS * Ci;
+  int blocks = (int)std::min<size_t>(cdiv(total, 256), 4096);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, (int)nsplit, Co, Ci, TAPS, dw);
+  return check_launch("wgrad_reduce_kernel");
+}
+}  // namespace
+
+extern "C" int64_t im2im_conv_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t taps) {
+  if (Ci <= 0 || Co <= 0 || Ci % 64 || Co % 32) return -1;
+  const int64_t ntiles = (int64_t)B * im2im::cdiv(H, 8) * im2im::cdiv(W, 16);
+  const int64_t cblocks = im2im::cdiv(Co, 64) * (Ci / 64);
+  int64_t nsplit = im2im::cdiv(1024, cblocks);
+  if (nsplit > ntiles) nsplit = ntiles;
+  if (nsplit < 1) nsplit = 1;
+  return nsplit * (int64_t)Co * taps * Ci * (int64_t)sizeof(float);
+}
+
+extern "C" int im2im_conv_wgrad(const void* x, const void* dz, float* dw, void* workspace, int64_t workspace_bytes,
+                                int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t taps, int32_t dtype,
+                                im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(x && dz && dw && workspace);
+  IM2IM_REQUIRE(B > 0 && H > 0 && W > 0);
+  IM2IM_REQUIRE(Ci > 0 && Ci % 64 == 0);
+  IM2IM_REQUIRE(Co > 0 && Co % 32 == 0);
+  IM2IM_REQUIRE(taps == 9 || taps == 1);
+  IM2IM_REQUIRE(dtype == IM2IM_F32 || dtype == IM2IM_BF16);
+  float* partial = reinterpret_cast<float*>(workspace);
+  if (dtype == IM2IM_BF16)
+    return taps == 9 ? launch_wgrad<bf16_t, 9>(x, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream)
+                     : launch_wgrad<bf16_t, 1>(x, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream);
+  return taps == 9 ? launch_wgrad<float, 9>(x, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream)
+                   : launch_wgrad<float, 1>(x, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream);
+}
+
+extern "C" int im2im_pack_conv_weight(const float* w, int32_t Co, int32_t Ci, int32_t taps, int32_t dtype, void* wf,
+                                      void* wd, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(w && wf && Co > 0 && Ci > 0 && taps > 0);
+  IM2IM_REQUIRE(dtype == IM2IM_F32 || dtype == IM2IM_BF16);
+  const size_t total = (size_t)Co * Ci * taps;
+  int blocks = (int)std::min<size_t>(im2im::cdiv(total, 256), 4096);
+  if (dtype == IM2IM_BF16)
+    hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, w, Co, Ci, taps, (bf16_t*)wf, (bf16_t*)wd);
+  else
+    hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, stream, w, Co, Ci, taps, (float*)wf, (float*)wd);
+  return im2im::check_launch("pack_weight_kernel");
+}

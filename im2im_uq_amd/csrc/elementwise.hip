@@ -1,0 +1,687 @@
+// HBM-bound side passes of the UNet train/eval step on gfx950, all NHWC:
+// BatchNorm(+ReLU) forward/backward, 2x2 max-pool, bilinear x2 upsample + pad + concat, fused
+// quantile (pinball x2 + MSE) loss, multi-tensor Adam.  Every kernel moves 16 B per lane per access
+// (8 bf16 or 4 fp32 channels) and does its arithmetic in fp32.
+#include "common.h"
+#include "dtypes.h"
+#include "reduce.h"
+
+namespace {
+using namespace im2im;
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm2d, train mode (core/models/trunks/unet_parts.py:17,20; torch defaults eps=1e-5, momentum=0.1)
+// stage 2 of the statistics reduction: tmp[S][2][C] fp64 (sum, sum of squares) ->
+//   mean_invstd[2][C], scale_shift[2][C] (scale = gamma*invstd, shift = beta - mean*scale),
+//   running stats (unbiased variance, as torch).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ tmp, int S, int C, double count,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           float momentum, float eps, float* __restrict__ mean_invstd,
+                                                           float* __restrict__ scale_shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, sq = 0.0;
+  for (int i = 0; i < S; ++i) { s += tmp[((size_t)i * 2 + 0) * C + c]; sq += tmp[((size_t)i * 2 + 1) * C + c]; }
+  const double mean = s / count;
+  double var = sq / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  mean_invstd[c] = (float)mean;
+  mean_invstd[C + c] = invstd;
+  const float sc = gamma[c] * invstd;
+  scale_shift[c] = sc;
+  scale_shift[C + c] = beta[c] - (float)mean * sc;
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// eval-mode fold: scale = gamma/sqrt(rv+eps), shift = beta + (conv_bias - rm)*scale
+__global__ __launch_bounds__(256) void bn_fold_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ rm, const float* __restrict__ rv,
+                                                            const float* __restrict__ conv_bias, float eps, int C,
+                                                            float* __restrict__ scale_shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(rv[c] + eps);
+  scale_shift[c] = sc;
+  scale_shift[C + c] = beta[c] + ((conv_bias ? conv_bias[c] : 0.f) - rm[c]) * sc;
+}
+
+// a = relu(z*scale + shift), [M][C]
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict__ z, const float* __restrict__ scale_shift,
+                                                             T* __restrict__ a, int64_t nvec, int C) {
+  constexpr int N = Vec16<T>::N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int c0 = (int)((i * N) % C);
+    float v[N];
+    Vec16<T>::load(z + i * N, v);
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k] * scale_shift[c0 + k] + scale_shift[C + c0 + k], 0.f);
+    Vec16<T>::store(a + i * N, v);
+  }
+}
+
+// backward pass 1: per-block partial sums of g = da*[z*scale+shift > 0] and g*xhat.  partial[blk][2][C]
+// A thread keeps one channel vector (256 % (C/N) == 0) and strides rows; per-thread sums are combined through
+// LDS in a fixed order, so the result is deterministic.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __restrict__ da, const T* __restrict__ z,
+                                                                  const float* __restrict__ scale_shift,
+                                                                  const float* __restrict__ mean_invstd, int64_t M, int C,
+                                                                  int64_t rows_per_block, float* __restrict__ partial) {
+  constexpr int N = Vec16<T>::N;
+  __shared__ float s_part[256][2 * N + 1];
+  const int vpr = C / N;                                   // vectors per row (divides 256)
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
+  const int64_t v0 = r0 * vpr, v1 = r1 * vpr;
+  const int cv = threadIdx.x % vpr;
+  const int c0 = cv * N;
+  float sc[N], sh[N], mu[N], is[N], s1[N], s2[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    sc[k] = scale_shift[c0 + k]; sh[k] = scale_shift[C + c0 + k];
+    mu[k] = mean_invstd[c0 + k]; is[k] = mean_invstd[C + c0 + k];
+    s1[k] = 0.f; s2[k] = 0.f;
+  }
+  if (threadIdx.x < (256 / vpr) * vpr) {
+    for (int64_t i = v0 + threadIdx.x; i < v1; i += (256 / vpr) * vpr) {
+      float g[N], zz[N];
+      Vec16<T>::load(da + i * N, g);
+      Vec16<T>::load(z + i * N, zz);
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const float gg = (zz[k] * sc[k] + sh[k] > 0.f) ? g[k] : 0.f;
+        s1[k] += gg;
+        s2[k] += gg * ((zz[k] - mu[k]) * is[k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) { s_part[threadIdx.x][k] = s1[k]; s_part[threadIdx.x][N + k] = s2[k]; }
+  __syncthreads();
+  const int groups = 256 / vpr;
+  for (int j = threadIdx.x; j < 2 * C; j += 256) {
+    const int which = j / C, c = j % C;
+    float acc = 0.f;
+    for (int g = 0; g < groups; ++g) acc += s_part[g * vpr + c / N][which * N + c % N];
+    partial[(size_t)blockIdx.x * 2 * C + j] = acc;
+  }
+}
+
+// stage 2: dgamma = sum g*xhat, dbeta = sum g; coef[3][C] = {scale, dbeta/M, dgamma/M}
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ tmp, int S, int C, double count,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ coef) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < S; ++i) { s1 += tmp[((size_t)i * 2 + 0) * C + c]; s2 += tmp[((size_t)i * 2 + 1) * C + c]; }
+  dbeta[c] = (float)s1;
+  dgamma[c] = (float)s2;
+  coef[c] = (float)(s1 / count);
+  coef[C + c] = (float)(s2 / count);
+}
+
+// backward pass 2: dz = scale * (g - dbeta/M - xhat * dgamma/M)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restrict__ da, const T* __restrict__ z,
+                                                                 const float* __restrict__ scale_shift,
+                                                                 const float* __restrict__ mean_invstd,
+                                                                 const float* __restrict__ coef, T* __restrict__ dz,
+                                                                 int64_t nvec, int C) {
+  constexpr int N = Vec16<T>::N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int c0 = (int)((i * N) % C);
+    float g[N], zz[N], o[N];
+    Vec16<T>::load(da + i * N, g);
+    Vec16<T>::load(z + i * N, zz);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const int c = c0 + k;
+      const float sc = scale_shift[c];
+      const float gg = (zz[k] * sc + scale_shift[C + c] > 0.f) ? g[k] : 0.f;
+      const float xhat = (zz[k] - mean_invstd[c]) * mean_invstd[C + c];
+      o[k] = sc * (gg - coef[c] - xhat * coef[C + c]);
+    }
+    Vec16<T>::store(dz + i * N, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums of an [M][C] tensor (bias gradient of the 1x1 out conv): partial[blk][C]; fixed-order, deterministic
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int64_t M, int C, int64_t rows_per_block,
+                                                              float* __restrict__ partial) {
+  constexpr int N = Vec16<T>::N;
+  __shared__ float s_part[256][N + 1];
+  const int vpr = C / N;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
+  float s1[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) s1[k] = 0.f;
+  if (threadIdx.x < (256 / vpr) * vpr) {
+    for (int64_t i = r0 * vpr + threadIdx.x; i < r1 * vpr; i += (256 / vpr) * vpr) {
+      float v[N];
+      Vec16<T>::load(x + i * N, v);
+#pragma unroll
+      for (int k = 0; k < N; ++k) s1[k] += v[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) s_part[threadIdx.x][k] = s1[k];
+  __syncthreads();
+  const int groups = 256 / vpr, cvt = threadIdx.x % vpr;
+  (void)cvt;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float acc = 0.f;
+    for (int g = 0; g < groups; ++g) acc += s_part[g * vpr + c / N][c % N];
+    partial[(size_t)blockIdx.x * C + c] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void sum_final_kernel(const double* __restrict__ tmp, int S, int64_t K, float* __restrict__ out) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  double s = 0.0;
+  for (int i = 0; i < S; ++i) s += tmp[(size_t)i * K + k];
+  out[k] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxPool2d(2) (unet_parts.py:34), NHWC.  Ties keep the first maximum in (h, w) scan order, as torch.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W,
+                                                            int C) {
+  constexpr int N = Vec16<T>::N;
+  const int Ho = H / 2, Wo = W / 2, vpr = C / N;
+  const int64_t total = (int64_t)B * Ho * Wo * vpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % vpr);
+    int64_t r = i / vpr;
+    const int xo = (int)(r % Wo); r /= Wo;
+    const int yo = (int)(r % Ho);
+    const int64_t b = r / Ho;
+    const T* p = x + (((b * H + 2 * yo) * W + 2 * xo) * (int64_t)C) + cv * N;
+    float v00[N], v01[N], v10[N], v11[N], o[N];
+    Vec16<T>::load(p, v00);
+    Vec16<T>::load(p + C, v01);
+    Vec16<T>::load(p + (int64_t)W * C, v10);
+    Vec16<T>::load(p + (int64_t)W * C + C, v11);
+#pragma unroll
+    for (int k = 0; k < N; ++k) o[k] = fmaxf(fmaxf(v00[k], v01[k]), fmaxf(v10[k], v11[k]));
+    Vec16<T>::store(y + i * N, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                            T* __restrict__ dx, int B, int H, int W, int C) {
+  constexpr int N = Vec16<T>::N;
+  const int Ho = H / 2, Wo = W / 2, vpr = C / N;
+  // one thread per INPUT 2x2 window position incl. the dropped odd row/col (gets zeros)
+  const int Hc = (H + 1) / 2, Wc = (W + 1) / 2;
+  const int64_t total = (int64_t)B * Hc * Wc * vpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % vpr);
+    int64_t r = i / vpr;
+    const int xo = (int)(r % Wc); r /= Wc;
+    const int yo = (int)(r % Hc);
+    const int64_t b = r / Hc;
+    const int64_t base = (((b * H + 2 * yo) * W + 2 * xo) * (int64_t)C) + cv * N;
+    float z[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) z[k] = 0.f;
+    if (yo < Ho && xo < Wo) {
+      float v[4][N], g[N], o[4][N];
+      Vec16<T>::load(x + base, v[0]);
+      Vec16<T>::load(x + base + C, v[1]);
+      Vec16<T>::load(x + base + (int64_t)W * C, v[2]);
+      Vec16<T>::load(x + base + (int64_t)W * C + C, v[3]);
+      Vec16<T>::load(dy + (((b * Ho + yo) * Wo + xo) * (int64_t)C) + cv * N, g);
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        int am = 0; float m = v[0][k];
+        if (v[1][k] > m) { m = v[1][k]; am = 1; }
+        if (v[2][k] > m) { m = v[2][k]; am = 2; }
+        if (v[3][k] > m) { m = v[3][k]; am = 3; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q][k] = (am == q) ? g[k] : 0.f;
+      }
+      Vec16<T>::store(dx + base, o[0]);
+      Vec16<T>::store(dx + base + C, o[1]);
+      Vec16<T>::store(dx + base + (int64_t)W * C, o[2]);
+      Vec16<T>::store(dx + base + (int64_t)W * C + C, o[3]);
+    } else {
+      // odd tail: positions not covered by any window
+      for (int dyy = 0; dyy < 2; ++dyy)
+        for (int dxx = 0; dxx < 2; ++dxx) {
+          const int yy = 2 * yo + dyy, xx = 2 * xo + dxx;
+          if (yy < H && xx < W) Vec16<T>::store(dx + (((b * H + yy) * W + xx) * (int64_t)C) + cv * N, z);
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Up block input (unet_parts.py:58-68): cat([skip, pad(upsample_bilinear_x2_align_corners(deep))], C)
+//   deep [B][h][w][Cd], skip [B][H][W][Cs] -> out [B][H][W][Cs+Cd]; pad offsets (H-2h)/2, (W-2w)/2.
+__device__ __forceinline__ void bilinear_src(int dst, int in_size, int out_size, int& i0, int& i1, float& l0, float& l1) {
+  // torch area_pixel_compute_source_index, align_corners=True: src = dst * (in-1)/(out-1)
+  const float scale = out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+  const float src = scale * (float)dst;
+  i0 = (int)src;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ deep, const T* __restrict__ skip,
+                                                         T* __restrict__ out, int B, int h, int w, int Cd, int H, int W,
+                                                         int Cs) {
+  constexpr int N = Vec16<T>::N;
+  const int Ct = Cs + Cd, vpr = Ct / N, vs = Cs / N;
+  const int py = (H - 2 * h) / 2, px = (W - 2 * w) / 2;
+  const int64_t total = (int64_t)B * H * W * vpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % vpr);
+    int64_t r = i / vpr;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int64_t b = r / H;
+    if (cv < vs) {
+      *reinterpret_cast<uint4*>(out + i * N) =
+          *reinterpret_cast<const uint4*>(skip + (((b * H + y) * W + x) * (int64_t)Cs) + cv * N);
+      continue;
+    }
+    float o[N];
+    const int uy = y - py, ux = x - px;
+    if (uy < 0 || uy >= 2 * h || ux < 0 || ux >= 2 * w) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) o[k] = 0.f;
+    } else {
+      int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+      bilinear_src(uy, h, 2 * h, y0, y1, ly0, ly1);
+      bilinear_src(ux, w, 2 * w, x0, x1, lx0, lx1);
+      const int c = (cv - vs) * N;
+      float v00[N], v01[N], v10[N], v11[N];
+      Vec16<T>::load(deep + (((b * h + y0) * w + x0) * (int64_t)Cd) + c, v00);
+      Vec16<T>::load(deep + (((b * h + y0) * w + x1) * (int64_t)Cd) + c, v01);
+      Vec16<T>::load(deep + (((b * h + y1) * w + x0) * (int64_t)Cd) + c, v10);
+      Vec16<T>::load(deep + (((b * h + y1) * w + x1) * (int64_t)Cd) + c, v11);
+#pragma unroll
+      for (int k = 0; k < N; ++k) o[k] = ly0 * (lx0 * v00[k] + lx1 * v01[k]) + ly1 * (lx0 * v10[k] + lx1 * v11[k]);
+    }
+    Vec16<T>::store(out + i * N, o);
+  }
+}
+
+// backward: dskip = dout[..., :Cs] (copy), ddeep gathered (deterministic, no atomics)
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_bwd_kernel(const T* __restrict__ dout, T* __restrict__ ddeep,
+                                                         T* __restrict__ dskip, int B, int h, int w, int Cd, int H, int W,
+                                                         int Cs) {
+  constexpr int N = Vec16<T>::N;
+  const int Ct = Cs + Cd, vs = Cs / N, vd = Cd / N;
+  const int py = (H - 2 * h) / 2, px = (W - 2 * w) / 2;
+  const int64_t n_skip = (int64_t)B * H * W * vs, n_deep = (int64_t)B * h * w * vd;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_skip + n_deep; i += (int64_t)gridDim.x * 256) {
+    if (i < n_skip) {
+      const int cv = (int)(i % vs);
+      const int64_t pix = i / vs;
+      *reinterpret_cast<uint4*>(dskip + i * N) = *reinterpret_cast<const uint4*>(dout + pix * Ct + cv * N);
+      continue;
+    }
+    const int64_t j = i - n_skip;
+    const int cv = (int)(j % vd);
+    int64_t r = j / vd;
+    const int xi = (int)(r % w); r /= w;
+    const int yi = (int)(r % h);
+    const int64_t b = r / h;
+    float acc[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] = 0.f;
+    // output rows whose source index pair can contain yi: uy in [2*yi-2, 2*yi+3]
+    for (int uy = max(0, 2 * yi - 2); uy <= min(2 * h - 1, 2 * yi + 3); ++uy) {
+      int y0, y1; float ly0, ly1;
+      bilinear_src(uy, h, 2 * h, y0, y1, ly0, ly1);
+      const float wy = (y0 == yi ? ly0 : 0.f) + (y1 == yi ? ly1 : 0.f);
+      if (wy == 0.f) continue;
+      const int y = uy + py;
+      if (y < 0 || y >= H) continue;
+      for (int ux = max(0, 2 * xi - 2); ux <= min(2 * w - 1, 2 * xi + 3); ++ux) {
+        int x0, x1; float lx0, lx1;
+        bilinear_src(ux, w, 2 * w, x0, x1, lx0, lx1);
+        const float wx = (x0 == xi ? lx0 : 0.f) + (x1 == xi ? lx1 : 0.f);
+        if (wx == 0.f) continue;
+        const int x = ux + px;
+        if (x < 0 || x >= W) continue;
+        float g[N];
+        Vec16<T>::load(dout + (((b * H + y) * W + x) * (int64_t)Ct) + Cs + cv * N, g);
+        const float ww = wy * wx;
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] += ww * g[k];
+      }
+    }
+    Vec16<T>::store(ddeep + j * N, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused quantile loss (quantile_layer.py:23-32, pinball.py:12-26): three plane pointers + image stride
+// so PinballLoss alone can reuse it.  sums[3] (fp64 via partials) then
+//   loss = w_lo * S_lo/P + w_hi * S_hi/P + w_mse * S_mse/P
+struct LossArgs {
+  const float* lo; const float* mid; const float* hi; const float* y;
+  int64_t N, P, img_stride;      // planes: ptr + n*img_stride + i ; y: n*P + i
+  float q_lo, q_hi;
+};
+__global__ __launch_bounds__(256) void qloss_partial_kernel(LossArgs a, float* __restrict__ partial) {
+  __shared__ float s_red[3][4];
+  const int64_t total = a.N * a.P;
+  float s_lo = 0.f, s_hi = 0.f, s_m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / a.P, p = i - n * a.P;
+    const float y = a.y[i];
+    const float el = a.lo[n * a.img_stride + p] - y;
+    const float eh = a.hi[n * a.img_stride + p] - y;
+    const float em = a.mid[n * a.img_stride + p] - y;
+    s_lo += (el < 0.f) ? a.q_lo * fabsf(el) : (el > 0.f ? (1.f - a.q_lo) * fabsf(el) : 0.f);
+    s_hi += (eh < 0.f) ? a.q_hi * fabsf(eh) : (eh > 0.f ? (1.f - a.q_hi) * fabsf(eh) : 0.f);
+    s_m += em * em;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s_lo += __shfl_down(s_lo, off, 64); s_hi += __shfl_down(s_hi, off, 64); s_m += __shfl_down(s_m, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = s_lo; s_red[1][threadIdx.x >> 6] = s_hi; s_red[2][threadIdx.x >> 6] = s_m; }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    partial[(size_t)blockIdx.x * 3 + threadIdx.x] = s_red[threadIdx.x][0] + s_red[threadIdx.x][1] + s_red[threadIdx.x][2] + s_red[threadIdx.x][3];
+}
+__global__ void qloss_final_kernel(const double* __restrict__ tmp, int S, double count, float w_lo, float w_hi, float w_mse,
+                                   float* __restrict__ loss) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s[3] = {0, 0, 0};
+  for (int i = 0; i < S; ++i) for (int k = 0; k < 3; ++k) s[k] += tmp[(size_t)i * 3 + k];
+  // each term is an fp32 mean in the reference; combine in fp32 in the same order
+  const float l0 = (float)(s[0] / count), l1 = (float)(s[1] / count), l2 = (float)(s[2] / count);
+  loss[0] = w_lo * l0 + w_hi * l1 + w_mse * l2;
+}
+// d(pred)[N][3][P] fp32 ; gscale points at the upstream scalar gradient on the device
+__global__ __launch_bounds__(256) void qloss_bwd_kernel(LossArgs a, const float* __restrict__ gscale, float w_lo, float w_hi,
+                                                         float w_mse, float* __restrict__ d_lo, float* __restrict__ d_mid,
+                                                         float* __restrict__ d_hi, int64_t d_stride) {
+  const int64_t total = a.N * a.P;
+  const float g = gscale[0] / (float)total;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / a.P, p = i - n * a.P;
+    const float y = a.y[i];
+    const float el = a.lo[n * a.img_stride + p] - y;
+    const float eh = a.hi[n * a.img_stride + p] - y;
+    const float em = a.mid[n * a.img_stride + p] - y;
+    if (d_lo) d_lo[n * d_stride + p] = g * w_lo * (el < 0.f ? -a.q_lo : (el > 0.f ? 1.f - a.q_lo : 0.f));
+    if (d_hi) d_hi[n * d_stride + p] = g * w_hi * (eh < 0.f ? -a.q_hi : (eh > 0.f ? 1.f - a.q_hi : 0.f));
+    if (d_mid) d_mid[n * d_stride + p] = g * w_mse * 2.f * em;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-tensor Adam (torch.optim.Adam defaults as used at core/scripts/train.py:120; no weight decay / amsgrad)
+constexpr int ADAM_MAX_TENSORS = 24;
+struct AdamArgs {
+  float* p[ADAM_MAX_TENSORS]; const float* g[ADAM_MAX_TENSORS]; float* m[ADAM_MAX_TENSORS]; float* v[ADAM_MAX_TENSORS];
+  int64_t start[ADAM_MAX_TENSORS + 1];     // prefix sums of sizes in units of 1024-element chunks
+  int n;
+  int64_t size[ADAM_MAX_TENSORS];
+  float lr, beta1, beta2, eps, step_size, bc2_sqrt;
+};
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+  // find the tensor of this 1024-element chunk
+  const int64_t chunk = blockIdx.x;
+  int t = 0;
+  while (t + 1 < a.n && chunk >= a.start[t + 1]) ++t;
+  const int64_t off = (chunk - a.start[t]) * 1024;
+  float* __restrict__ p = a.p[t]; const float* __restrict__ g = a.g[t];
+  float* __restrict__ m = a.m[t]; float* __restrict__ v = a.v[t];
+  const int64_t n = a.size[t];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t i = off + k * 256 + threadIdx.x;
+    if (i < n) {
+      const float gi = g[i];
+      const float mi = m[i] + (1.f - a.beta1) * (gi - m[i]);               // exp_avg.lerp_(grad, 1-beta1)
+      const float vi = a.beta2 * v[i] + (1.f - a.beta2) * gi * gi;         // mul_(beta2).addcmul_(g, g, 1-beta2)
+      const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
+      m[i] = mi; v[i] = vi;
+      p[i] = p[i] - a.step_size * (mi / denom);
+    }
+  }
+}
+
+template <typename F> int for_dtype(int dtype, F f) {
+  if (dtype == IM2IM_BF16) return f((bf16_t*)nullptr);
+  if (dtype == IM2IM_F32) return f((float*)nullptr);
+  return fail_invalid("dtype");
+}
+inline int ew_blocks(int64_t n) { int64_t b = cdiv(n, 256); if (b > 256 * 32) b = 256 * 32; if (b < 1) b = 1; return (int)b; }
+
+}  // namespace
+
+// ================================================================================================
+extern "C" int64_t im2im_reduce_workspace_bytes(int64_t K) { return im2im::reduce_tmp_bytes(K); }
+
+extern "C" int im2im_bn_finalize(const float* partial, int64_t R, int32_t C, int64_t count, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                 float* mean_invstd, float* scale_shift, void* ws, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(partial && gamma && beta && mean_invstd && scale_shift && ws && R > 0 && C > 0 && count > 0);
+  IM2IM_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+  int rc;
+  const int S = launch_reduce_stage1(partial, R, 2 * (int64_t)C, (double*)ws, stream, &rc);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, stream, (const double*)ws, S, (int)C,
+                     (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean_invstd, scale_shift);
+  return check_launch("bn_finalize_kernel");
+}
+
+extern "C" int im2im_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                  const float* conv_bias, float eps, int32_t C, float* scale_shift, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(gamma && beta && running_mean && running_var && scale_shift && C > 0);
+  hipLaunchKernelGGL(bn_fold_eval_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, stream, gamma, beta, running_mean,
+                     running_var, conv_bias, eps, (int)C, scale_shift);
+  return check_launch("bn_fold_eval_kernel");
+}
+
+extern "C" int im2im_bn_relu_apply(const void* z, const float* scale_shift, void* a, int64_t M, int32_t C, int32_t dtype,
+                                   im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(z && scale_shift && a && M > 0 && C > 0 && C % 8 == 0);
+  return for_dtype(dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    const int64_t nvec = M * C / Vec16<T>::N;
+    hipLaunchKernelGGL(bn_relu_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, stream, (const T*)z, scale_shift, (T*)a, nvec, (int)C);
+    return check_launch("bn_relu_apply_kernel");
+  });
+}
+
+extern "C" int64_t im2im_bn_bwd_workspace_bytes(int64_t M, int32_t C) {
+  const int64_t nblk = std::min<int64_t>(cdiv(M, 64), 2048);
+  return nblk * 2 * C * (int64_t)sizeof(float) + reduce_tmp_bytes(2 * (int64_t)C) + 2 * (int64_t)C * sizeof(float);
+}
+
+extern "C" int im2im_bn_relu_bwd(const void* da, const void* z, const float* scale_shift, const float* mean_invstd, void* dz,
+                                 float* dgamma, float* dbeta, int64_t M, int32_t C, int32_t dtype, void* ws, int64_t ws_bytes,
+                                 im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(da && z && scale_shift && mean_invstd && dz && dgamma && dbeta && ws && M > 0 && C > 0 && C % 8 == 0);
+  IM2IM_REQUIRE(ws_bytes >= im2im_bn_bwd_workspace_bytes(M, C));
+  IM2IM_REQUIRE(C <= 1024);                                   // one channel vector per thread
+  const int64_t nblk = std::min<int64_t>(cdiv(M, 64), 2048);
+  const int64_t rpb = cdiv(M, nblk);
+  float* partial = (float*)ws;
+  double* tmp = (double*)((char*)ws + nblk * 2 * C * sizeof(float));
+  float* coef = (float*)((char*)tmp + reduce_tmp_bytes(2 * (int64_t)C));
+  return for_dtype(dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<T>, dim3((unsigned)cdiv(M, rpb)), dim3(256), 0, stream,
+                       (const T*)da, (const T*)z, scale_shift, mean_invstd, M, (int)C, rpb, partial);
+    if (int rc = check_launch("bn_relu_bwd_reduce_kernel")) return rc;
+    int rc;
+    const int S = launch_reduce_stage1(partial, cdiv(M, rpb), 2 * (int64_t)C, tmp, stream, &rc);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, stream, (const double*)tmp, S, (int)C,
+                       (double)M, dgamma, dbeta, coef);
+    if (int rc2 = check_launch("bn_bwd_finalize_kernel")) return rc2;
+    const int64_t nvec = M * C / Vec16<T>::N;
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, stream, (const T*)da, (const T*)z,
+                       scale_shift, mean_invstd, coef, (T*)dz, nvec, (int)C);
+    return check_launch("bn_relu_bwd_apply_kernel");
+  });
+}
+
+extern "C" int64_t im2im_colsum_workspace_bytes(int64_t M, int32_t C) {
+  const int64_t nblk = std::min<int64_t>(cdiv(M, 64), 2048);
+  return nblk * C * (int64_t)sizeof(float) + reduce_tmp_bytes(C);
+}
+
+extern "C" int im2im_colsum(const void* x, float* out, int64_t M, int32_t C, int32_t dtype, void* ws, int64_t ws_bytes,
+                            im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(x && out && ws && M > 0 && C > 0 && C % 8 == 0);
+  IM2IM_REQUIRE(ws_bytes >= im2im_colsum_workspace_bytes(M, C));
+  IM2IM_REQUIRE(C <= 1024);
+  const int64_t nblk = std::min<int64_t>(cdiv(M, 64), 2048);
+  const int64_t rpb = cdiv(M, nblk);
+  float* partial = (float*)ws;
+  double* tmp = (double*)((char*)ws + nblk * C * sizeof(float));
+  return for_dtype(dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    hipLaunchKernelGGL(colsum_partial_kernel<T>, dim3((unsigned)cdiv(M, rpb)), dim3(256), 0, stream, (const T*)x,
+                       M, (int)C, rpb, partial);
+    if (int rc = check_launch("colsum_partial_kernel")) return rc;
+    int rc;
+    const int S = launch_reduce_stage1(partial, cdiv(M, rpb), C, tmp, stream, &rc);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sum_final_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, stream, (const double*)tmp, S, (int64_t)C, out);
+    return check_launch("sum_final_kernel");
+  });
+}
+
+extern "C" int im2im_maxpool2_fwd(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                                  im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(x && y && B > 0 && H >= 2 && W >= 2 && C > 0 && C % 8 == 0);
+  return for_dtype(dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    const int64_t n = (int64_t)B * (H / 2) * (W / 2) * (C / Vec16<T>::N);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, stream, (const T*)x, (T*)y, B, H, W, C);
+    return check_launch("maxpool2_fwd_kernel");
+  });
+}
+
+extern "C" int im2im_maxpool2_bwd(const void* x, const void* dy, void* dx, int32_t B, int32_t H, int32_t W, int32_t C,
+                                  int32_t dtype, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(x && dy && dx && B > 0 && H >= 2 && W >= 2 && C > 0 && C % 8 == 0);
+  return for_dtype(dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / Vec16<T>::N);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, stream, (const T*)x, (const T*)dy, (T*)dx, B, H, W, C);
+    return check_launch("maxpool2_bwd_kernel");
+  });
+}
+
+extern "C" int im2im_upsample2x_concat_fwd(const void* deep, const void* skip, void* out, int32_t B, int32_t h, int32_t w,
+                                           int32_t Cd, int32_t H, int32_t W, int32_t Cs, int32_t dtype, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(deep && skip && out && B > 0 && h > 0 && w > 0 && H >= 2 * h && W >= 2 * w);
+  IM2IM_REQUIRE(Cd > 0 && Cs > 0 && Cd % 8 == 0 && Cs % 8 == 0);
+  return for_dtype(dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    const int64_t n = (int64_t)B * H * W * ((Cs + Cd) / Vec16<T>::N);
+    hipLaunchKernelGGL(upcat_fwd_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, stream, (const T*)deep, (const T*)skip, (T*)out, B, h, w, Cd, H, W, Cs);
+    return check_launch("upcat_fwd_kernel");
+  });
+}
+
+extern "C" int im2im_upsample2x_concat_bwd(const void* dout, void* ddeep, void* dskip, int32_t B, int32_t h, int32_t w,
+                                           int32_t Cd, int32_t H, int32_t W, int32_t Cs, int32_t dtype, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(dout && ddeep && dskip && B > 0 && h > 0 && w > 0 && H >= 2 * h && W >= 2 * w);
+  IM2IM_REQUIRE(Cd > 0 && Cs > 0 && Cd % 8 == 0 && Cs % 8 == 0);
+  return for_dtype(dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    const int64_t n = (int64_t)B * H * W * (Cs / Vec16<T>::N) + (int64_t)B * h * w * (Cd / Vec16<T>::N);
+    hipLaunchKernelGGL(upcat_bwd_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, stream, (const T*)dout, (T*)ddeep, (T*)dskip, B, h, w, Cd, H, W, Cs);
+    return check_launch("upcat_bwd_kernel");
+  });
+}
+
+extern "C" int64_t im2im_quantile_loss_workspace_bytes(void) { return 1024 * 3 * (int64_t)sizeof(float) + reduce_tmp_bytes(3); }
+
+extern "C" int im2im_quantile_loss_fwd(const float* lo, const float* mid, const float* hi, const float* target, int64_t N,
+                                       int64_t P, int64_t img_stride, float q_lo, float q_hi, float w_lo, float w_hi,
+                                       float w_mse, float* loss, void* ws, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(lo && mid && hi && target && loss && ws && N > 0 && P > 0);
+  LossArgs a{lo, mid, hi, target, N, P, img_stride, q_lo, q_hi};
+  float* partial = (float*)ws;
+  double* tmp = (double*)((char*)ws + 1024 * 3 * sizeof(float));
+  int64_t nblk = cdiv(N * P, 256 * 8);
+  if (nblk > 1024) nblk = 1024;
+  hipLaunchKernelGGL(qloss_partial_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, a, partial);
+  if (int rc = check_launch("qloss_partial_kernel")) return rc;
+  int rc;
+  const int S = launch_reduce_stage1(partial, nblk, 3, tmp, stream, &rc);
+  if (rc) return rc;
+  hipLaunchKernelGGL(qloss_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)tmp, S, (double)(N * P), w_lo, w_hi, w_mse, loss);
+  return check_launch("qloss_final_kernel");
+}
+
+extern "C" int im2im_quantile_loss_bwd(const float* lo, const float* mid, const float* hi, const float* target, int64_t N,
+                                       int64_t P, int64_t img_stride, float q_lo, float q_hi, float w_lo, float w_hi,
+                                       float w_mse, const float* grad_out, float* d_lo, float* d_mid, float* d_hi,
+                                       int64_t d_stride, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(lo && mid && hi && target && grad_out && N > 0 && P > 0);
+  LossArgs a{lo, mid, hi, target, N, P, img_stride, q_lo, q_hi};
+  hipLaunchKernelGGL(qloss_bwd_kernel, dim3(ew_blocks(N * P)), dim3(256), 0, stream, a, grad_out, w_lo, w_hi, w_mse, d_lo, d_mid, d_hi, d_stride);
+  return check_launch("qloss_bwd_kernel");
+}
+
+extern "C" int im2im_adam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                               float* const* exp_avg_sq, const int64_t* sizes, float lr, float beta1, float beta2, float eps,
+                               int64_t step, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(n_tensors >= 0 && step >= 1);
+  IM2IM_REQUIRE(n_tensors == 0 || (params && grads && exp_avg && exp_avg_sq && sizes));
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  for (int base = 0; base < n_tensors; base += ADAM_MAX_TENSORS) {
+    AdamArgs a;
+    a.n = std::min(ADAM_MAX_TENSORS, n_tensors - base);
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+    a.step_size = (float)((double)lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    int64_t chunks = 0;
+    for (int i = 0; i < a.n; ++i) {
+      IM2IM_REQUIRE(params[base + i] && grads[base + i] && exp_avg[base + i] && exp_avg_sq[base + i] && sizes[base + i] >= 0);
+      a.p[i] = params[base + i]; a.g[i] = grads[base + i]; a.m[i] = exp_avg[base + i]; a.v[i] = exp_avg_sq[base + i];
+      a.size[i] = sizes[base + i];
+      a.start[i] = chunks;
+      chunks += cdiv(sizes[base + i], 1024);
+    }
+    a.start[a.n] = chunks;
+    if (chunks == 0) continue;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)chunks), dim3(256), 0, stream, a);
+    if (int rc = check_launch("adam_kernel")) return rc;
+  }
+  return IM2IM_OK;
+}

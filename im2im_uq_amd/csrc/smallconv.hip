@@ -1,0 +1,359 @@
+// Direct (VALU) 3x3 convolutions where one side has only a handful of channels -- memory-bound layers
+// that would waste an MFMA tile (SURVEY K1 "first conv", K7 heads):
+//   s2l : fp32 NCHW, CS<=8 channels  ->  NHWC T, CL in {32,64} channels
+//         = first UNet conv (core/models/trunks/unet_parts.py:16 with Cin = n_in) incl. BatchNorm partial
+//           statistics / folded eval BN + ReLU, and the data-gradient of the quantile heads;
+//   l2s : NHWC T, CL channels -> fp32 NCHW planes, CS<=8 channels
+//         = the three quantile heads written straight into the [B,3,C,H,W] output
+//           (core/models/finallayers/quantile_layer.py:15-17,20);
+//   wgrad : out[s][tap][l] = sum_px L[px][l] * S[s][px+tap]  -> weight gradients of both.
+// One thread per pixel of a 16x16 tile; the small side's weights are wave-uniform, so they are fetched
+// with scalar loads and cost no LDS or vector bandwidth.
+#include "common.h"
+#include "dtypes.h"
+#include "reduce.h"
+
+namespace {
+using namespace im2im;
+
+constexpr int TS = 16;                 // tile side
+constexpr int HS = TS + 2;             // halo side
+constexpr int CS_MAX = 8;
+
+// wave-level reduce-scatter of v[CL] over the 64 lanes: lane l ends with the wave sum of channel l % CL
+// (for CL == 32 both 32-lane halves are combined as well).
+template <int CL>
+__device__ __forceinline__ float wave_reduce_scatter(float (&v)[CL], int lane) {
+  float cur[CL];
+#pragma unroll
+  for (int i = 0; i < CL; ++i) cur[i] = v[i];
+  int n = CL;
+#pragma unroll
+  for (int off = CL / 2; off >= 1; off >>= 1) {
+    const bool up = (lane & off) != 0;
+#pragma unroll
+    for (int i = 0; i < off; ++i) {
+      const float send = up ? cur[i] : cur[i + off];
+      const float keep = up ? cur[i + off] : cur[i];
+      cur[i] = keep + __shfl_xor(send, off, 64);
+    }
+    n = off;
+  }
+  (void)n;
+  float r = cur[0];
+  if (CL == 32) r += __shfl_xor(r, 32, 64);
+  return r;
+}
+
+struct S2LArgs {
+  const float* in;      // [B][CS][H][W]
+  const float* w;       // [CS][9][CL]
+  const float* bias;    // [CL] | null
+  const float* scale_shift;   // [2][CL] | null
+  void* out;            // [B][H][W][CL] T
+  float* stats;         // [blk][2][CL] | null
+  int B, H, W, CS, tilesY, tilesX, relu, flip;
+};
+
+template <typename T, int CL>
+__global__ __launch_bounds__(256) void smallconv_s2l_kernel(S2LArgs a) {
+  __shared__ float s_in[CS_MAX][HS][HS + 1];
+  __shared__ float s_stat[4][2][CL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int t = blockIdx.x;
+  const int tx_id = t % a.tilesX; t /= a.tilesX;
+  const int ty_id = t % a.tilesY;
+  const int b = t / a.tilesY;
+  const int y0 = ty_id * TS, x0 = tx_id * TS;
+  const float* inb = a.in + (size_t)b * a.CS * a.H * a.W;
+  for (int i = tid; i < a.CS * HS * HS; i += 256) {
+    const int s = i / (HS * HS), r = i % (HS * HS);
+    const int hy = r / HS, hx = r % HS;
+    const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+    s_in[s][hy][hx] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? inb[((size_t)s * a.H + yy) * a.W + xx] : 0.f;
+  }
+  __syncthreads();
+  const int ty = tid / TS, tx = tid % TS;
+  float acc[CL];
+#pragma unroll
+  for (int l = 0; l < CL; ++l) acc[l] = a.bias ? a.bias[l] : 0.f;
+  for (int s = 0; s < a.CS; ++s) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const float xv = s_in[s][ty + tap / 3][tx + tap % 3];
+      const float* wr = a.w + ((size_t)s * 9 + (a.flip ? 8 - tap : tap)) * CL;      // wave-uniform -> scalar loads
+#pragma unroll
+      for (int l = 0; l < CL; ++l) acc[l] += xv * wr[l];
+    }
+  }
+  const int yy = y0 + ty, xx = x0 + tx;
+  const bool valid = yy < a.H && xx < a.W;
+  if (a.scale_shift) {
+#pragma unroll
+    for (int l = 0; l < CL; ++l) acc[l] = acc[l] * a.scale_shift[l] + a.scale_shift[CL + l];
+  }
+  if (a.relu) {
+#pragma unroll
+    for (int l = 0; l < CL; ++l) acc[l] = fmaxf(acc[l], 0.f);
+  }
+  // round to the storage type first so the statistics describe what BatchNorm will normalise
+#pragma unroll
+  for (int l = 0; l < CL; ++l) acc[l] = to_float(from_float<T>(acc[l]));
+  if (valid) {
+    T* o = reinterpret_cast<T*>(a.out) + (((size_t)b * a.H + yy) * a.W + xx) * CL;
+    constexpr int N = Vec16<T>::N;
+#pragma unroll
+    for (int l = 0; l < CL; l += N) Vec16<T>::store(o + l, acc + l);
+  }
+  if (a.stats) {
+    float sq[CL];
+#pragma unroll
+    for (int l = 0; l < CL; ++l) { if (!valid) acc[l] = 0.f; sq[l] = acc[l] * acc[l]; }
+    const float s1 = wave_reduce_scatter<CL>(acc, lane);
+    const float s2 = wave_reduce_scatter<CL>(sq, lane);
+    if (lane < CL) { s_stat[wave][0][lane] = s1; s_stat[wave][1][lane] = s2; }
+    __syncthreads();
+    if (tid < 2 * CL) {
+      const int which = tid / CL, c = tid % CL;
+      a.stats[(size_t)blockIdx.x * 2 * CL + which * CL + c] =
+          s_stat[0][which][c] + s_stat[1][which][c] + s_stat[2][which][c] + s_stat[3][which][c];
+    }
+  }
+}
+
+struct L2SArgs {
+  const void* in;       // [B][H][W][CL] T
+  const float* w;       // [CS][9][CL]
+  const float* bias;    // [CS] | null
+  float* out;           // [B][CS][H][W]
+  int B, H, W, CS, tilesY, tilesX;
+};
+
+template <typename T, int CL>
+__global__ __launch_bounds__(256) void smallconv_l2s_kernel(L2SArgs a) {
+  constexpr int N = Vec16<T>::N;
+  constexpr int PITCH = CL * (int)sizeof(T) + 16;
+  __shared__ __attribute__((aligned(16))) char s_in[HS * HS * PITCH];
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int tx_id = t % a.tilesX; t /= a.tilesX;
+  const int ty_id = t % a.tilesY;
+  const int b = t / a.tilesY;
+  const int y0 = ty_id * TS, x0 = tx_id * TS;
+  const T* inb = reinterpret_cast<const T*>(a.in) + (size_t)b * a.H * a.W * CL;
+  constexpr int PPR = CL / N;
+  for (int i = tid; i < HS * HS * PPR; i += 256) {
+    const int px = i / PPR, part = i % PPR;
+    const int yy = y0 + px / HS - 1, xx = x0 + px % HS - 1;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
+      v = *reinterpret_cast<const uint4*>(inb + ((size_t)yy * a.W + xx) * CL + part * N);
+    *reinterpret_cast<uint4*>(s_in + px * PITCH + part * 16) = v;
+  }
+  __syncthreads();
+  const int ty = tid / TS, tx = tid % TS;
+  float acc[CS_MAX];
+#pragma unroll
+  for (int s = 0; s < CS_MAX; ++s) acc[s] = (a.bias && s < a.CS) ? a.bias[s] : 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const char* row = s_in + ((ty + tap / 3) * HS + tx + tap % 3) * PITCH;
+#pragma unroll
+    for (int part = 0; part < PPR; ++part) {
+      float xv[N];
+      Vec16<T>::load(reinterpret_cast<const T*>(row + part * 16), xv);
+#pragma unroll
+      for (int s = 0; s < CS_MAX; ++s) {
+        if (s < a.CS) {
+          const float* wr = a.w + ((size_t)s * 9 + tap) * CL + part * N;   // wave-uniform
+#pragma unroll
+          for (int k = 0; k < N; ++k) acc[s] += xv[k] * wr[k];
+        }
+      }
+    }
+  }
+  const int yy = y0 + ty, xx = x0 + tx;
+  if (yy < a.H && xx < a.W) {
+#pragma unroll
+    for (int s = 0; s < CS_MAX; ++s)
+      if (s < a.CS) a.out[(((size_t)b * a.CS + s) * a.H + yy) * a.W + xx] = acc[s];
+  }
+}
+
+struct SWArgs {
+  const float* S;       // [B][CS][H][W] fp32
+  const void* L;        // [B][H][W][CL] T
+  float* partial;       // [blk][CS*9*CL + CS]
+  int B, H, W, CS, tilesY, tilesX;
+};
+
+template <typename T, int CL>
+__global__ __launch_bounds__(256) void smallconv_wgrad_kernel(SWArgs a) {
+  constexpr int N = Vec16<T>::N;
+  constexpr int G = 256 / CL;
+  __shared__ __attribute__((aligned(16))) T s_L[TS * TS][CL];
+  __shared__ float s_S[CS_MAX][HS][HS + 1];
+  __shared__ float s_red[G][9][CL];
+  __shared__ float s_b[G];
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int tx_id = t % a.tilesX; t /= a.tilesX;
+  const int ty_id = t % a.tilesY;
+  const int b = t / a.tilesY;
+  const int y0 = ty_id * TS, x0 = tx_id * TS;
+  const float* Sb = a.S + (size_t)b * a.CS * a.H * a.W;
+  const T* Lb = reinterpret_cast<const T*>(a.L) + (size_t)b * a.H * a.W * CL;
+  for (int i = tid; i < a.CS * HS * HS; i += 256) {
+    const int s = i / (HS * HS), r = i % (HS * HS);
+    const int hy = r / HS, hx = r % HS;
+    const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+    s_S[s][hy][hx] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? Sb[((size_t)s * a.H + yy) * a.W + xx] : 0.f;
+  }
+  constexpr int PPR = CL / N;
+  for (int i = tid; i < TS * TS * PPR; i += 256) {
+    const int px = i / PPR, part = i % PPR;
+    const int yy = y0 + px / TS, xx = x0 + px % TS;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (yy < a.H && xx < a.W) v = *reinterpret_cast<const uint4*>(Lb + ((size_t)yy * a.W + xx) * CL + part * N);
+    *reinterpret_cast<uint4*>(&s_L[px][part * N]) = v;
+  }
+  __syncthreads();
+  const int l = tid % CL, g = tid / CL;
+  float acc[CS_MAX][9];
+  float bsum[CS_MAX];
+#pragma unroll
+  for (int s = 0; s < CS_MAX; ++s) {
+    bsum[s] = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) acc[s][tp] = 0.f;
+  }
+  for (int px = g; px < TS * TS; px += G) {
+    const float lv = to_float(s_L[px][l]);
+    const int ty = px / TS, tx = px % TS;
+#pragma unroll
+    for (int s = 0; s < CS_MAX; ++s) {
+      if (s < a.CS) {
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) acc[s][tp] += lv * s_S[s][ty + tp / 3][tx + tp % 3];
+        bsum[s] += s_S[s][ty + 1][tx + 1];
+      }
+    }
+  }
+  const int K = a.CS * 9 * CL + a.CS;
+  float* out = a.partial + (size_t)blockIdx.x * K;
+  for (int s = 0; s < a.CS; ++s) {
+    __syncthreads();
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < CS_MAX; ++q) if (q == s) v = acc[q][tp];
+      s_red[g][tp][l] = v;
+    }
+    if (l == 0) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < CS_MAX; ++q) if (q == s) v = bsum[q];
+      s_b[g] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < 9 * CL; i += 256) {
+      const int tp = i / CL, ll = i % CL;
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < G; ++q) v += s_red[q][tp][ll];
+      out[((size_t)s * 9 + tp) * CL + ll] = v;
+    }
+    if (tid == 0) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < G; ++q) v += s_b[q];
+      out[(size_t)a.CS * 9 * CL + s] = v;
+    }
+  }
+}
+
+// tmp[S][K] -> dw with index map, dbias tail
+//   l_major != 0: dw[(l*CS + s)*9 + tap]        (first conv: weight [co=l][ci=s][tap])
+//   l_major == 0: dw[(s*CL + l)*9 + (8 - tap)]  (heads: weight [co=s][ci=l][tap], correlation flipped)
+__global__ __launch_bounds__(256) void smallconv_wgrad_final_kernel(const double* __restrict__ tmp, int S, int CS, int CL,
+                                                                     int l_major, float* __restrict__ dw,
+                                                                     float* __restrict__ dbias) {
+  const int K = CS * 9 * CL + CS;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  double v = 0.0;
+  for (int i = 0; i < S; ++i) v += tmp[(size_t)i * K + k];
+  if (k >= CS * 9 * CL) { if (dbias) dbias[k - CS * 9 * CL] = (float)v; return; }
+  const int l = k % CL, tp = (k / CL) % 9, s = k / (9 * CL);
+  if (l_major) dw[((size_t)l * CS + s) * 9 + tp] = (float)v;
+  else dw[((size_t)s * CL + l) * 9 + (8 - tp)] = (float)v;
+}
+
+template <typename F> int for_dtype_cl(int dtype, int CL, F f) {
+  if (dtype == IM2IM_BF16 && CL == 64) return f((bf16_t*)nullptr, std::integral_constant<int, 64>{});
+  if (dtype == IM2IM_BF16 && CL == 32) return f((bf16_t*)nullptr, std::integral_constant<int, 32>{});
+  if (dtype == IM2IM_F32 && CL == 64) return f((float*)nullptr, std::integral_constant<int, 64>{});
+  if (dtype == IM2IM_F32 && CL == 32) return f((float*)nullptr, std::integral_constant<int, 32>{});
+  return fail_invalid("small conv: dtype must be f32/bf16 and the wide side 32 or 64 channels");
+}
+
+}  // namespace
+
+extern "C" int64_t im2im_smallconv_tiles(int32_t B, int32_t H, int32_t W) {
+  return (int64_t)B * im2im::cdiv(H, TS) * im2im::cdiv(W, TS);
+}
+
+extern "C" int im2im_smallconv_s2l_fwd(const float* in, const float* w, const float* bias, const float* scale_shift, void* out,
+                                       float* stats, int32_t B, int32_t H, int32_t W, int32_t CS, int32_t CL, int32_t relu,
+                                       int32_t flip, int32_t dtype, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(in && w && out && B > 0 && H > 0 && W > 0 && CS >= 1 && CS <= CS_MAX);
+  S2LArgs a{in, w, bias, scale_shift, out, stats, B, H, W, CS, (int)cdiv(H, TS), (int)cdiv(W, TS), relu, flip};
+  return for_dtype_cl(dtype, CL, [&](auto* tag, auto cl) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    hipLaunchKernelGGL((smallconv_s2l_kernel<T, decltype(cl)::value>), dim3((unsigned)(B * a.tilesY * a.tilesX)), dim3(256), 0, stream, a);
+    return check_launch("smallconv_s2l_kernel");
+  });
+}
+
+extern "C" int im2im_smallconv_l2s_fwd(const void* in, const float* w, const float* bias, float* out, int32_t B, int32_t H,
+                                       int32_t W, int32_t CL, int32_t CS, int32_t dtype, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(in && w && out && B > 0 && H > 0 && W > 0 && CS >= 1 && CS <= CS_MAX);
+  L2SArgs a{in, w, bias, out, B, H, W, CS, (int)cdiv(H, TS), (int)cdiv(W, TS)};
+  return for_dtype_cl(dtype, CL, [&](auto* tag, auto cl) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    hipLaunchKernelGGL((smallconv_l2s_kernel<T, decltype(cl)::value>), dim3((unsigned)(B * a.tilesY * a.tilesX)), dim3(256), 0, stream, a);
+    return check_launch("smallconv_l2s_kernel");
+  });
+}
+
+extern "C" int64_t im2im_smallconv_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t CS, int32_t CL) {
+  const int64_t K = (int64_t)CS * 9 * CL + CS;
+  return im2im_smallconv_tiles(B, H, W) * K * (int64_t)sizeof(float) + im2im::reduce_tmp_bytes(K);
+}
+
+extern "C" int im2im_smallconv_wgrad(const float* S, const void* L, float* dw, float* dbias, int32_t B, int32_t H, int32_t W,
+                                     int32_t CS, int32_t CL, int32_t l_major, int32_t dtype, void* ws, int64_t ws_bytes,
+                                     im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(S && L && dw && ws && B > 0 && H > 0 && W > 0 && CS >= 1 && CS <= CS_MAX);
+  IM2IM_REQUIRE(ws_bytes >= im2im_smallconv_wgrad_workspace_bytes(B, H, W, CS, CL));
+  const int64_t nblk = im2im_smallconv_tiles(B, H, W);
+  const int64_t K = (int64_t)CS * 9 * CL + CS;
+  float* partial = (float*)ws;
+  double* tmp = (double*)((char*)ws + nblk * K * sizeof(float));
+  SWArgs a{S, L, partial, B, H, W, CS, (int)cdiv(H, TS), (int)cdiv(W, TS)};
+  return for_dtype_cl(dtype, CL, [&](auto* tag, auto cl) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    hipLaunchKernelGGL((smallconv_wgrad_kernel<T, decltype(cl)::value>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
+    if (int rc = check_launch("smallconv_wgrad_kernel")) return rc;
+    int rc;
+    const int Sp = launch_reduce_stage1(partial, nblk, K, tmp, stream, &rc);
+    if (rc) return rc;
+    hipLaunchKernelGGL(smallconv_wgrad_final_kernel, dim3((unsigned)cdiv(K, 256)), dim3(256), 0, stream, (const double*)tmp, Sp,
+                       (int)CS, (int)CL, (int)l_major, dw, dbias);
+    return check_launch("smallconv_wgrad_final_kernel");
+  });
+}

@@ -1,0 +1,464 @@
+"""autograd.Function layer over the HIP training kernels (C ABI in include/im2im_uq.h).
+
+Internal activation convention: tensors are *logically* NCHW ([B,C,H,W], so user code and
+state_dicts see the reference's shapes) but live in channels-last memory in the compute dtype
+(bf16 by default, fp32 for tight parity); `nhwc()` / `nchw()` are zero-copy views between the two.
+All arithmetic on activations happens in the HIP kernels; torch is used for allocation and autograd
+bookkeeping only.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+from . import _lib
+from ._lib import check, dptr, lib, stream_ptr
+
+F32 = torch.float32
+BF16 = torch.bfloat16
+_DT = {F32: 0, BF16: 1}
+
+_default_dtype = {"bf16": BF16, "bfloat16": BF16, "fp32": F32, "float32": F32}[
+    os.environ.get("IM2IM_COMPUTE_DTYPE", "bf16").lower()]
+
+
+def set_compute_dtype(dt) -> None:
+    """'bf16' (throughput: bf16 storage + bf16 MFMA, fp32 accumulate) or 'fp32' (exact-fp32 MFMA, parity)."""
+    global _default_dtype
+    _default_dtype = {"bf16": BF16, "fp32": F32, BF16: BF16, F32: F32}[dt]
+
+
+def get_compute_dtype():
+    return _default_dtype
+
+
+def nhwc(x: torch.Tensor, dtype=None) -> torch.Tensor:
+    """[B,C,H,W] logical -> contiguous [B,H,W,C] (view when x is channels-last in `dtype`)."""
+    y = x.permute(0, 2, 3, 1)
+    if dtype is not None and y.dtype != dtype:
+        y = y.to(dtype)
+    return y if y.is_contiguous() else y.contiguous()
+
+
+def nchw(y: torch.Tensor) -> torch.Tensor:
+    return y.permute(0, 3, 1, 2)
+
+
+class _Scratch:
+    """one growing byte buffer per device; every kernel runs on the same stream, so consecutive users
+    of the scratch are ordered."""
+    bufs = {}
+
+    @classmethod
+    def get(cls, nbytes: int, device) -> torch.Tensor:
+        key = (torch.device(device).index, "a")
+        buf = cls.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            cls.bufs[key] = buf
+        return buf
+
+
+def _gpu(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise _lib.Im2ImError(f"{name} must live on the GPU; the HIP path has no CPU fallback (got {t.device})")
+
+
+# ----------------------------------------------------------------------------------------- raw ops
+def pack_weight(w: torch.Tensor, dtype, want_wd=True):
+    """w [Co,Ci,kh,kw] fp32 -> (wf [Co,taps,Ci], wd [Ci,taps(reversed),Co]) in `dtype`."""
+    co, ci = w.shape[0], w.shape[1]
+    taps = w.shape[2] * w.shape[3]
+    w = w.detach()
+    if w.dtype != F32 or not w.is_contiguous():
+        w = w.to(F32).contiguous()
+    wf = torch.empty((co, taps, ci), dtype=dtype, device=w.device)
+    wd = torch.empty((ci, taps, co), dtype=dtype, device=w.device) if want_wd else None
+    check(lib.im2im_pack_conv_weight(dptr(w), co, ci, taps, _DT[dtype], dptr(wf), dptr(wd), stream_ptr(w.device)),
+          "im2im_pack_conv_weight")
+    return wf, wd
+
+
+def conv_fwd(x, wf, bias=None, scale_shift=None, relu=False, want_stats=False):
+    """x [B,H,W,Ci], wf [Co,taps,Ci] -> y [B,H,W,Co] (+ stats [R,2,Co])."""
+    b, h, w_, ci = x.shape
+    co, taps = wf.shape[0], wf.shape[1]
+    y = torch.empty((b, h, w_, co), dtype=x.dtype, device=x.device)
+    stats = None
+    if want_stats:
+        rows = lib.im2im_conv_stats_rows(b, h, w_, co)
+        stats = torch.empty((rows, 2, co), dtype=F32, device=x.device)
+    sc = sh = None
+    if scale_shift is not None:
+        sc, sh = scale_shift[0], scale_shift[1]
+    check(lib.im2im_conv_fwd(dptr(x), dptr(wf), dptr(bias), dptr(sc), dptr(sh), dptr(y), dptr(stats), b, h, w_, ci, co, taps,
+                             int(relu), _DT[x.dtype], stream_ptr(x.device)), "im2im_conv_fwd")
+    return (y, stats) if want_stats else y
+
+
+def conv_wgrad(x, dz, taps):
+    """x [B,H,W,Ci], dz [B,H,W,Co] -> dw [Co,Ci,taps] fp32."""
+    b, h, w_, ci = x.shape
+    co = dz.shape[3]
+    nbytes = lib.im2im_conv_wgrad_workspace_bytes(b, h, w_, ci, co, taps)
+    if nbytes < 0:
+        raise _lib.Im2ImError(f"conv wgrad: unsupported channels Ci={ci} Co={co}")
+    ws = _Scratch.get(nbytes, x.device)
+    dw = torch.empty((co, ci, taps), dtype=F32, device=x.device)
+    check(lib.im2im_conv_wgrad(dptr(x), dptr(dz), dptr(dw), dptr(ws), ws.numel(), b, h, w_, ci, co, taps, _DT[x.dtype],
+                               stream_ptr(x.device)), "im2im_conv_wgrad")
+    return dw
+
+
+def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps):
+    rows, _, c = stats.shape
+    dev = stats.device
+    mean_invstd = torch.empty((2, c), dtype=F32, device=dev)
+    scale_shift = torch.empty((2, c), dtype=F32, device=dev)
+    ws = _Scratch.get(lib.im2im_reduce_workspace_bytes(2 * c), dev)
+    check(lib.im2im_bn_finalize(dptr(stats), rows, c, count, dptr(gamma), dptr(beta), dptr(running_mean), dptr(running_var),
+                                float(momentum), float(eps), dptr(mean_invstd), dptr(scale_shift), dptr(ws), stream_ptr(dev)),
+          "im2im_bn_finalize")
+    return mean_invstd, scale_shift
+
+
+def bn_fold_eval(gamma, beta, running_mean, running_var, conv_bias, eps):
+    c = gamma.numel()
+    out = torch.empty((2, c), dtype=F32, device=gamma.device)
+    check(lib.im2im_bn_fold_eval(dptr(gamma), dptr(beta), dptr(running_mean), dptr(running_var), dptr(conv_bias), float(eps), c,
+                                 dptr(out), stream_ptr(gamma.device)), "im2im_bn_fold_eval")
+    return out
+
+
+def bn_relu_apply(z, scale_shift):
+    a = torch.empty_like(z)
+    c = z.shape[-1]
+    check(lib.im2im_bn_relu_apply(dptr(z), dptr(scale_shift), dptr(a), z.numel() // c, c, _DT[z.dtype], stream_ptr(z.device)),
+          "im2im_bn_relu_apply")
+    return a
+
+
+def bn_relu_bwd(da, z, scale_shift, mean_invstd):
+    c = z.shape[-1]
+    m = z.numel() // c
+    dev = z.device
+    dz = torch.empty_like(z)
+    dgamma = torch.empty((c,), dtype=F32, device=dev)
+    dbeta = torch.empty((c,), dtype=F32, device=dev)
+    nbytes = lib.im2im_bn_bwd_workspace_bytes(m, c)
+    ws = _Scratch.get(nbytes, dev)
+    check(lib.im2im_bn_relu_bwd(dptr(da), dptr(z), dptr(scale_shift), dptr(mean_invstd), dptr(dz), dptr(dgamma), dptr(dbeta), m, c,
+                                _DT[z.dtype], dptr(ws), ws.numel(), stream_ptr(dev)), "im2im_bn_relu_bwd")
+    return dz, dgamma, dbeta
+
+
+def colsum(x):
+    c = x.shape[-1]
+    m = x.numel() // c
+    out = torch.empty((c,), dtype=F32, device=x.device)
+    ws = _Scratch.get(lib.im2im_colsum_workspace_bytes(m, c), x.device)
+    check(lib.im2im_colsum(dptr(x), dptr(out), m, c, _DT[x.dtype], dptr(ws), ws.numel(), stream_ptr(x.device)), "im2im_colsum")
+    return out
+
+
+def smallconv_s2l(x_nchw, w, bias, scale_shift, cl, dtype, relu=False, flip=False, want_stats=False):
+    b, cs, h, w_ = x_nchw.shape
+    out = torch.empty((b, h, w_, cl), dtype=dtype, device=x_nchw.device)
+    stats = None
+    if want_stats:
+        stats = torch.empty((lib.im2im_smallconv_tiles(b, h, w_), 2, cl), dtype=F32, device=x_nchw.device)
+    check(lib.im2im_smallconv_s2l_fwd(dptr(x_nchw), dptr(w), dptr(bias), dptr(scale_shift), dptr(out), dptr(stats), b, h, w_, cs, cl,
+                                      int(relu), int(flip), _DT[dtype], stream_ptr(x_nchw.device)), "im2im_smallconv_s2l_fwd")
+    return (out, stats) if want_stats else out
+
+
+def smallconv_l2s(x, w, bias, cs):
+    b, h, w_, cl = x.shape
+    out = torch.empty((b, cs, h, w_), dtype=F32, device=x.device)
+    check(lib.im2im_smallconv_l2s_fwd(dptr(x), dptr(w), dptr(bias), dptr(out), b, h, w_, cl, cs, _DT[x.dtype], stream_ptr(x.device)),
+          "im2im_smallconv_l2s_fwd")
+    return out
+
+
+def smallconv_wgrad(s_nchw, l_nhwc, l_major, want_bias):
+    b, cs, h, w_ = s_nchw.shape
+    cl = l_nhwc.shape[3]
+    dev = s_nchw.device
+    dw = torch.empty((cl, cs, 9) if l_major else (cs, cl, 9), dtype=F32, device=dev)
+    dbias = torch.empty((cs,), dtype=F32, device=dev) if want_bias else None
+    ws = _Scratch.get(lib.im2im_smallconv_wgrad_workspace_bytes(b, h, w_, cs, cl), dev)
+    check(lib.im2im_smallconv_wgrad(dptr(s_nchw), dptr(l_nhwc), dptr(dw), dptr(dbias), b, h, w_, cs, cl, int(l_major),
+                                    _DT[l_nhwc.dtype], dptr(ws), ws.numel(), stream_ptr(dev)), "im2im_smallconv_wgrad")
+    return dw, dbias
+
+
+# ----------------------------------------------------------------------------------------- autograd
+class ConvBnReluTrain(torch.autograd.Function):
+    """conv3x3(pad 1, bias) -> BatchNorm2d(batch statistics) -> ReLU  (unet_parts.py:16-18 / 19-21), train mode.
+
+    The conv epilogue emits the per-channel partial sums, so BatchNorm statistics cost no extra pass over
+    the activation.  The conv bias shifts the batch mean and cancels in the normalised output, so its
+    gradient is identically zero here (the reference's autograd produces rounding noise around zero)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, cdt):
+        _gpu(x, "input")
+        co, ci = weight.shape[0], weight.shape[1]
+        small = ci <= 8
+        b, _, h, w_ = x.shape
+        if small:
+            xin = x.detach().to(F32).contiguous()
+            _, wd = pack_weight(weight, F32)
+            z, stats = smallconv_s2l(xin, wd, bias.detach(), None, co, cdt, flip=True, want_stats=True)
+            wd = None
+        else:
+            xin = nhwc(x.detach(), cdt)
+            wf, wd = pack_weight(weight, cdt)
+            z, stats = conv_fwd(xin, wf, bias.detach(), want_stats=True)
+        mean_invstd, scale_shift = bn_finalize(stats, b * h * w_, gamma.detach(), beta.detach(), running_mean, running_var,
+                                               momentum, eps)
+        a = bn_relu_apply(z, scale_shift)
+        ctx.small = small
+        ctx.save_for_backward(xin, z, scale_shift, mean_invstd, wd if wd is not None else torch.empty(0), bias)
+        return nchw(a)
+
+    @staticmethod
+    def backward(ctx, da):
+        xin, z, scale_shift, mean_invstd, wd, bias = ctx.saved_tensors
+        da = nhwc(da, z.dtype)
+        dz, dgamma, dbeta = bn_relu_bwd(da, z, scale_shift, mean_invstd)
+        dx = None
+        if ctx.small:
+            dw, _ = smallconv_wgrad(xin, dz, l_major=True, want_bias=False)
+            dw = dw.view(dz.shape[3], xin.shape[1], 3, 3)
+        else:
+            dw = conv_wgrad(xin, dz, 9).view(dz.shape[3], xin.shape[3], 3, 3)
+            if ctx.needs_input_grad[0]:
+                dx = nchw(conv_fwd(dz, wd))
+        return dx, dw, torch.zeros_like(bias), dgamma, dbeta, None, None, None, None, None
+
+
+def conv_bn_relu_eval(x, weight, bias, gamma, beta, running_mean, running_var, eps, cdt, cache=None):
+    """eval mode: BatchNorm folded into the conv epilogue (one kernel, no intermediate)."""
+    _gpu(x, "input")
+    co, ci = weight.shape[0], weight.shape[1]
+    fold = bn_fold_eval(gamma.detach(), beta.detach(), running_mean, running_var, bias.detach(), eps)
+    if ci <= 8:
+        xin = x.detach().to(F32).contiguous()
+        _, wd = pack_weight(weight, F32)
+        return nchw(smallconv_s2l(xin, wd, None, fold, co, cdt, relu=True, flip=True))
+    wf, _ = pack_weight(weight, cdt, want_wd=False)
+    return nchw(conv_fwd(nhwc(x.detach(), cdt), wf, None, fold, relu=True))
+
+
+class MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xin = nhwc(x.detach())
+        b, h, w_, c = xin.shape
+        y = torch.empty((b, h // 2, w_ // 2, c), dtype=xin.dtype, device=xin.device)
+        check(lib.im2im_maxpool2_fwd(dptr(xin), dptr(y), b, h, w_, c, _DT[xin.dtype], stream_ptr(xin.device)), "im2im_maxpool2_fwd")
+        ctx.save_for_backward(xin)
+        return nchw(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xin,) = ctx.saved_tensors
+        dy = nhwc(dy, xin.dtype)
+        b, h, w_, c = xin.shape
+        dx = torch.empty_like(xin)
+        check(lib.im2im_maxpool2_bwd(dptr(xin), dptr(dy), dptr(dx), b, h, w_, c, _DT[xin.dtype], stream_ptr(xin.device)),
+              "im2im_maxpool2_bwd")
+        return nchw(dx)
+
+
+class UpsampleConcat(torch.autograd.Function):
+    """cat([skip, zero_pad(bilinear x2 align_corners(deep))], dim=1)  (unet_parts.py:58-68) in one pass."""
+
+    @staticmethod
+    def forward(ctx, deep, skip):
+        d = nhwc(deep.detach())
+        s = nhwc(skip.detach(), d.dtype)
+        b, h, w_, cd = d.shape
+        _, hh, ww, cs = s.shape
+        out = torch.empty((b, hh, ww, cs + cd), dtype=d.dtype, device=d.device)
+        check(lib.im2im_upsample2x_concat_fwd(dptr(d), dptr(s), dptr(out), b, h, w_, cd, hh, ww, cs, _DT[d.dtype],
+                                              stream_ptr(d.device)), "im2im_upsample2x_concat_fwd")
+        ctx.shape = (b, h, w_, cd, hh, ww, cs)
+        return nchw(out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        b, h, w_, cd, hh, ww, cs = ctx.shape
+        dout = nhwc(dout)
+        ddeep = torch.empty((b, h, w_, cd), dtype=dout.dtype, device=dout.device)
+        dskip = torch.empty((b, hh, ww, cs), dtype=dout.dtype, device=dout.device)
+        check(lib.im2im_upsample2x_concat_bwd(dptr(dout), dptr(ddeep), dptr(dskip), b, h, w_, cd, hh, ww, cs, _DT[dout.dtype],
+                                              stream_ptr(dout.device)), "im2im_upsample2x_concat_bwd")
+        return nchw(ddeep), nchw(dskip)
+
+
+class Conv1x1(torch.autograd.Function):
+    """OutConv (unet_parts.py:87-94): 1x1 conv with bias on the MFMA kernel (taps = 1)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cdt):
+        xin = nhwc(x.detach(), cdt)
+        wf, wd = pack_weight(weight, cdt)
+        y = conv_fwd(xin, wf, bias.detach())
+        ctx.save_for_backward(xin, wd)
+        return nchw(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xin, wd = ctx.saved_tensors
+        dy = nhwc(dy, xin.dtype)
+        dx = nchw(conv_fwd(dy, wd)) if ctx.needs_input_grad[0] else None
+        dw = conv_wgrad(xin, dy, 1).view(dy.shape[3], xin.shape[3], 1, 1)
+        return dx, dw, colsum(dy), None
+
+
+class QuantileHeads(torch.autograd.Function):
+    """Three 3x3 heads (lower, prediction, upper) in one kernel, output written directly as [B,3,C,H,W] fp32
+    (finallayers/quantile_layer.py:15-17,19-21)."""
+
+    @staticmethod
+    def forward(ctx, feat, w_lo, b_lo, w_mid, b_mid, w_hi, b_hi, cdt):
+        x = nhwc(feat.detach(), cdt)
+        c_out = w_lo.shape[0]
+        w_all = torch.cat([w_lo.detach(), w_mid.detach(), w_hi.detach()], dim=0)
+        b_all = torch.cat([b_lo.detach(), b_mid.detach(), b_hi.detach()], dim=0).to(F32).contiguous()
+        wf, _ = pack_weight(w_all, F32, want_wd=False)              # [3C][9][Cmid] fp32
+        b, h, w_, _ = x.shape
+        out = smallconv_l2s(x, wf, b_all, 3 * c_out)                # [B,3C,H,W]
+        ctx.save_for_backward(x, wf)
+        ctx.c_out = c_out
+        return out.view(b, 3, c_out, h, w_)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wf = ctx.saved_tensors
+        c = ctx.c_out
+        b, h, w_, cmid = x.shape
+        dout = dout.to(F32).contiguous().view(b, 3 * c, h, w_)
+        dfeat = None
+        if ctx.needs_input_grad[0]:
+            dfeat = nchw(smallconv_s2l(dout, wf, None, None, cmid, x.dtype, flip=True))
+        dw, db = smallconv_wgrad(dout, x, l_major=False, want_bias=True)
+        dw = dw.view(3, c, cmid, 3, 3)
+        db = db.view(3, c)
+        return dfeat, dw[0], db[0], dw[1], db[1], dw[2], db[2], None
+
+
+class QuantileLoss(torch.autograd.Function):
+    """w_lo*pinball(q_lo) + w_hi*pinball(q_hi) + w_mse*MSE, each mean-reduced, in one fused reduction."""
+
+    @staticmethod
+    def forward(ctx, lo, mid, hi, target, stride, n, p, q_lo, q_hi, w_lo, w_hi, w_mse):
+        dev = target.device
+        loss = torch.empty((), dtype=F32, device=dev)
+        ws = _Scratch.get(lib.im2im_quantile_loss_workspace_bytes(), dev)
+        check(lib.im2im_quantile_loss_fwd(dptr(lo), dptr(mid), dptr(hi), dptr(target), n, p, stride, q_lo, q_hi, w_lo, w_hi, w_mse,
+                                          dptr(loss), dptr(ws), stream_ptr(dev)), "im2im_quantile_loss_fwd")
+        ctx.save_for_backward(lo, mid, hi, target)
+        ctx.cfg = (stride, n, p, q_lo, q_hi, w_lo, w_hi, w_mse)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        lo, mid, hi, target = ctx.saved_tensors
+        stride, n, p, q_lo, q_hi, w_lo, w_hi, w_mse = ctx.cfg
+        gout = gout.to(F32).contiguous()
+        grads = [None, None, None]
+        ptrs = []
+        for i in range(3):
+            if ctx.needs_input_grad[i]:
+                grads[i] = torch.empty((n, p), dtype=F32, device=target.device)
+            ptrs.append(dptr(grads[i]))
+        check(lib.im2im_quantile_loss_bwd(dptr(lo), dptr(mid), dptr(hi), dptr(target), n, p, stride, q_lo, q_hi, w_lo, w_hi, w_mse,
+                                          dptr(gout), ptrs[0], ptrs[1], ptrs[2], p, stream_ptr(target.device)),
+              "im2im_quantile_loss_bwd")
+        for i, t in enumerate((lo, mid, hi)):
+            if grads[i] is not None:
+                grads[i] = grads[i].view(t.shape)
+        return grads[0], grads[1], grads[2], None, None, None, None, None, None, None, None, None
+
+
+class QuantileLossPacked(torch.autograd.Function):
+    """same loss on the packed [B,3,C,H,W] model output (gradient written in place into one [B,3,C,H,W])."""
+
+    @staticmethod
+    def forward(ctx, pred, target, q_lo, q_hi, w_lo, w_hi, w_mse):
+        n = pred.shape[0]
+        p = pred[0, 0].numel()
+        dev = pred.device
+        loss = torch.empty((), dtype=F32, device=dev)
+        ws = _Scratch.get(lib.im2im_quantile_loss_workspace_bytes(), dev)
+        base = pred.data_ptr()
+        check(lib.im2im_quantile_loss_fwd(base, base + 4 * p, base + 8 * p, dptr(target), n, p, 3 * p, q_lo, q_hi, w_lo, w_hi, w_mse,
+                                          dptr(loss), dptr(ws), stream_ptr(dev)), "im2im_quantile_loss_fwd")
+        ctx.save_for_backward(pred, target)
+        ctx.cfg = (n, p, q_lo, q_hi, w_lo, w_hi, w_mse)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, target = ctx.saved_tensors
+        n, p, q_lo, q_hi, w_lo, w_hi, w_mse = ctx.cfg
+        gout = gout.to(F32).contiguous()
+        d = torch.empty_like(pred)
+        base, dbase = pred.data_ptr(), d.data_ptr()
+        check(lib.im2im_quantile_loss_bwd(base, base + 4 * p, base + 8 * p, dptr(target), n, p, 3 * p, q_lo, q_hi, w_lo, w_hi, w_mse,
+                                          dptr(gout), dbase, dbase + 4 * p, dbase + 8 * p, 3 * p, stream_ptr(pred.device)),
+              "im2im_quantile_loss_bwd")
+        return d, None, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------- optimizer
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(params, lr) semantics (defaults betas=(0.9,0.999), eps=1e-8, no weight decay) in one
+    multi-tensor HIP launch per 24 tensors.  Drop-in for `optim.Adam(net.parameters(), lr=lr)` at train.py:120."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            ps, gs, ms, vs = [], [], [], []
+            step = None
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.dtype != F32 or not p.is_cuda:
+                    raise _lib.Im2ImError("FusedAdam: parameters must be fp32 tensors on the GPU")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                step = st["step"]
+                g = p.grad
+                if g.dtype != F32 or not g.is_contiguous():
+                    g = g.to(F32).contiguous()
+                if not p.is_contiguous():
+                    raise _lib.Im2ImError("FusedAdam: non-contiguous parameter")
+                ps.append(p); gs.append(g); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"])
+            if not ps:
+                continue
+            n = len(ps)
+            arr = ctypes.c_void_p * n
+            sizes = (ctypes.c_int64 * n)(*[p.numel() for p in ps])
+            b1, b2 = group["betas"]
+            check(lib.im2im_adam_step(n, arr(*[p.data_ptr() for p in ps]), arr(*[g.data_ptr() for g in gs]),
+                                      arr(*[m.data_ptr() for m in ms]), arr(*[v.data_ptr() for v in vs]), sizes,
+                                      float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(step),
+                                      stream_ptr(ps[0].device)), "im2im_adam_step")
+        return loss

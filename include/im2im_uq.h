@@ -27,6 +27,12 @@ extern "C" {
 
 typedef void* im2im_stream_t;      /* hipStream_t */
 
+/* element type of activation tensors ("compute dtype").  The reference runs fp32 everywhere
+ * (core/scripts/train.py:149); IM2IM_F32 is the tight-parity mode (exact-fp32 MFMA), IM2IM_BF16 the
+ * throughput mode (bf16 storage + bf16 MFMA inputs, fp32 accumulate). */
+#define IM2IM_F32 0
+#define IM2IM_BF16 1
+
 int im2im_abi_version(void);
 const char* im2im_last_error(void);
 
@@ -75,6 +81,139 @@ int im2im_fraction_missed(const float* lower_edge, const float* upper_edge, cons
  * core/calibration/bounds.py:17-29 (scipy binom.cdf + brentq), including its "return 1.0 on any
  * solver exception" path (muhat == 0 -> NaN, Q3). */
 double im2im_hb_mu_plus(double muhat, int64_t n, double delta, int32_t maxiters);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution by MFMA implicit GEMM.  Activations are NHWC, element type `dtype`.
+ * Replaces nn.Conv2d 3x3 pad 1 (core/models/trunks/unet_parts.py:16,19) and 1x1 (:90) and their
+ * autograd backward.
+ *
+ * im2im_pack_conv_weight: w [Co][Ci][taps] fp32 (torch parameter layout, taps = kh*3+kw) ->
+ *   wf [Co][taps][Ci]            operand of the forward conv
+ *   wd [Ci][taps reversed][Co]   operand of dgrad (= forward conv of dz with flipped taps); may be NULL
+ */
+int im2im_pack_conv_weight(const float* w, int32_t Co, int32_t Ci, int32_t taps, int32_t dtype,
+                           void* wf, void* wd, im2im_stream_t stream);
+
+/* y[b,h,w,co] = epi( sum_{tap,ci} x[b,h+kh-1,w+kw-1,ci] * wf[co][tap][ci] + bias[co] )
+ *   x [B][H][W][Ci], y [B][H][W][Co] (dtype), Ci % 32 == 0, Co % 32 == 0, taps in {9,1}
+ *   bias fp32 [Co] or NULL;  scale/shift fp32 [Co] or both NULL: v = v*scale + shift (folded eval-mode
+ *   BatchNorm, unet_parts.py:17,20);  relu != 0: v = max(v,0) (unet_parts.py:18,21)
+ *   stats (may be NULL): [rows][2][Co] fp32 per-tile partial sums and sums of squares of the STORED
+ *   values over valid pixels, rows = im2im_conv_stats_rows(B,H,W,Co): train-mode BatchNorm statistics
+ *   without re-reading y.  dgrad uses the same entry point with x = dz and wf = wd. */
+int64_t im2im_conv_stats_rows(int32_t B, int32_t H, int32_t W, int32_t Co);
+int im2im_conv_fwd(const void* x, const void* wf, const float* bias, const float* scale,
+                   const float* shift, void* y, float* stats, int32_t B, int32_t H, int32_t W,
+                   int32_t Ci, int32_t Co, int32_t taps, int32_t relu, int32_t dtype,
+                   im2im_stream_t stream);
+
+/* dw[co][ci][tap] (fp32, torch layout) = sum_{b,h,w} dz[b,h,w,co] * x[b,h+kh-1,w+kw-1,ci]
+ *   Ci % 64 == 0, Co % 32 == 0.  workspace: im2im_conv_wgrad_workspace_bytes(...) bytes (split-K slabs,
+ *   reduced deterministically). */
+int64_t im2im_conv_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t taps);
+int im2im_conv_wgrad(const void* x, const void* dz, float* dw, void* workspace, int64_t workspace_bytes,
+                     int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t taps,
+                     int32_t dtype, im2im_stream_t stream);
+
+
+/* Shared scratch for the deterministic two-stage "sum over pixels" reductions: bytes needed to reduce
+ * K columns (used by bn_finalize; other entry points have their own *_workspace_bytes). */
+int64_t im2im_reduce_workspace_bytes(int64_t K);
+
+/* ---------------------------------------------------------------------------------------------
+ * BatchNorm2d + ReLU: nn.BatchNorm2d / nn.ReLU at core/models/trunks/unet_parts.py:17-18,20-21
+ * (torch defaults eps = 1e-5, momentum = 0.1), tensors [M = B*H*W][C] in `dtype`.
+ *
+ * im2im_bn_finalize: per-tile partial sums from the conv epilogue (partial [R][2][C]) -> batch mean and
+ *   biased variance; writes mean_invstd [2][C], scale_shift [2][C] (scale = gamma*invstd,
+ *   shift = beta - mean*scale) and, if non-NULL, the running statistics (unbiased variance, as torch).
+ *   ws: im2im_reduce_workspace_bytes(2*C) bytes.
+ * im2im_bn_fold_eval: eval-mode fold into the conv epilogue: scale = gamma/sqrt(rv+eps),
+ *   shift = beta + (conv_bias - rm)*scale.
+ * im2im_bn_relu_apply: a = max(z*scale + shift, 0).
+ * im2im_bn_relu_bwd: given da, the saved pre-BN z and the forward's scale_shift / mean_invstd:
+ *   dgamma = sum g*xhat, dbeta = sum g, dz = scale*(g - dbeta/M - xhat*dgamma/M), g = da*[a > 0].
+ */
+int im2im_bn_finalize(const float* partial, int64_t R, int32_t C, int64_t count, const float* gamma,
+                      const float* beta, float* running_mean, float* running_var, float momentum,
+                      float eps, float* mean_invstd, float* scale_shift, void* ws, im2im_stream_t stream);
+int im2im_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, const float* conv_bias, float eps, int32_t C,
+                       float* scale_shift, im2im_stream_t stream);
+int im2im_bn_relu_apply(const void* z, const float* scale_shift, void* a, int64_t M, int32_t C,
+                        int32_t dtype, im2im_stream_t stream);
+int64_t im2im_bn_bwd_workspace_bytes(int64_t M, int32_t C);
+int im2im_bn_relu_bwd(const void* da, const void* z, const float* scale_shift, const float* mean_invstd,
+                      void* dz, float* dgamma, float* dbeta, int64_t M, int32_t C, int32_t dtype,
+                      void* ws, int64_t ws_bytes, im2im_stream_t stream);
+
+/* out[c] = sum_m x[m][c] (bias gradient of the 1x1 out conv, unet_parts.py:90). */
+int64_t im2im_colsum_workspace_bytes(int64_t M, int32_t C);
+int im2im_colsum(const void* x, float* out, int64_t M, int32_t C, int32_t dtype, void* ws,
+                 int64_t ws_bytes, im2im_stream_t stream);
+
+/* MaxPool2d(2) (unet_parts.py:34), NHWC; ties keep the first maximum in (h,w) order. */
+int im2im_maxpool2_fwd(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C,
+                       int32_t dtype, im2im_stream_t stream);
+int im2im_maxpool2_bwd(const void* x, const void* dy, void* dx, int32_t B, int32_t H, int32_t W,
+                       int32_t C, int32_t dtype, im2im_stream_t stream);
+
+/* Up-block input (unet_parts.py:58-68): out = cat([skip, zero_pad(bilinear_x2_align_corners(deep))])
+ * on the channel axis, NHWC.  deep [B][h][w][Cd], skip [B][H][W][Cs], out [B][H][W][Cs+Cd], H >= 2h, W >= 2w.
+ * bwd: dskip = dout[..., :Cs]; ddeep = transpose of the interpolation (gathered, no atomics). */
+int im2im_upsample2x_concat_fwd(const void* deep, const void* skip, void* out, int32_t B, int32_t h,
+                                int32_t w, int32_t Cd, int32_t H, int32_t W, int32_t Cs, int32_t dtype,
+                                im2im_stream_t stream);
+int im2im_upsample2x_concat_bwd(const void* dout, void* ddeep, void* dskip, int32_t B, int32_t h,
+                                int32_t w, int32_t Cd, int32_t H, int32_t W, int32_t Cs, int32_t dtype,
+                                im2im_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Small-channel direct 3x3 convolutions (pad 1), 16x16-pixel tiles, weights fp32.
+ * s2l: in fp32 NCHW [B][CS][H][W] (CS <= 8) -> out NHWC [B][H][W][CL] (CL in {32,64}).
+ *   w [CS][9][CL] (tap index reversed when flip != 0); bias [CL]|NULL; scale_shift [2][CL]|NULL; relu;
+ *   stats [im2im_smallconv_tiles][2][CL]|NULL as for im2im_conv_fwd.  Uses: first UNet conv
+ *   (unet_parts.py:16, Cin = n_in) and the data gradient of the quantile heads.
+ * l2s: in NHWC [B][H][W][CL] -> out fp32 NCHW [B][CS][H][W]; w [CS][9][CL]; bias [CS]|NULL.  Use: the three
+ *   quantile heads written directly as [B,3,C,H,W] (finallayers/quantile_layer.py:15-17,20).
+ * wgrad: dw from S fp32 NCHW [B][CS][H][W] and L NHWC [B][H][W][CL]:
+ *   l_major != 0: dw[(l*CS+s)*9+tap] = sum_px L[px][l]*S[s][px+tap]   (first conv: S = input, L = dz)
+ *   l_major == 0: dw[(s*CL+l)*9+tap] = sum_px S[s][px]*L[px+tap][l]   (heads: S = dout, L = features)
+ *   dbias [CS]|NULL = sum_px S[s][px].
+ */
+int64_t im2im_smallconv_tiles(int32_t B, int32_t H, int32_t W);
+int im2im_smallconv_s2l_fwd(const float* in, const float* w, const float* bias, const float* scale_shift,
+                            void* out, float* stats, int32_t B, int32_t H, int32_t W, int32_t CS,
+                            int32_t CL, int32_t relu, int32_t flip, int32_t dtype, im2im_stream_t stream);
+int im2im_smallconv_l2s_fwd(const void* in, const float* w, const float* bias, float* out, int32_t B,
+                            int32_t H, int32_t W, int32_t CL, int32_t CS, int32_t dtype,
+                            im2im_stream_t stream);
+int64_t im2im_smallconv_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t CS, int32_t CL);
+int im2im_smallconv_wgrad(const float* S, const void* L, float* dw, float* dbias, int32_t B, int32_t H,
+                          int32_t W, int32_t CS, int32_t CL, int32_t l_major, int32_t dtype, void* ws,
+                          int64_t ws_bytes, im2im_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused quantile loss: quantile_regression_loss_fn (finallayers/quantile_layer.py:23-32) with
+ * PinballLoss (losses/pinball.py:12-26) and nn.MSELoss, all mean-reduced:
+ *   loss = w_lo*pinball_{q_lo}(lo, y) + w_hi*pinball_{q_hi}(hi, y) + w_mse*mean((mid - y)^2)
+ * lo/mid/hi: fp32 planes, element (n, i) at ptr[n*img_stride + i], i < P; target [N][P].
+ * bwd writes d_lo/d_mid/d_hi (each may be NULL) at [n*d_stride + i], scaled by the device scalar *grad_out. */
+int64_t im2im_quantile_loss_workspace_bytes(void);
+int im2im_quantile_loss_fwd(const float* lo, const float* mid, const float* hi, const float* target,
+                            int64_t N, int64_t P, int64_t img_stride, float q_lo, float q_hi, float w_lo,
+                            float w_hi, float w_mse, float* loss, void* ws, im2im_stream_t stream);
+int im2im_quantile_loss_bwd(const float* lo, const float* mid, const float* hi, const float* target,
+                            int64_t N, int64_t P, int64_t img_stride, float q_lo, float q_hi, float w_lo,
+                            float w_hi, float w_mse, const float* grad_out, float* d_lo, float* d_mid,
+                            float* d_hi, int64_t d_stride, im2im_stream_t stream);
+
+/* Multi-tensor Adam: optim.Adam(net.parameters(), lr) at core/scripts/train.py:120 with torch
+ * defaults (betas, eps, no weight decay, no amsgrad).  Host arrays of n_tensors device pointers / sizes;
+ * `step` is the 1-based step count used for bias correction. */
+int im2im_adam_step(int32_t n_tensors, float* const* params, const float* const* grads,
+                    float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes, float lr,
+                    float beta1, float beta2, float eps, int64_t step, im2im_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,237 @@
+"""GPU parity of each training-path HIP kernel against a plain PyTorch-CPU fp32 restatement of the same op
+(the substrate the reference runs on).  fp32 mode: tight tolerances; bf16 mode: tolerance stated per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def tol(dt):
+    return 2e-5 if dt == F32 else 1.5e-2
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q(t, dt):
+    """quantise a CPU reference operand the way the kernel will see it."""
+    return t.to(dt).to(F32)
+
+
+CONV_CASES = [
+    # B, H, W, Ci, Co, taps
+    (2, 20, 24, 64, 64, 9),       # 8x8 tiles, overhang in both dims
+    (1, 40, 40, 128, 128, 9),     # 8x8 tiles, BN=128
+    (2, 70, 66, 32, 32, 9),       # 16x16 tiles, BN=32, overhang
+    (1, 80, 72, 64, 128, 9),      # 16x16 tiles, BN=128
+    (1, 64, 64, 96, 64, 9),       # 3 K-chunks
+    (2, 33, 17, 64, 32, 1),       # 1x1, small
+    (1, 96, 80, 64, 32, 1),       # 1x1, 16x16 tiles
+    (1, 9, 7, 256, 256, 9),       # deep level style
+]
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case, dt):
+    from im2im_uq_amd import nn_ops
+    b, h, w, ci, co, taps = case
+    k = 3 if taps == 9 else 1
+    x = rnd(b, ci, h, w, seed=1)
+    wt = rnd(co, ci, k, k, seed=2, scale=(ci * taps) ** -0.5)
+    bias = rnd(co, seed=3, scale=0.1)
+    xq, wq = q(x, dt).requires_grad_(True), q(wt, dt).requires_grad_(True)
+    ref = F.conv2d(xq, wq, bias, padding=k // 2)
+    x_d = x.to(DEV).permute(0, 2, 3, 1).contiguous().to(dt)
+    wf, wd = nn_ops.pack_weight(wt.to(DEV), dt)
+    y, stats = nn_ops.conv_fwd(x_d, wf, bias.to(DEV), want_stats=True)
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert rel_l2(got, ref.detach()) < tol(dt)
+    # BatchNorm partial statistics of the STORED values
+    s = stats.double().sum(0).cpu()
+    yst = y.double().cpu().reshape(-1, co)
+    np.testing.assert_allclose(s[0].numpy(), yst.sum(0).numpy(), rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(s[1].numpy(), (yst * yst).sum(0).numpy(), rtol=1e-4, atol=1e-2)
+    # folded affine + relu epilogue
+    ss = torch.stack([rnd(co, seed=4).abs() + 0.5, rnd(co, seed=5)]).to(DEV)
+    y2 = nn_ops.conv_fwd(x_d, wf, None, ss, relu=True).float().cpu().permute(0, 3, 1, 2)
+    ref2 = F.relu(F.conv2d(xq, wq, None, padding=k // 2) * ss[0].cpu()[None, :, None, None] + ss[1].cpu()[None, :, None, None])
+    assert rel_l2(y2, ref2.detach()) < tol(dt)
+    # backward: dgrad = forward kernel with the flipped/transposed weights, wgrad kernel
+    gy = rnd(b, co, h, w, seed=6)
+    gyq = q(gy, dt)
+    ref.backward(gyq)
+    gy_d = gy.to(DEV).permute(0, 2, 3, 1).contiguous().to(dt)
+    dx = nn_ops.conv_fwd(gy_d, wd).float().cpu().permute(0, 3, 1, 2)
+    assert rel_l2(dx, xq.grad) < tol(dt)
+    if ci % 64 == 0:
+        dw = nn_ops.conv_wgrad(x_d, gy_d, taps).cpu().view(co, ci, k, k)
+        assert rel_l2(dw, wq.grad) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("shape", [(2, 1, 37, 29, 64), (1, 2, 48, 48, 64), (2, 3, 16, 20, 32), (1, 6, 33, 18, 32)])
+def test_smallconv_family(shape, dt):
+    from im2im_uq_amd import nn_ops
+    b, cs, h, w, cl = shape
+    # s2l forward (first conv): x NCHW fp32 -> NHWC
+    x = rnd(b, cs, h, w, seed=1)
+    wt = rnd(cl, cs, 3, 3, seed=2, scale=0.3)
+    bias = rnd(cl, seed=3, scale=0.1)
+    x_r, w_r = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    ref = F.conv2d(x_r, w_r, bias, padding=1)
+    _, wd = nn_ops.pack_weight(wt.to(DEV), F32)
+    z, stats = nn_ops.smallconv_s2l(x.to(DEV), wd, bias.to(DEV), None, cl, dt, flip=True, want_stats=True)
+    got = z.float().cpu().permute(0, 3, 1, 2)
+    assert rel_l2(got, ref.detach()) < (1e-5 if dt == F32 else 5e-3)
+    zs = z.double().cpu().reshape(-1, cl)
+    np.testing.assert_allclose(stats.double().sum(0)[0].cpu().numpy(), zs.sum(0).numpy(), rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(stats.double().sum(0)[1].cpu().numpy(), (zs * zs).sum(0).numpy(), rtol=1e-4, atol=1e-2)
+    # its weight gradient (l_major)
+    gz = rnd(b, cl, h, w, seed=4)
+    ref.backward(q(gz, dt))
+    gz_d = gz.to(DEV).permute(0, 2, 3, 1).contiguous().to(dt)
+    dw, _ = nn_ops.smallconv_wgrad(x.to(DEV), gz_d, l_major=True, want_bias=False)
+    assert rel_l2(dw.cpu().view(cl, cs, 3, 3), w_r.grad) < 1e-4
+    # l2s forward (heads): NHWC feat -> NCHW planes, and its backward pair
+    feat = rnd(b, cl, h, w, seed=5)
+    wh = rnd(cs, cl, 3, 3, seed=6, scale=0.2)
+    bh = rnd(cs, seed=7, scale=0.1)
+    f_r, wh_r, bh_r = q(feat, dt).requires_grad_(True), wh.clone().requires_grad_(True), bh.clone().requires_grad_(True)
+    refh = F.conv2d(f_r, wh_r, bh_r, padding=1)
+    wf, _ = nn_ops.pack_weight(wh.to(DEV), F32, want_wd=False)
+    f_d = feat.to(DEV).permute(0, 2, 3, 1).contiguous().to(dt)
+    out = nn_ops.smallconv_l2s(f_d, wf, bh.to(DEV), cs)
+    assert rel_l2(out.cpu(), refh.detach()) < 1e-5
+    go = rnd(b, cs, h, w, seed=8)
+    refh.backward(go)
+    dfeat = nn_ops.smallconv_s2l(go.to(DEV), wf, None, None, cl, dt, flip=True).float().cpu().permute(0, 3, 1, 2)
+    assert rel_l2(dfeat, f_r.grad) < (1e-5 if dt == F32 else 5e-3)
+    dwh, dbh = nn_ops.smallconv_wgrad(go.to(DEV), f_d, l_major=False, want_bias=True)
+    assert rel_l2(dwh.cpu().view(cs, cl, 3, 3), wh_r.grad) < 1e-4
+    assert rel_l2(dbh.cpu(), bh_r.grad) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("shape", [(2, 20, 24, 64), (1, 33, 31, 128), (3, 8, 8, 512), (2, 16, 16, 32)])
+def test_batchnorm_relu_fwd_bwd(shape, dt):
+    from im2im_uq_amd import nn_ops
+    b, h, w, c = shape
+    z = rnd(b, c, h, w, seed=1) * 1.5 + 0.3
+    gamma, beta = rnd(c, seed=2).abs() + 0.5, rnd(c, seed=3) * 0.2
+    rm, rv = rnd(c, seed=4) * 0.1, rnd(c, seed=5).abs() + 0.5
+    zq = q(z, dt).requires_grad_(True)
+    g_r, b_r = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_r, rv_r = rm.clone(), rv.clone()
+    ref = F.relu(F.batch_norm(zq, rm_r, rv_r, g_r, b_r, training=True, momentum=0.1, eps=1e-5))
+    z_d = z.to(DEV).permute(0, 2, 3, 1).contiguous().to(dt)
+    zf = z_d.float().reshape(-1, c)
+    stats = torch.stack([zf.sum(0), (zf * zf).sum(0)])[None].contiguous()          # one partial row
+    rm_d, rv_d = rm.to(DEV), rv.to(DEV)
+    mean_invstd, scale_shift = nn_ops.bn_finalize(stats, b * h * w, gamma.to(DEV), beta.to(DEV), rm_d, rv_d, 0.1, 1e-5)
+    a = nn_ops.bn_relu_apply(z_d, scale_shift)
+    assert rel_l2(a.float().cpu().permute(0, 3, 1, 2), ref.detach()) < (1e-5 if dt == F32 else 6e-3)
+    np.testing.assert_allclose(rm_d.cpu().numpy(), rm_r.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rv_d.cpu().numpy(), rv_r.numpy(), rtol=1e-4, atol=1e-5)
+    ga = rnd(b, c, h, w, seed=6)
+    ref.backward(q(ga, dt))
+    ga_d = ga.to(DEV).permute(0, 2, 3, 1).contiguous().to(dt)
+    dz, dgamma, dbeta = nn_ops.bn_relu_bwd(ga_d, z_d, scale_shift, mean_invstd)
+    t = 2e-5 if dt == F32 else 1.2e-2
+    assert rel_l2(dz.float().cpu().permute(0, 3, 1, 2), zq.grad) < t
+    assert rel_l2(dgamma.cpu(), g_r.grad) < t and rel_l2(dbeta.cpu(), b_r.grad) < t
+    # eval fold
+    fold = nn_ops.bn_fold_eval(gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV), None, 1e-5).cpu()
+    ref_sc = gamma / torch.sqrt(rv + 1e-5)
+    np.testing.assert_allclose(fold[0].numpy(), ref_sc.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(fold[1].numpy(), (beta - rm * ref_sc).numpy(), rtol=1e-4, atol=1e-6)
+    cs = nn_ops.colsum(z_d)
+    np.testing.assert_allclose(cs.detach().cpu().numpy(), zf.detach().sum(0).cpu().numpy(), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_maxpool_and_upsample_concat(dt):
+    from im2im_uq_amd import nn_ops
+    for (b, c, h, w) in [(2, 64, 16, 20), (1, 32, 7, 9), (1, 128, 40, 40)]:
+        x = q(rnd(b, c, h, w, seed=1), dt)
+        x[:, :, :2, :4] = 0.0                                     # ties (post-ReLU zeros): first max wins
+        xr = x.clone().requires_grad_(True)
+        ref = F.max_pool2d(xr, 2)
+        xd = x.to(DEV).to(dt).to(memory_format=torch.channels_last).requires_grad_(True)
+        y = nn_ops.MaxPool2.apply(xd)
+        assert torch.equal(y.float().cpu(), ref.detach())
+        g = q(rnd(*ref.shape, seed=2), dt)
+        ref.backward(g)
+        y.backward(g.to(DEV).to(dt))
+        assert torch.equal(xd.grad.float().cpu(), xr.grad)
+    for (b, cd, h, w, cs, hh, ww) in [(2, 32, 8, 8, 32, 16, 16), (1, 64, 5, 6, 32, 11, 13), (1, 512, 20, 20, 512, 40, 40)]:
+        deep, skip = q(rnd(b, cd, h, w, seed=3), dt), q(rnd(b, cs, hh, ww, seed=4), dt)
+        dr, sr = deep.clone().requires_grad_(True), skip.clone().requires_grad_(True)
+        u = F.interpolate(dr, scale_factor=2, mode="bilinear", align_corners=True)
+        dy, dx = hh - u.shape[2], ww - u.shape[3]
+        ref = torch.cat([sr, F.pad(u, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])], dim=1)
+        dd = deep.to(DEV).to(dt).to(memory_format=torch.channels_last).requires_grad_(True)
+        sd = skip.to(DEV).to(dt).to(memory_format=torch.channels_last).requires_grad_(True)
+        out = nn_ops.UpsampleConcat.apply(dd, sd)
+        assert rel_l2(out.float().cpu(), ref.detach()) < (1e-6 if dt == F32 else 4e-3)
+        g = q(rnd(*ref.shape, seed=5), dt)
+        ref.backward(g)
+        out.backward(g.to(DEV).to(dt))
+        assert rel_l2(dd.grad.float().cpu(), dr.grad) < (1e-6 if dt == F32 else 6e-3)
+        assert torch.equal(sd.grad.float().cpu(), sr.grad)
+
+
+def test_quantile_loss_golden_and_oracle():
+    from conftest import load_golden
+    from im2im_uq_amd.core.models.finallayers.quantile_layer import quantile_regression_loss_fn
+    from im2im_uq_amd.core.models.losses.pinball import PinballLoss
+    g = load_golden("g2_quantile_loss")
+    for params, lk, gk in ((dict(q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1), "loss", "grad"),
+                           (dict(q_lo=0.1, q_hi=0.8, q_lo_weight=0.5, q_hi_weight=2.0, mse_weight=3.0), "loss_w", "grad_w")):
+        p = torch.from_numpy(g["pred"]).to(DEV).requires_grad_(True)
+        loss = quantile_regression_loss_fn(p, torch.from_numpy(g["target"]).to(DEV), params)
+        (loss * 1.0).backward()
+        assert loss.item() == pytest.approx(float(g[lk]), rel=2e-6)
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g[gk], rtol=1e-5, atol=1e-9)
+    g = load_golden("g1_pinball")
+    for qq, tag in ((0.05, "005"), (0.95, "095")):
+        o = torch.from_numpy(g["output"]).to(DEV).requires_grad_(True)
+        loss = PinballLoss(quantile=qq)(o, torch.from_numpy(g["target"]).to(DEV))
+        loss.backward()
+        assert loss.item() == pytest.approx(float(g[f"loss_{tag}"]), rel=2e-6)
+        np.testing.assert_allclose(o.grad.cpu().numpy(), g[f"grad_{tag}"], rtol=1e-5, atol=0)
+    # full-size property: loss of (pred == target everywhere) is exactly 0 and its gradient is 0
+    y = torch.rand(2, 1, 320, 320, device=DEV)
+    p = torch.stack([y, y, y], dim=1).contiguous().requires_grad_(True)
+    loss = quantile_regression_loss_fn(p, y, dict(q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1))
+    loss.backward()
+    assert loss.item() == 0.0 and float(p.grad.abs().max()) == 0.0
+
+
+def test_fused_adam_matches_torch_adam():
+    from im2im_uq_amd import nn_ops
+    shapes = [(64, 1, 3, 3), (64,), (512, 1024, 3, 3), (3,), (32, 64, 1, 1)] + [(7,)] * 30    # > 24 tensors: two launches
+    ps_ref = [rnd(*s, seed=i).requires_grad_(True) for i, s in enumerate(shapes)]
+    ps = [p.detach().clone().to(DEV).requires_grad_(True) for p in ps_ref]
+    o_ref = torch.optim.Adam(ps_ref, lr=1e-3)
+    o = nn_ops.FusedAdam(ps, lr=1e-3)
+    for step in range(4):
+        for i, (pr, p) in enumerate(zip(ps_ref, ps)):
+            g = rnd(*pr.shape, seed=100 * step + i) * (10.0 ** (i % 5 - 3))
+            pr.grad = g.clone()
+            p.grad = g.to(DEV)
+        o_ref.step(); o.step()
+    for pr, p in zip(ps_ref, ps):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), pr.detach().numpy(), rtol=2e-6, atol=2e-7)
