@@ -63,41 +63,73 @@ def is_param(key: str) -> bool:
                 or key.endswith("num_batches_tracked"))
 
 
-def double_conv(x, state, prefix, training):
+# ---- bf16 storage emulation ---------------------------------------------------------------------
+# The HIP path's throughput mode keeps activations (and the gradients flowing between layers) in bf16 and
+# feeds bf16 operands to the MFMA units with fp32 accumulation -- the numerics of torch.autocast(bfloat16)
+# applied to the reference.  `emulate_bf16=True` restates the reference with a bf16 round-trip at exactly
+# the points where the kernels store a bf16 tensor, so the bf16 mode can be checked against the reference
+# arithmetic *at that precision* (tests/test_model_gpu.py), separately from the bf16-vs-fp32 distance.
+class _RoundFwd(torch.autograd.Function):          # operand rounding (weights): value rounded, gradient untouched
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _store(x, emulate):
+    """a tensor the kernels write in the compute dtype: value and incoming gradient both pass through bf16."""
+    return x.to(torch.bfloat16).to(torch.float32) if emulate else x
+
+
+def _operand(w, emulate):
+    return _RoundFwd.apply(w) if emulate else w
+
+
+def double_conv(x, state, prefix, training, emulate_bf16=False):
     """(conv3x3 pad1 + bias -> BatchNorm2d -> ReLU) x 2, unet_parts.py:15-25."""
     p = f"baseModel.{prefix}.double_conv"
     for idx in (0, 3):
-        x = F.conv2d(x, state[f"{p}.{idx}.weight"], state[f"{p}.{idx}.bias"], padding=1)
+        w = state[f"{p}.{idx}.weight"]
+        if w.shape[1] > 8:                      # the <=8-channel first conv runs on fp32 weights in the kernels
+            w = _operand(w, emulate_bf16)
+        x = F.conv2d(x, w, state[f"{p}.{idx}.bias"], padding=1)
+        if training:
+            x = _store(x, emulate_bf16)         # train mode stores the pre-BN conv output; eval folds BN into the conv
         x = F.batch_norm(x, state[f"{p}.{idx + 1}.running_mean"], state[f"{p}.{idx + 1}.running_var"],
                          state[f"{p}.{idx + 1}.weight"], state[f"{p}.{idx + 1}.bias"],
                          training=training, momentum=BN_MOMENTUM, eps=BN_EPS)
         if training:
             state[f"{p}.{idx + 1}.num_batches_tracked"] += 1
-        x = F.relu(x)
+        x = _store(F.relu(x), emulate_bf16)
     return x
 
 
-def up_block(x_deep, x_skip, state, prefix, training):
+def up_block(x_deep, x_skip, state, prefix, training, emulate_bf16=False):
     """bilinear x2 (align_corners=True) -> zero-pad to skip -> cat([skip, up]) -> DoubleConv,
     unet_parts.py:58-69."""
     u = F.interpolate(x_deep, scale_factor=2, mode="bilinear", align_corners=True)
     dy = x_skip.shape[2] - u.shape[2]
     dx = x_skip.shape[3] - u.shape[3]
     u = F.pad(u, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
-    return double_conv(torch.cat([x_skip, u], dim=1), state, prefix, training)
+    cat = _store(torch.cat([x_skip, u], dim=1), emulate_bf16)
+    return double_conv(cat, state, prefix, training, emulate_bf16)
 
 
-def unet_forward(x, state, training: bool):
+def unet_forward(x, state, training: bool, emulate_bf16=False):
     """core/models/trunks/unet.py:33-46."""
-    x1 = double_conv(x, state, "inc", training)
+    x1 = double_conv(x, state, "inc", training, emulate_bf16)
     skips = [x1]
     h = x1
     for i in range(1, 5):
-        h = double_conv(F.max_pool2d(h, 2), state, f"down{i}.maxpool_conv.1", training)  # unet_parts.py:33-40
+        h = double_conv(F.max_pool2d(h, 2), state, f"down{i}.maxpool_conv.1", training, emulate_bf16)  # unet_parts.py:33-40
         skips.append(h)
     for i in range(1, 5):
-        h = up_block(h, skips[4 - i], state, f"up{i}.conv", training)
-    return F.conv2d(h, state["baseModel.out.conv.weight"], state["baseModel.out.conv.bias"])  # unet_parts.py:90-94
+        h = up_block(h, skips[4 - i], state, f"up{i}.conv", training, emulate_bf16)
+    out = F.conv2d(h, _operand(state["baseModel.out.conv.weight"], emulate_bf16), state["baseModel.out.conv.bias"])  # unet_parts.py:90-94
+    return _store(out, emulate_bf16)
 
 
 def quantile_heads(feat, state):
@@ -107,9 +139,9 @@ def quantile_heads(feat, state):
     return torch.stack(outs, dim=1)
 
 
-def model_forward(x, state, training: bool = False):
+def model_forward(x, state, training: bool = False, emulate_bf16: bool = False):
     """ModelWithUncertainty.forward, core/models/add_uncertainty.py:25-27."""
-    return quantile_heads(unet_forward(x, state, training), state)
+    return quantile_heads(unet_forward(x, state, training, emulate_bf16), state)
 
 
 def pinball(output, target, q: float):

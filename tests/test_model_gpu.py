@@ -1,0 +1,277 @@
+"""End-to-end GPU parity of the UNet + quantile head + loss + Adam path against the goldens produced by the
+reference (G4, G5, G11) and against the CPU oracle's autograd.  fp32 compute mode = parity mode (stated
+tolerances are fp32 re-association noise through 23 conv layers); bf16 = throughput mode, looser, stated."""
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import TensorDataset
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = torch.from_numpy
+PARAMS = dict(uncertainty_type="quantiles", q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1,
+              alpha=0.1, delta=0.1, num_lambdas=50, rcps_loss="fraction_missed", minimum_lambda=0, maximum_lambda=6,
+              device=DEV, dataset="synthetic", batch_size=8, lr=1e-3, input_normalization="standard",
+              output_normalization="min-max", num_validation_images=2)
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).double().flatten(), torch.as_tensor(b).double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def build(n_in=1, dt="fp32"):
+    from im2im_uq_amd import nn_ops
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from im2im_uq_amd.core.models.trunks.unet import UNet
+    from oracle import model as om
+    nn_ops.set_compute_dtype(dt)
+    model = add_uncertainty(UNet(n_in, 1), dict(PARAMS))
+    model.load_state_dict(om.det_state(n_in, 1))
+    return model.to(DEV)
+
+
+@pytest.fixture(autouse=True)
+def _restore_dtype():
+    from im2im_uq_amd import nn_ops
+    yield
+    nn_ops.set_compute_dtype("bf16")
+
+
+@pytest.mark.parametrize("n_in", [1, 2])
+def test_g4_forward_eval_and_train_fp32(n_in):
+    g = load_golden(f"g4_model_fwd_nin{n_in}")
+    model = build(n_in, "fp32")
+    x = T(g["x"]).to(DEV)
+    model.eval()
+    with torch.no_grad():
+        out = model(x)
+    assert out.shape == g["out_eval"].shape and out.dtype == torch.float32
+    np.testing.assert_allclose(out.cpu().numpy(), g["out_eval"], rtol=0, atol=2e-4)
+    model.train()
+    out = model(x)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out_train"], rtol=0, atol=5e-4)
+    sd = model.state_dict()
+    np.testing.assert_allclose(sd["baseModel.inc.double_conv.1.running_mean"].cpu().numpy(), g["rm_inc1"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sd["baseModel.inc.double_conv.1.running_var"].cpu().numpy(), g["rv_inc1"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sd["baseModel.up4.conv.double_conv.4.running_mean"].cpu().numpy(), g["rm_up4"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(sd["baseModel.up4.conv.double_conv.4.running_var"].cpu().numpy(), g["rv_up4"], rtol=1e-3, atol=1e-5)
+    assert int(sd["baseModel.inc.double_conv.1.num_batches_tracked"]) == int(g["nbt"])
+
+
+def test_g4_forward_bf16_tolerance():
+    """bf16 storage + bf16 MFMA inputs vs the reference's fp32: relative L2 error of the output images <= 3 %."""
+    g = load_golden("g4_model_fwd_nin1")
+    model = build(1, "bf16")
+    model.eval()
+    with torch.no_grad():
+        out = model(T(g["x"]).to(DEV))
+    assert rel_l2(out.cpu(), g["out_eval"]) < 3e-2
+    model.train()
+    out = model(T(g["x"]).to(DEV))
+    # train mode at 32x32, B=2: the bottleneck BatchNorm normalises with statistics of only 8 samples per
+    # channel, which amplifies bf16 rounding; 8 % here, 3 % at a well-conditioned size (next test)
+    assert rel_l2(out.detach().cpu(), g["out_train"]) < 8e-2
+
+
+def test_bf16_forward_backward_vs_oracle_96px():
+    """bf16 mode against the fp32 CPU oracle at 96x96, B=4.  Train mode stores the pre-BatchNorm conv output in
+    bf16 (as torch.autocast(bfloat16) does), whose rounding error is amplified by |mean|/std of a channel when
+    BatchNorm subtracts the batch mean: measured 4-6 % relative L2 on the output images in train mode against
+    0.1-0.7 % in eval mode (tools/debug_bf16.py).  Stated tolerance: outputs 8 %, loss 2 %, weight gradients
+    25 % worst tensor / 10 % median tensor."""
+    from oracle import model as om
+    model = build(1, "bf16")
+    model.train()
+    x, y = om.det_images(4, 1, 96, 96, salt=7)
+    pred = model(x.to(DEV))
+    loss = model.loss_fn(pred, y.to(DEV))
+    loss.backward()
+    st = om.det_state(1, 1)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in st.items() if om.is_param(k)}
+    work = dict(st); work.update(leaves)
+    ref_pred = om.model_forward(x, work, training=True)
+    ref_loss = om.quantile_loss(ref_pred, y, PARAMS)
+    ref_loss.backward()
+    assert rel_l2(pred.detach().cpu(), ref_pred.detach()) < 8e-2
+    assert loss.item() == pytest.approx(ref_loss.item(), rel=2e-2)
+    errs = {}
+    for name, p in model.named_parameters():
+        if ".double_conv.0.bias" in name or ".double_conv.3.bias" in name:
+            continue
+        errs[name] = rel_l2(p.grad.cpu(), leaves[name].grad)
+    # gradients: bf16 forward rounding flips ReLU masks / max-pool winners, so weight gradients of the deep layers
+    # differ from the fp32 ones by tens of percent on these smooth synthetic images -- for ANY bf16-storage
+    # implementation (the emulating oracle shows the same numbers, see the next test).  Only a sanity bound here.
+    assert max(errs.values()) < 0.8, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    assert errs["last_layer.prediction.weight"] < 2e-2 and errs["baseModel.up4.conv.double_conv.3.weight"] < 5e-2
+
+
+def test_bf16_matches_reference_arithmetic_at_bf16_precision():
+    """The bf16 mode checked against the reference's arithmetic evaluated AT bf16 storage precision (oracle with
+    emulate_bf16=True: a bf16 round-trip wherever the kernels store a bf16 tensor, fp32 accumulation).
+    Eval mode (BatchNorm folded, one rounding per layer): 0.5 %.  Train mode: 3 % on the outputs, 0.2 % on the
+    loss.  Weight gradients: on these smooth synthetic images a single bf16 rounding flip moves ReLU masks and
+    2x2 max-pool winners, so two bf16-storage implementations that differ only in fp32 accumulation ORDER
+    already disagree by ~20 % (median tensor) in the deep layers -- the fp32 mode is the gradient-parity mode
+    (test_backward_gradients_vs_oracle_fp32, 2e-3); here only the shallow layers are bounded tightly."""
+    from oracle import model as om
+    x, y = om.det_images(4, 1, 96, 96, salt=7)
+    model = build(1, "bf16")
+    model.eval()
+    with torch.no_grad():
+        out = model(x.to(DEV))
+        ref = om.model_forward(x, om.det_state(1, 1), training=False, emulate_bf16=True)
+    assert rel_l2(out.cpu(), ref) < 5e-3
+    model.train()
+    pred = model(x.to(DEV))
+    loss = model.loss_fn(pred, y.to(DEV))
+    loss.backward()
+    st = om.det_state(1, 1)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in st.items() if om.is_param(k)}
+    work = dict(st); work.update(leaves)
+    ref_pred = om.model_forward(x, work, training=True, emulate_bf16=True)
+    ref_loss = om.quantile_loss(ref_pred, y, PARAMS)
+    ref_loss.backward()
+    assert rel_l2(pred.detach().cpu(), ref_pred.detach()) < 3e-2
+    assert loss.item() == pytest.approx(ref_loss.item(), rel=2e-3)
+    errs = {}
+    for name, p in model.named_parameters():
+        if ".double_conv.0.bias" in name or ".double_conv.3.bias" in name:
+            continue
+        errs[name] = rel_l2(p.grad.cpu(), leaves[name].grad)
+    for k in ("last_layer.lower.weight", "last_layer.prediction.weight", "last_layer.upper.weight", "baseModel.out.conv.weight"):
+        assert errs[k] < 1e-2, (k, errs[k])
+    assert errs["baseModel.up4.conv.double_conv.3.weight"] < 3e-2
+    assert max(errs.values()) < 0.5, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+
+
+def test_backward_gradients_vs_oracle_fp32():
+    from oracle import model as om
+    model = build(1, "fp32")
+    model.train()
+    x, y = om.det_images(3, 1, 32, 32, salt=5)
+    pred = model(x.to(DEV))
+    loss = model.loss_fn(pred, y.to(DEV))
+    loss.backward()
+    st = om.det_state(1, 1)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in st.items() if om.is_param(k)}
+    work = dict(st); work.update(leaves)
+    ref_loss = om.quantile_loss(om.model_forward(x, work, training=True), y, PARAMS)
+    ref_loss.backward()
+    assert loss.item() == pytest.approx(ref_loss.item(), rel=2e-5)
+    worst = {}
+    for name, p in model.named_parameters():
+        ref = leaves[name].grad
+        if ".double_conv.0.bias" in name or ".double_conv.3.bias" in name:
+            # conv bias in front of train-mode BatchNorm: gradient is analytically zero; reference has fp noise
+            assert float(p.grad.abs().max()) == 0.0 and float(ref.abs().max()) < 1e-5
+            continue
+        worst[name] = rel_l2(p.grad.cpu(), ref)
+    bad = {k: v for k, v in worst.items() if v > 2e-3}
+    assert not bad, bad
+
+
+def test_g5_adam_trajectory_fp32():
+    from im2im_uq_amd import nn_ops
+    from oracle import model as om
+    g = load_golden("g5_adam_trajectory")
+    model = build(1, "fp32")
+    opt = nn_ops.FusedAdam(model.parameters(), lr=float(g["lr"]))
+    model.train()
+    losses = []
+    for step in range(5):
+        x, y = om.det_images(4, 1, 32, 32, salt=step)
+        pred = model(x.to(DEV))
+        loss = model.loss_fn(pred, y.to(DEV))
+        losses.append(loss.item())
+        opt.zero_grad(); loss.backward(); opt.step()
+    # Step 0 is exact to fp32 noise.  Later steps: Adam turns every gradient entry into a ~lr-sized step whose
+    # SIGN is decided by rounding noise wherever the true gradient is ~0 (dead-ReLU channels), so 0.06 % of the
+    # weights differ by 2*lr after one step on ANY two fp32 implementations (tools/debug_step.py prints this);
+    # the per-step pieces are pinned tightly elsewhere (gradients vs oracle, FusedAdam vs torch.optim.Adam).
+    assert losses[0] == pytest.approx(float(g["losses"][0]), rel=1e-5)
+    np.testing.assert_allclose(losses, g["losses"], rtol=2.5e-2)
+    model.eval()
+    with torch.no_grad():
+        probe = model(T(g["probe_x"]).to(DEV))
+    assert rel_l2(probe.cpu(), g["probe_out"]) < 1e-1
+    sd = model.state_dict()
+    for k in ("last_layer.upper.weight", "baseModel.out.conv.weight", "baseModel.up4.conv.double_conv.4.weight"):
+        flat = sd[k].flatten().cpu()
+        sample = flat[::max(1, flat.numel() // 512)][:512]
+        assert np.median(np.abs(sample.numpy() - g["sample." + k])) < 2e-4          # typical weight: same trajectory
+        np.testing.assert_allclose(sample.numpy(), g["sample." + k], atol=1.1e-2)    # worst case: 5 steps * 2*lr
+
+
+def test_g5_loss_trajectory_bf16():
+    from im2im_uq_amd import nn_ops
+    from oracle import model as om
+    g = load_golden("g5_adam_trajectory")
+    model = build(1, "bf16")
+    opt = nn_ops.FusedAdam(model.parameters(), lr=float(g["lr"]))
+    model.train()
+    losses = []
+    for step in range(5):
+        x, y = om.det_images(4, 1, 32, 32, salt=step)
+        loss = model.loss_fn(model(x.to(DEV)), y.to(DEV))
+        losses.append(loss.item())
+        opt.zero_grad(); loss.backward(); opt.step()
+    assert losses[0] == pytest.approx(float(g["losses"][0]), rel=1e-2)
+    assert losses[-1] < 0.5 * losses[0]
+    np.testing.assert_allclose(losses, g["losses"], rtol=2.5e-1)   # bf16 + Adam sign sensitivity (see fp32 test)
+
+
+def test_g11_train_net_calibrate_end_to_end_fp32():
+    """config (1): 32x32 synthetic, train_net -> get_loss_table -> calibrate_model -> nested_sets, through the
+    drop-in driver API, against the same sequence run on the reference."""
+    from im2im_uq_amd.core.calibration.calibrate_model import calibrate_model
+    from im2im_uq_amd.core.scripts.eval import get_loss_table
+    from im2im_uq_amd.core.scripts.train import train_net
+    g = load_golden("g11_end_to_end")
+    n_train, n_cal, n_val = [int(v) for v in g["split"]]
+    x, y = T(g["x"]), T(g["y"])
+    cfg = dict(PARAMS, batch_size=8, lr=1e-3, num_lambdas=50, maximum_lambda=6)
+    model = build(1, "fp32")
+    tr = TensorDataset(x[:n_train], y[:n_train])
+    ca = TensorDataset(x[n_train:n_train + n_cal], y[n_train:n_train + n_cal])
+    va = TensorDataset(x[n_train + n_cal:], y[n_train + n_cal:])
+    model = train_net(model, tr, va, DEV, 2, 8, 1e-3, False, None, 100, 100, cfg)
+    model.eval()
+    with torch.no_grad():
+        val_table = get_loss_table(model, va, cfg)
+        model, cal_table = calibrate_model(model, ca, cfg)
+        lo, mid, hi = model.nested_sets((x[n_train + n_cal:].to(DEV),))
+    lambdas = torch.linspace(0, 6, 50)
+    dl = float(lambdas[1] - lambdas[0])
+    assert abs(float(model.lhat) - float(g["lhat"])) <= dl + 1e-6          # same grid point or its neighbour
+    assert rel_l2(mid.cpu(), g["pred"]) < 6e-2                              # two Adam steps: see test_g5 note
+    assert rel_l2(lo.cpu(), g["lower"]) < 1e-1 and rel_l2(hi.cpu(), g["upper"]) < 1e-1
+    assert np.abs(val_table.numpy() - g["val_table"]).mean() < 3e-2
+    assert cal_table.shape == g["cal_table"].shape
+
+
+def test_full_size_320_smoke_properties_bf16():
+    """BASELINE size: one 320x320 train step and eval forward run, outputs finite, lower <= pred <= upper after
+    nested sets, loss decreases over a few steps on a fixed batch."""
+    from im2im_uq_amd import nn_ops
+    from oracle import model as om
+    model = build(1, "bf16")
+    opt = nn_ops.FusedAdam(model.parameters(), lr=1e-3)
+    x, y = om.det_images(2, 1, 320, 320, salt=2)
+    x, y = x.to(DEV), y.to(DEV)
+    model.train()
+    losses = []
+    for _ in range(6):
+        loss = model.loss_fn(model(x), y)
+        losses.append(loss.item())
+        opt.zero_grad(); loss.backward(); opt.step()
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    model.eval()
+    with torch.no_grad():
+        out = model(x)
+        lo, mid, hi = model.nested_sets_from_output(out, 1.0)
+    assert out.shape == (2, 3, 1, 320, 320) and bool(torch.isfinite(out).all())
+    assert bool((lo <= mid).all()) and bool((mid <= hi).all())
