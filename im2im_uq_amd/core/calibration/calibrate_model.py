@@ -172,13 +172,18 @@ def collect_outputs(model, dataset, config, device, shard=True):
         outputs = torch.cat([model(s[0].unsqueeze(0).to(device, torch.float32)) for s in samples], dim=0)
         return outputs.contiguous(), labels.contiguous()
     n_total = len(dataset)
-    if dist is not None:
+    if dist is not None and not getattr(dataset, "im2im_local_shard", False):
         lo, hi = shard_bounds(n_total, dist.get_rank(), dist.get_world_size())
         dataset = Subset(dataset, range(lo, hi))
     n = len(dataset)
     outputs = labels = None
     counter = 0
-    loader = DataLoader(dataset, num_workers=0, batch_size=config['batch_size'], pin_memory=True)
+    if isinstance(dataset, TensorDataset) and dataset.tensors[0].is_cuda:
+        # inputs already resident in HBM: slice batches in place, no host round trip
+        bs = config['batch_size']
+        loader = ((dataset.tensors[0][s:s + bs], dataset.tensors[1][s:s + bs]) for s in range(0, n, bs))
+    else:
+        loader = DataLoader(dataset, num_workers=0, batch_size=config['batch_size'], pin_memory=True)
     for batch in loader:
         out = model(batch[0].to(device=device, dtype=torch.float32))
         if outputs is None:
@@ -233,6 +238,8 @@ def calibrate_model(model, dataset, config):
         rcps_loss_fn = get_rcps_loss_fn(config)
         model = model.to(device)
         n_total = len(dataset) if config.get('dataset') != 'temca' else None
+        if getattr(dataset, "im2im_local_shard", False):      # caller already holds only this rank's shard
+            n_total = None
         outputs, labels = collect_outputs(model, dataset, config, device)
         dlambda = lambdas[1] - lambdas[0]
         model.set_lhat(lambdas[-1] + dlambda - 1e-9)
@@ -243,10 +250,8 @@ def calibrate_model(model, dataset, config):
             table = torch.stack([get_rcps_losses_from_outputs(model, ds, rcps_loss_fn, lam - dlambda, device)
                                  for lam in lambdas], dim=1).to(device)
         if _dist() is not None:
-            if n_total is None:
-                cnt = torch.tensor([table.shape[0]], device=table.device)
-                _dist().all_reduce(cnt)
-                n_total = int(cnt.item())
+            if n_total is None:                               # equal-size local shards
+                n_total = table.shape[0] * _dist().get_world_size()
             table = gather_rows(table, n_total)
         lhat, calib_loss_table, trace = scan_loss_table(table.cpu(), lambdas, alpha, delta)
         model.set_lhat(lhat)

@@ -57,7 +57,7 @@ template <> struct Frag<float> {
 };
 
 template <typename T, int TH, int TW, int BN, int WM, int WN, int TAPS>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int PAD = (TAPS == 9) ? 1 : 0;
   constexpr int HH = TH + 2 * PAD, HWD = TW + 2 * PAD, HPX = HH * HWD;
   constexpr int KC = 32;
@@ -497,7 +497,7 @@ int launch_wgrad(const void* x, const void* dz, float* partial, int64_t partial_
   const size_t wsz = (size_t)Co * TAPS * Ci * sizeof(float);
   int64_t max_split = partial_bytes / (int64_t)wsz;
   if (max_split < 1) return fail_invalid("wgrad: workspace smaller than one weight-sized slab");
-  int64_t nsplit = cdiv(1024, cblocks);
+  int64_t nsplit = cdiv(512, cblocks);
   if (nsplit > a.ntiles) nsplit = a.ntiles;
   if (nsplit > max_split) nsplit = max_split;
   if (nsplit < 1) nsplit = 1;
@@ -522,7 +522,7 @@ extern "C" int64_t im2im_conv_wgrad_workspace_bytes(int32_t B, int32_t H, int32_
   if (Ci <= 0 || Co <= 0 || Ci % 64 || Co % 32) return -1;
   const int64_t ntiles = (int64_t)B * im2im::cdiv(H, 8) * im2im::cdiv(W, 16);
   const int64_t cblocks = im2im::cdiv(Co, 64) * (Ci / 64);
-  int64_t nsplit = im2im::cdiv(1024, cblocks);
+  int64_t nsplit = im2im::cdiv(512, cblocks);
   if (nsplit > ntiles) nsplit = ntiles;
   if (nsplit < 1) nsplit = 1;
   return nsplit * (int64_t)Co * taps * Ci * (int64_t)sizeof(float);

@@ -61,6 +61,42 @@ class _Scratch:
         return buf
 
 
+class KernelTimer:
+    """optional per-launch timing of the MFMA conv kernels with HIP events recorded on the launch stream
+    (bench.py's roofline leg).  Usage: nn_ops.TIMER = KernelTimer(); ...; rows = nn_ops.TIMER.collect()."""
+
+    def __init__(self):
+        self.records = []
+
+    def wrap(self, name, flops, device):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(device))
+        self.records.append((name, flops, e0, e1))
+        return e1
+
+    def collect(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            n, f, t = out.get(name, (0, 0.0, 0.0))
+            out[name] = (n + 1, f + flops, t + ms)
+        return out
+
+
+TIMER = None
+
+
+def _tile_name(kind, h, w_, co, taps, dtype):
+    small = h < 64 or w_ < 64
+    bn = 128 if co % 128 == 0 else 64 if co % 64 == 0 else 32
+    if kind == "wgrad":
+        return f"conv_wgrad_kernel<{'bf16' if dtype == BF16 else 'f32'},8,16,{taps}>"
+    th, tw = (16, 16) if not small else ((8, 16) if bn == 32 else (8, 8))
+    return f"conv_igemm_kernel<{'bf16' if dtype == BF16 else 'f32'},{th},{tw},{bn},taps={taps}>"
+
+
 def _gpu(t: torch.Tensor, name: str) -> None:
     if not t.is_cuda:
         raise _lib.Im2ImError(f"{name} must live on the GPU; the HIP path has no CPU fallback (got {t.device})")
@@ -93,8 +129,11 @@ def conv_fwd(x, wf, bias=None, scale_shift=None, relu=False, want_stats=False):
     sc = sh = None
     if scale_shift is not None:
         sc, sh = scale_shift[0], scale_shift[1]
+    ev = TIMER.wrap(_tile_name("igemm", h, w_, co, taps, x.dtype), 2.0 * b * h * w_ * co * ci * taps, x.device) if TIMER else None
     check(lib.im2im_conv_fwd(dptr(x), dptr(wf), dptr(bias), dptr(sc), dptr(sh), dptr(y), dptr(stats), b, h, w_, ci, co, taps,
                              int(relu), _DT[x.dtype], stream_ptr(x.device)), "im2im_conv_fwd")
+    if ev is not None:
+        ev.record(torch.cuda.current_stream(x.device))
     return (y, stats) if want_stats else y
 
 
@@ -107,8 +146,11 @@ def conv_wgrad(x, dz, taps):
         raise _lib.Im2ImError(f"conv wgrad: unsupported channels Ci={ci} Co={co}")
     ws = _Scratch.get(nbytes, x.device)
     dw = torch.empty((co, ci, taps), dtype=F32, device=x.device)
+    ev = TIMER.wrap(_tile_name("wgrad", h, w_, co, taps, x.dtype), 2.0 * b * h * w_ * co * ci * taps, x.device) if TIMER else None
     check(lib.im2im_conv_wgrad(dptr(x), dptr(dz), dptr(dw), dptr(ws), ws.numel(), b, h, w_, ci, co, taps, _DT[x.dtype],
                                stream_ptr(x.device)), "im2im_conv_wgrad")
+    if ev is not None:
+        ev.record(torch.cuda.current_stream(x.device))
     return dw
 
 
