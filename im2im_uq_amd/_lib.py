@@ -34,6 +34,7 @@ _i32, _i64, _f32, _f64, _ptr = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, c
 SIGNATURES = {
     "im2im_abi_version": (_i32, []),
     "im2im_last_error": (ctypes.c_char_p, []),
+    "im2im_rcps_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "im2im_rcps_loss_table": (_i32, [_ptr, _ptr, _i64, _i64, _ptr, _i32, _ptr, _ptr, _ptr, _ptr]),
     "im2im_rcps_miscoverage": (_i32, [_ptr, _ptr, _i64, _i32, _i64, _f32, _ptr, _ptr]),
     "im2im_nested_sets": (_i32, [_ptr, _i64, _i64, _f32, _ptr, _ptr, _i32, _ptr]),

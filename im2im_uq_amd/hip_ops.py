@@ -32,14 +32,34 @@ def rcps_loss_table(outputs: torch.Tensor, labels: torch.Tensor, lam: torch.Tens
         raise _lib.Im2ImError("lam grid must be ascending (the one-pass scoring relies on monotone edges)")
     L = lam_cpu.numel()
     dev = outputs.device
-    lam_dev = lam_cpu.to(dev)
-    hist = torch.empty((n, L + 1), dtype=torch.int32, device=dev)
+    lam_dev = _grid_on_device(lam_cpu, dev)
+    hist = torch.empty((max(1, lib.im2im_rcps_workspace_bytes(n, p, L) // 4),), dtype=torch.int32, device=dev)
     table = torch.empty((n, L), dtype=F32, device=dev)
     counts = torch.empty((n, L), dtype=torch.int32, device=dev) if want_counts else None
-    with torch.cuda.device(dev):
-        check(lib.im2im_rcps_loss_table(dptr(outputs), dptr(labels), n, p, dptr(lam_dev), L, dptr(hist), dptr(table),
-                                        dptr(counts), stream_ptr(dev)), "im2im_rcps_loss_table")
+    rcps_loss_table_raw(outputs, labels, n, p, lam_dev, hist, table, counts)
     return (table, counts) if want_counts else table
+
+
+_grid_cache = {}
+
+
+def _grid_on_device(lam_cpu: torch.Tensor, dev) -> torch.Tensor:
+    """the lambda grid is tiny and reused call after call: keep the device copy (keyed by its bytes)."""
+    key = (lam_cpu.numpy().tobytes(), str(dev))
+    t = _grid_cache.get(key)
+    if t is None:
+        if len(_grid_cache) > 64:
+            _grid_cache.clear()
+        t = _grid_cache[key] = lam_cpu.to(dev)
+    return t
+
+
+def rcps_loss_table_raw(outputs, labels, n, p, lam_dev, hist, table, counts=None):
+    """no allocation, no host traffic: memset + histogram kernel + suffix kernel on the current stream."""
+    dev = outputs.device
+    with torch.cuda.device(dev):
+        check(lib.im2im_rcps_loss_table(dptr(outputs), dptr(labels), n, p, dptr(lam_dev), lam_dev.numel(), dptr(hist), dptr(table),
+                                        dptr(counts), stream_ptr(dev)), "im2im_rcps_loss_table")
 
 
 def rcps_miscoverage(outputs: torch.Tensor, labels: torch.Tensor, lam: float) -> torch.Tensor:

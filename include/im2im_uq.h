@@ -48,12 +48,13 @@ const char* im2im_last_error(void);
  *   label   [N][P]    fp32
  *   lam     [L]       fp32   device; ascending grid of the lambdas the edges are evaluated at
  *                            (the caller passes lambdas - dlambda for calibrate_model, Q1)
- *   hist_ws [N][L+1]  int32  workspace (zeroed by the call)
+ *   hist_ws           int32  workspace of im2im_rcps_workspace_bytes(N, P, L) bytes (no initialisation needed)
  *   table   [N][L]    fp32   table[n][j] = (#pixels of image n missed at lam[j]) / P, bit-identical
  *                            to the reference's fp32 mean of 0/1 indicators
  *   counts  [N][L]    int32  optional (may be NULL): the integer miss counts
  * Edge arithmetic is fp32 with separate multiply and add (no FMA), as on the reference CPU path.
  */
+int64_t im2im_rcps_workspace_bytes(int64_t N, int64_t P, int32_t L);
 int im2im_rcps_loss_table(const float* out3, const float* label, int64_t N, int64_t P,
                           const float* lam, int32_t L, int32_t* hist_ws, float* table,
                           int32_t* counts, im2im_stream_t stream);
