@@ -189,12 +189,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   }
 
   // ---------------------------------------------------------------- epilogue
+  // The MFMA result layout gives each lane ONE channel of 16 pixel rows; storing that directly is 2 bytes per lane
+  // per store instruction (issue-bound).  Instead every wave transposes its sub-tile through a private LDS region
+  // ([pixel][channel], rows padded by 16 B) and writes whole 16-byte pieces of NHWC rows.
+  constexpr int WROWS = MT * 32, WCOLS = NT * 32;
+  constexpr int WP = WCOLS * (int)sizeof(T) + 16;             // padded row pitch of the wave's LDS tile
+  constexpr int WBYTES = WROWS * WP;
+  constexpr int EPR = WCOLS / EPP;                            // 16-byte pieces per row
+  constexpr int ROWS_PER_PASS = 64 / EPR;
   T* __restrict__ yg = reinterpret_cast<T*>(a.y) + (size_t)b * a.H * a.W * a.Co;
   const bool want_stats = a.stats != nullptr;
-  if (want_stats) __syncthreads();                 // LDS (A region) is re-used for the stats scratch
+  __syncthreads();                                           // every wave is done reading the operand buffers
+  char* wbuf = smem + wave * WBYTES;
+  float st_s[NT], st_q[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int nl = (wn * NT + nt) * 32 + l31;      // channel within the block tile
+    const int nl = (wn * NT + nt) * 32 + l31;                  // channel within the block tile
     const int n = n0 + nl;
     const float bias_v = a.bias ? a.bias[n] : 0.f;
     const float sc = a.scale ? a.scale[n] : 1.f;
@@ -204,26 +214,43 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int m = wm * WROWS + row;
         const int yy = y0 + m / TW, xx = x0 + m % TW;
         float v = acc[mt][nt][r] + bias_v;
         v = v * sc + sh;
         if (a.relu) v = fmaxf(v, 0.f);
         const T tv = from_float<T>(v);
+        *reinterpret_cast<T*>(wbuf + row * WP + (nt * 32 + l31) * (int)sizeof(T)) = tv;
         if (yy < a.H && xx < a.W) {
-          yg[((size_t)yy * a.W + xx) * a.Co + n] = tv;
           const float fv = to_float(tv);
           s += fv; sq += fv * fv;
         }
       }
     }
-    if (want_stats) {
+    st_s[nt] = s; st_q[nt] = sq;
+  }
+  // wave-private region: LDS operations of one wave complete in issue order, no barrier needed
+#pragma unroll
+  for (int pass = 0; pass < WROWS / ROWS_PER_PASS; ++pass) {
+    const int row = pass * ROWS_PER_PASS + lane / EPR;
+    const int piece = lane % EPR;
+    const uint4 v = *reinterpret_cast<const uint4*>(wbuf + row * WP + piece * 16);
+    const int m = wm * WROWS + row;
+    const int yy = y0 + m / TW, xx = x0 + m % TW;
+    if (yy < a.H && xx < a.W)
+      *reinterpret_cast<uint4*>(yg + ((size_t)yy * a.W + xx) * a.Co + n0 + wn * WCOLS + piece * EPP) = v;
+  }
+  if (want_stats) {
+    __syncthreads();                                         // the stats scratch aliases wave 0's tile
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int nl = (wn * NT + nt) * 32 + l31;
+      float s = st_s[nt], sq = st_q[nt];
       s += __shfl_xor(s, 32, 64);
       sq += __shfl_xor(sq, 32, 64);
       if (half == 0) { ldsS[(wm * BN + nl) * 2 + 0] = s; ldsS[(wm * BN + nl) * 2 + 1] = sq; }
     }
-  }
-  if (want_stats) {
     __syncthreads();
     if (tid < BN) {
       float s = 0.f, sq = 0.f;
@@ -423,7 +450,9 @@ int launch_conv(const ConvArgs& a_in, hipStream_t stream) {
   a.tilesX = (int)cdiv(a.W, TW);
   constexpr int PAD = (TAPS == 9) ? 1 : 0;
   constexpr int ROWB = 32 * (int)sizeof(T) + 16;
-  constexpr size_t smem = (size_t)((TH + 2 * PAD) * (TW + 2 * PAD) + 2 * BN) * ROWB;
+  constexpr size_t smem_main = (size_t)((TH + 2 * PAD) * (TW + 2 * PAD) + 2 * BN) * ROWB;
+  constexpr size_t smem_epi = (size_t)4 * (TH * TW / WM) * ((BN / WN) * sizeof(T) + 16);   // 4 wave-private output tiles
+  constexpr size_t smem = smem_main > smem_epi ? smem_main : smem_epi;
   static_assert(smem >= (size_t)WM * BN * 2 * 4, "stats scratch fits");
   auto kern = conv_igemm_kernel<T, TH, TW, BN, WM, WN, TAPS>;
   static bool attr_set = false;
