@@ -56,15 +56,16 @@ template <> struct Frag<float> {
   }
 };
 
-template <typename T, int TH, int TW, int BN, int WM, int WN, int TAPS>
+template <typename T, int TB, int TH, int TW, int BN, int WM, int WN, int TAPS>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int PAD = (TAPS == 9) ? 1 : 0;
-  constexpr int HH = TH + 2 * PAD, HWD = TW + 2 * PAD, HPX = HH * HWD;
+  constexpr int HH = TH + 2 * PAD, HWD = TW + 2 * PAD, HPI = HH * HWD, HPX = TB * HPI;   // halo pixels per image / per tile
+  constexpr int MI = TH * TW;                         // output pixels per image in the tile
   constexpr int KC = 32;
   constexpr int EPP = 16 / (int)sizeof(T);          // elements per 16-B piece
   constexpr int PPR = KC / EPP;                     // pieces per row
   constexpr int ROWB = KC * (int)sizeof(T) + 16;    // padded LDS row pitch (bytes)
-  constexpr int M = TH * TW;
+  constexpr int M = TB * TH * TW;
   constexpr int MT = M / (32 * WM), NT = BN / (32 * WN);
   static_assert(WM * WN == 4, "4 waves");
   static_assert(MT >= 1 && NT >= 1 && M % (32 * WM) == 0 && BN % (32 * WN) == 0, "tile split");
@@ -84,11 +85,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   int mt_id = blockIdx.x;
   const int tx_id = mt_id % a.tilesX; mt_id /= a.tilesX;
   const int ty_id = mt_id % a.tilesY;
-  const int b = mt_id / a.tilesY;
+  const int b0 = (mt_id / a.tilesY) * TB;             // first image of this tile (TB images share the weight tiles)
   const int y0 = ty_id * TH, x0 = tx_id * TW;
   const int n0 = blockIdx.y * BN;
 
-  const T* __restrict__ xg = reinterpret_cast<const T*>(a.x) + (size_t)b * a.H * a.W * a.Ci;
+  const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
 
   // per-lane LDS byte offsets of this lane's A rows / B rows
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = (wm * MT + mt) * 32 + l31;
-    aoff[mt] = ((m / TW) * HWD + (m % TW)) * ROWB;
+    aoff[mt] = ((m / MI) * HPI + ((m % MI) / TW) * HWD + (m % TW)) * ROWB;
   }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) boff[nt] = ((wn * NT + nt) * 32 + l31) * ROWB;
@@ -116,11 +117,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     for (int i = 0; i < A_ROUNDS; ++i) {
       const int p = i * 256 + tid;
       const int px = p / PPR, part = p % PPR;
-      const int hy = px / HWD, hx = px % HWD;
+      const int bb = b0 + px / HPI, pi = px % HPI;
+      const int hy = pi / HWD, hx = pi % HWD;
       const int yy = y0 + hy - PAD, xx = x0 + hx - PAD;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (px < HPX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
-        v = *reinterpret_cast<const uint4*>(xg + ((size_t)yy * a.W + xx) * a.Ci + chunk * KC + part * EPP);
+      if (px < HPX && bb < a.B && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
+        v = *reinterpret_cast<const uint4*>(xg + (((size_t)bb * a.H + yy) * a.W + xx) * a.Ci + chunk * KC + part * EPP);
       ra[i] = v;
     }
   };
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int WBYTES = WROWS * WP;
   constexpr int EPR = WCOLS / EPP;                            // 16-byte pieces per row
   constexpr int ROWS_PER_PASS = 64 / EPR;
-  T* __restrict__ yg = reinterpret_cast<T*>(a.y) + (size_t)b * a.H * a.W * a.Co;
+  T* __restrict__ yg = reinterpret_cast<T*>(a.y);
   const bool want_stats = a.stats != nullptr;
   __syncthreads();                                           // every wave is done reading the operand buffers
   char* wbuf = smem + wave * WBYTES;
@@ -216,13 +218,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         const int m = wm * WROWS + row;
-        const int yy = y0 + m / TW, xx = x0 + m % TW;
+        const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
         float v = acc[mt][nt][r] + bias_v;
         v = v * sc + sh;
         if (a.relu) v = fmaxf(v, 0.f);
         const T tv = from_float<T>(v);
         *reinterpret_cast<T*>(wbuf + row * WP + (nt * 32 + l31) * (int)sizeof(T)) = tv;
-        if (yy < a.H && xx < a.W) {
+        if (bb < a.B && yy < a.H && xx < a.W) {
           const float fv = to_float(tv);
           s += fv; sq += fv * fv;
         }
@@ -237,9 +239,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     const int piece = lane % EPR;
     const uint4 v = *reinterpret_cast<const uint4*>(wbuf + row * WP + piece * 16);
     const int m = wm * WROWS + row;
-    const int yy = y0 + m / TW, xx = x0 + m % TW;
-    if (yy < a.H && xx < a.W)
-      *reinterpret_cast<uint4*>(yg + ((size_t)yy * a.W + xx) * a.Co + n0 + wn * WCOLS + piece * EPP) = v;
+    const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
+    if (bb < a.B && yy < a.H && xx < a.W)
+      *reinterpret_cast<uint4*>(yg + (((size_t)bb * a.H + yy) * a.W + xx) * a.Co + n0 + wn * WCOLS + piece * EPP) = v;
   }
   if (want_stats) {
     __syncthreads();                                         // the stats scratch aliases wave 0's tile
@@ -443,56 +445,58 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
   }
 }
 
-template <typename T, int TH, int TW, int BN, int WM, int WN, int TAPS>
+template <typename T, int TB, int TH, int TW, int BN, int WM, int WN, int TAPS>
 int launch_conv(const ConvArgs& a_in, hipStream_t stream) {
   ConvArgs a = a_in;
   a.tilesY = (int)cdiv(a.H, TH);
   a.tilesX = (int)cdiv(a.W, TW);
   constexpr int PAD = (TAPS == 9) ? 1 : 0;
   constexpr int ROWB = 32 * (int)sizeof(T) + 16;
-  constexpr size_t smem_main = (size_t)((TH + 2 * PAD) * (TW + 2 * PAD) + 2 * BN) * ROWB;
-  constexpr size_t smem_epi = (size_t)4 * (TH * TW / WM) * ((BN / WN) * sizeof(T) + 16);   // 4 wave-private output tiles
+  constexpr size_t smem_main = (size_t)(TB * (TH + 2 * PAD) * (TW + 2 * PAD) + 2 * BN) * ROWB;
+  constexpr size_t smem_epi = (size_t)4 * (TB * TH * TW / WM) * ((BN / WN) * sizeof(T) + 16);   // 4 wave-private output tiles
   constexpr size_t smem = smem_main > smem_epi ? smem_main : smem_epi;
   static_assert(smem >= (size_t)WM * BN * 2 * 4, "stats scratch fits");
-  auto kern = conv_igemm_kernel<T, TH, TW, BN, WM, WN, TAPS>;
+  auto kern = conv_igemm_kernel<T, TB, TH, TW, BN, WM, WN, TAPS>;
   static bool attr_set = false;
   if (!attr_set && smem > 64 * 1024) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  dim3 grid((unsigned)((size_t)a.B * a.tilesY * a.tilesX), (unsigned)(a.Co / BN));
+  dim3 grid((unsigned)((size_t)cdiv(a.B, TB) * a.tilesY * a.tilesX), (unsigned)(a.Co / BN));
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, a);
   return check_launch("conv_igemm_kernel");
 }
 
 // pixel-tile shape per problem: 16x16 for the large-extent levels, 8x8 (8x16 when Cout == 32) for the
 // deep, small-extent ones (40x40, 20x20) so that little of a tile hangs over the image edge.
-struct TileChoice { int th, tw, bn; };
+struct TileChoice { int tb, th, tw, bn; };
 inline TileChoice pick_tile(int H, int W, int Co) {
   const bool small = (H < 64 || W < 64);
   const int bn = (Co % 128 == 0) ? 128 : (Co % 64 == 0) ? 64 : 32;
-  if (!small) return {16, 16, bn};
-  return bn == 32 ? TileChoice{8, 16, 32} : TileChoice{8, 8, bn};
+  if (!small) return {1, 16, 16, bn};
+  // small extents: an 8x8 patch of FOUR consecutive images per tile, so a weight tile is still amortised over
+  // 256 output pixels (M = 256) while little of a tile hangs over the 40x40 / 20x20 image edge
+  return TileChoice{4, 8, 8, bn};
 }
 
 template <typename T, int TAPS>
 int dispatch_conv(const ConvArgs& a, hipStream_t stream) {
   const TileChoice t = pick_tile(a.H, a.W, a.Co);
-  if (t.th == 16) {
-    if (t.bn == 128) return launch_conv<T, 16, 16, 128, 2, 2, TAPS>(a, stream);
-    if (t.bn == 64) return launch_conv<T, 16, 16, 64, 4, 1, TAPS>(a, stream);
-    return launch_conv<T, 16, 16, 32, 4, 1, TAPS>(a, stream);
+  if (t.tb == 1) {
+    if (t.bn == 128) return launch_conv<T, 1, 16, 16, 128, 2, 2, TAPS>(a, stream);
+    if (t.bn == 64) return launch_conv<T, 1, 16, 16, 64, 4, 1, TAPS>(a, stream);
+    return launch_conv<T, 1, 16, 16, 32, 4, 1, TAPS>(a, stream);
   }
-  if (t.bn == 128) return launch_conv<T, 8, 8, 128, 1, 4, TAPS>(a, stream);
-  if (t.bn == 64) return launch_conv<T, 8, 8, 64, 2, 2, TAPS>(a, stream);
-  return launch_conv<T, 8, 16, 32, 4, 1, TAPS>(a, stream);
+  if (t.bn == 128) return launch_conv<T, 4, 8, 8, 128, 2, 2, TAPS>(a, stream);
+  if (t.bn == 64) return launch_conv<T, 4, 8, 8, 64, 4, 1, TAPS>(a, stream);
+  return launch_conv<T, 4, 8, 8, 32, 4, 1, TAPS>(a, stream);
 }
 
 }  // namespace
 
 extern "C" int64_t im2im_conv_stats_rows(int32_t B, int32_t H, int32_t W, int32_t Co) {
   const TileChoice t = pick_tile(H, W, Co);
-  return (int64_t)B * im2im::cdiv(H, t.th) * im2im::cdiv(W, t.tw);
+  return im2im::cdiv(B, t.tb) * im2im::cdiv(H, t.th) * im2im::cdiv(W, t.tw);
 }
 
 extern "C" int im2im_conv_fwd(const void* x, const void* w, const float* bias, const float* scale, const float* shift,

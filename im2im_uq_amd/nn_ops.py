@@ -93,8 +93,8 @@ def _tile_name(kind, h, w_, co, taps, dtype):
     bn = 128 if co % 128 == 0 else 64 if co % 64 == 0 else 32
     if kind == "wgrad":
         return f"conv_wgrad_kernel<{'bf16' if dtype == BF16 else 'f32'},8,16,{taps}>"
-    th, tw = (16, 16) if not small else ((8, 16) if bn == 32 else (8, 8))
-    return f"conv_igemm_kernel<{'bf16' if dtype == BF16 else 'f32'},{th},{tw},{bn},taps={taps}>"
+    tb, th, tw = (1, 16, 16) if not small else (4, 8, 8)
+    return f"conv_igemm_kernel<{'bf16' if dtype == BF16 else 'f32'},{tb}x{th}x{tw},{bn},taps={taps}>"
 
 
 def _gpu(t: torch.Tensor, name: str) -> None:
