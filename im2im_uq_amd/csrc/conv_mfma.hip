@@ -17,6 +17,7 @@
 // LDS rows are padded by 16 B so ds_read_b128 operand fetches are (nearly) conflict free.
 #include "common.h"
 #include "dtypes.h"
+#include <type_traits>
 
 namespace {
 
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ldsA = smem;
-  char* ldsB = smem + A_BYTES;                      // two buffers
+  char* ldsB = smem + A_BYTES;                      // two weight buffers
   float* ldsS = reinterpret_cast<float*>(smem);     // stats scratch, re-uses A after the main loop
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -110,71 +111,64 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  uint4 ra[A_ROUNDS], rb[B_ROUNDS];
+  uint4 ra[A_ROUNDS], rb[2][B_ROUNDS];
+
+  // Per-lane element offsets of this thread's staging pieces, computed ONCE (uniform base + 32-bit lane offset lets
+  // the compiler use scalar-base addressing and keeps the unrolled loop free of index arithmetic).
+  //   halo piece i:  xg_tile + a_goff[i] + chunk*KC      (a_goff < 0: outside the image/batch -> zeros)
+  //   weight piece i: wg_tile + b_goff[i] + tap*Ci + chunk*KC
+  const T* __restrict__ xg_tile = xg + (size_t)b0 * a.H * a.W * a.Ci;
+  const T* __restrict__ wg_tile = wg + (size_t)n0 * TAPS * a.Ci;
+  int a_goff[A_ROUNDS], a_loff[A_ROUNDS], b_goff[B_ROUNDS], b_loff[B_ROUNDS];
+#pragma unroll
+  for (int i = 0; i < A_ROUNDS; ++i) {
+    const int p = i * 256 + tid;
+    const int px = p / PPR, part = p % PPR;
+    const int tb = px / HPI, pi = px % HPI;
+    const int yy = y0 + pi / HWD - PAD, xx = x0 + pi % HWD - PAD;
+    const bool ok = px < HPX && b0 + tb < a.B && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+    a_goff[i] = ok ? (((tb * a.H + yy) * a.W + xx) * a.Ci + part * EPP) : -1;
+    a_loff[i] = (px < HPX) ? px * ROWB + part * 16 : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < B_ROUNDS; ++i) {
+    const int p = i * 256 + tid;
+    const int n = p / PPR, part = p % PPR;
+    b_goff[i] = (n < BN) ? (n * TAPS * a.Ci + part * EPP) : -1;
+    b_loff[i] = (n < BN) ? n * ROWB + part * 16 : -1;
+  }
 
   auto gload_A = [&](int chunk) {
+    const T* src = xg_tile + chunk * KC;
 #pragma unroll
     for (int i = 0; i < A_ROUNDS; ++i) {
-      const int p = i * 256 + tid;
-      const int px = p / PPR, part = p % PPR;
-      const int bb = b0 + px / HPI, pi = px % HPI;
-      const int hy = pi / HWD, hx = pi % HWD;
-      const int yy = y0 + hy - PAD, xx = x0 + hx - PAD;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (px < HPX && bb < a.B && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
-        v = *reinterpret_cast<const uint4*>(xg + (((size_t)bb * a.H + yy) * a.W + xx) * a.Ci + chunk * KC + part * EPP);
+      if (a_goff[i] >= 0) v = *reinterpret_cast<const uint4*>(src + a_goff[i]);
       ra[i] = v;
     }
   };
   auto swrite_A = [&]() {
 #pragma unroll
-    for (int i = 0; i < A_ROUNDS; ++i) {
-      const int p = i * 256 + tid;
-      const int px = p / PPR, part = p % PPR;
-      if (px < HPX) *reinterpret_cast<uint4*>(ldsA + px * ROWB + part * 16) = ra[i];
-    }
+    for (int i = 0; i < A_ROUNDS; ++i)
+      if ((HPX * PPR) % 256 == 0 || a_loff[i] >= 0) *reinterpret_cast<uint4*>(ldsA + a_loff[i]) = ra[i];
   };
-  auto gload_B = [&](int chunk, int tap) {
+  auto gload_B = [&](uint4 (&r)[B_ROUNDS], int chunk, int tap) {
+    const T* src = wg_tile + (tap * a.Ci + chunk * KC);
 #pragma unroll
     for (int i = 0; i < B_ROUNDS; ++i) {
-      const int p = i * 256 + tid;
-      const int n = p / PPR, part = p % PPR;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (n < BN)
-        v = *reinterpret_cast<const uint4*>(wg + ((size_t)(n0 + n) * TAPS + tap) * a.Ci + chunk * KC + part * EPP);
-      rb[i] = v;
+      if ((BN * PPR) % 256 == 0 || b_goff[i] >= 0) v = *reinterpret_cast<const uint4*>(src + b_goff[i]);
+      r[i] = v;
     }
   };
-  auto swrite_B = [&](int buf) {
+  auto swrite_B = [&](const uint4 (&r)[B_ROUNDS], int buf) {
 #pragma unroll
-    for (int i = 0; i < B_ROUNDS; ++i) {
-      const int p = i * 256 + tid;
-      const int n = p / PPR, part = p % PPR;
-      if (n < BN) *reinterpret_cast<uint4*>(ldsB + buf * B_BYTES + n * ROWB + part * 16) = rb[i];
-    }
+    for (int i = 0; i < B_ROUNDS; ++i)
+      if ((BN * PPR) % 256 == 0 || b_loff[i] >= 0) *reinterpret_cast<uint4*>(ldsB + buf * B_BYTES + b_loff[i]) = r[i];
   };
-
-  const int nchunks = a.Ci / KC;
-  const int niter = nchunks * TAPS;
-  gload_A(0);
-  gload_B(0, 0);
-  int chunk = 0, tap = 0;
-  for (int it = 0; it < niter; ++it) {
-    if (tap == 0) {
-      if (it) __syncthreads();                     // everyone done reading the previous halo
-      swrite_A();
-    }
-    swrite_B(it & 1);
-    __syncthreads();
-    int ntap = tap + 1, nchunk = chunk;
-    if (ntap == TAPS) { ntap = 0; ++nchunk; }
-    if (it + 1 < niter) {
-      gload_B(nchunk, ntap);
-      if (ntap == 0) gload_A(nchunk);
-    }
-    const int toff = (TAPS == 9) ? ((tap / 3) * HWD + (tap % 3)) * ROWB : 0;
+  auto compute = [&](int toff, int buf) {
     const char* pa = ldsA + toff;
-    const char* pb = ldsB + (it & 1) * B_BYTES;
+    const char* pb = ldsB + buf * B_BYTES;
 #pragma unroll
     for (int ks = 0; ks < Frag<T>::KSTEPS; ++ks) {
       typename Frag<T>::AB fa[MT], fb[NT];
@@ -187,7 +181,54 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Frag<T>::mfma(fa[mt], fb[nt], acc[mt][nt]);
     }
-    tap = ntap; chunk = nchunk;
+  };
+
+  const int nchunks = a.Ci / KC;
+  if constexpr (TAPS == 9) {
+    // 9 taps fully unrolled (every register-set / LDS-buffer index and tap offset is a compile-time constant).
+    // Weight tiles are prefetched TWO iterations ahead: iteration `it` writes register set it&1 (loaded at it-2)
+    // to LDS buffer it&1 and immediately re-issues that set for it+2.  9 is odd, so the parity of a chunk's first
+    // tap alternates: the body is instantiated for both parities.  The next chunk's halo is fetched 3 taps early.
+    gload_A(0);
+    gload_B(rb[0], 0, 0);
+    gload_B(rb[1], 0, 1);
+    auto chunk_body = [&](auto parity, int chunk) {
+      constexpr int P0 = decltype(parity)::value;
+      const bool more = chunk + 1 < nchunks;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        constexpr int dummy = 0; (void)dummy;
+        const int set = (P0 + tap) & 1;                // compile-time after unrolling
+        if (tap == 0) {
+          if (chunk) __syncthreads();                // everyone done reading the previous halo
+          swrite_A();
+        }
+        if (set) swrite_B(rb[1], 1); else swrite_B(rb[0], 0);
+        __syncthreads();
+        if (tap + 2 < 9) { if (set) gload_B(rb[1], chunk, tap + 2); else gload_B(rb[0], chunk, tap + 2); }
+        else if (more) { if (set) gload_B(rb[1], chunk + 1, tap + 2 - 9); else gload_B(rb[0], chunk + 1, tap + 2 - 9); }
+        if (tap == 6 && more) gload_A(chunk + 1);
+        compute(((tap / 3) * HWD + (tap % 3)) * ROWB, set);
+      }
+    };
+    for (int chunk = 0; chunk < nchunks; chunk += 2) {
+      chunk_body(std::integral_constant<int, 0>{}, chunk);
+      if (chunk + 1 < nchunks) chunk_body(std::integral_constant<int, 1>{}, chunk + 1);
+    }
+  } else {
+    gload_A(0);
+    gload_B(rb[0], 0, 0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      if (chunk) __syncthreads();
+      swrite_A();
+      if (chunk & 1) swrite_B(rb[1], 1); else swrite_B(rb[0], 0);
+      __syncthreads();
+      if (chunk + 1 < nchunks) {
+        gload_A(chunk + 1);
+        if (chunk & 1) gload_B(rb[0], chunk + 1, 0); else gload_B(rb[1], chunk + 1, 0);
+      }
+      compute(0, chunk & 1);
+    }
   }
 
   // ---------------------------------------------------------------- epilogue
