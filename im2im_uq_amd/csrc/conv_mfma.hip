@@ -72,7 +72,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   static_assert(MT >= 1 && NT >= 1 && M % (32 * WM) == 0 && BN % (32 * WN) == 0, "tile split");
   constexpr int A_ROUNDS = (HPX * PPR + 255) / 256;
   constexpr int B_ROUNDS = (BN * PPR + 255) / 256;
-  constexpr int A_BYTES = HPX * ROWB, B_BYTES = BN * ROWB;
+  // halo rows are padded by 96 B (bf16) so that the two image rows a 32-lane operand fetch spans land on disjoint
+  // bank groups: ds_read_b128 of the A fragments becomes conflict-free (it was 2-way for 16-wide, 3-way for 8-wide
+  // tiles; found by enumerating the hardware's 16-lane groups).
+  constexpr int HROWB = HWD * ROWB + (sizeof(T) == 2 ? 96 : 0);
+  constexpr int HIMGB = HH * HROWB;
+  constexpr int A_BYTES = TB * HIMGB, B_BYTES = BN * ROWB;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ldsA = smem;
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = (wm * MT + mt) * 32 + l31;
-    aoff[mt] = ((m / MI) * HPI + ((m % MI) / TW) * HWD + (m % TW)) * ROWB;
+    aoff[mt] = (m / MI) * HIMGB + ((m % MI) / TW) * HROWB + (m % TW) * ROWB;
   }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) boff[nt] = ((wn * NT + nt) * 32 + l31) * ROWB;
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     const int yy = y0 + pi / HWD - PAD, xx = x0 + pi % HWD - PAD;
     const bool ok = px < HPX && b0 + tb < a.B && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
     a_goff[i] = ok ? (((tb * a.H + yy) * a.W + xx) * a.Ci + part * EPP) : -1;
-    a_loff[i] = (px < HPX) ? px * ROWB + part * 16 : -1;
+    a_loff[i] = (px < HPX) ? tb * HIMGB + (pi / HWD) * HROWB + (pi % HWD) * ROWB + part * 16 : -1;
   }
 #pragma unroll
   for (int i = 0; i < B_ROUNDS; ++i) {
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         if (tap + 2 < 9) { if (set) gload_B(rb[1], chunk, tap + 2); else gload_B(rb[0], chunk, tap + 2); }
         else if (more) { if (set) gload_B(rb[1], chunk + 1, tap + 2 - 9); else gload_B(rb[0], chunk + 1, tap + 2 - 9); }
         if (tap == 6 && more) gload_A(chunk + 1);
-        compute(((tap / 3) * HWD + (tap % 3)) * ROWB, set);
+        compute((tap / 3) * HROWB + (tap % 3) * ROWB, set);
       }
     };
     for (int chunk = 0; chunk < nchunks; chunk += 2) {
@@ -454,6 +459,132 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
 }
 
+// bf16 3x3 wgrad, software-pipelined: one workgroup of 12 waves per CU = 2x2 (co, ci) quadrants x 3 tap groups
+// (kernel rows).  Each wave keeps only its 3 taps' accumulators (48 registers), so there is room to prefetch the
+// NEXT pixel tile into registers while the MFMAs of the current one run from LDS; the tile is then written to the
+// other LDS buffer and one barrier per tile separates the two.  (The single-buffered kernel above spends 63 % of
+// its wave cycles waiting on memory; SQ_WAIT_ANY, profiles/.)
+template <int TH, int TW>
+__global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
+  using T = bf16_t;
+  constexpr int NT = 768;
+  constexpr int HH = TH + 2, HWD = TW + 2, HPX = HH * HWD;
+  constexpr int M = TH * TW;
+  constexpr int CT = 64, EPP = 8, PPR = 8, PB = 192;
+  constexpr int A_BYTES = M * PB, B_BYTES = HPX * PB, BUF_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_ROUNDS = (M * PPR + NT - 1) / NT, B_ROUNDS = (HPX * PPR + NT - 1) / NT;
+  constexpr int KSTEPS = M / 16;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tg = wave >> 2;                          // tap group = kernel row kh
+  const int wco = (wave >> 1) & 1, wci = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ci_tiles = a.Ci / CT;
+  const int co0 = (blockIdx.x / ci_tiles) * CT, ci0 = (blockIdx.x % ci_tiles) * CT;
+  const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ dzg = reinterpret_cast<const T*>(a.dz);
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int q = lane & 15;
+  const int tr_col_b = (((lane >> 4) & 1) * 16 + (q & 3) * 4) * 2;
+  const int tr_row = q >> 2;
+
+  // staging pieces of this thread (tile-independent parts)
+  int a_px[A_ROUNDS], a_part[A_ROUNDS], b_px[B_ROUNDS], b_part[B_ROUNDS];
+#pragma unroll
+  for (int i = 0; i < A_ROUNDS; ++i) { const int p = i * NT + tid; a_px[i] = (p < M * PPR) ? p / PPR : -1; a_part[i] = p % PPR; }
+#pragma unroll
+  for (int i = 0; i < B_ROUNDS; ++i) { const int p = i * NT + tid; b_px[i] = (p < HPX * PPR) ? p / PPR : -1; b_part[i] = p % PPR; }
+  uint4 ra[A_ROUNDS], rb[B_ROUNDS];
+
+  auto gload = [&](int t) {
+    int tt = t;
+    const int tx_id = tt % a.tilesX; tt /= a.tilesX;
+    const int ty_id = tt % a.tilesY;
+    const int b = tt / a.tilesY;
+    const int y0 = ty_id * TH, x0 = tx_id * TW;
+    const T* xb = xg + (size_t)b * a.H * a.W * a.Ci + ci0;
+    const T* dzb = dzg + (size_t)b * a.H * a.W * a.Co + co0;
+#pragma unroll
+    for (int i = 0; i < A_ROUNDS; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (a_px[i] >= 0) {
+        const int yy = y0 + a_px[i] / TW, xx = x0 + a_px[i] % TW;
+        if (yy < a.H && xx < a.W && co0 + a_part[i] * EPP < a.Co)
+          v = *reinterpret_cast<const uint4*>(dzb + ((size_t)yy * a.W + xx) * a.Co + a_part[i] * EPP);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_ROUNDS; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (b_px[i] >= 0) {
+        const int yy = y0 + b_px[i] / HWD - 1, xx = x0 + b_px[i] % HWD - 1;
+        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
+          v = *reinterpret_cast<const uint4*>(xb + ((size_t)yy * a.W + xx) * a.Ci + b_part[i] * EPP);
+      }
+      rb[i] = v;
+    }
+  };
+  auto swrite = [&](int buf) {
+    char* la = smem + buf * BUF_BYTES;
+    char* lb = la + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_ROUNDS; ++i) if (a_px[i] >= 0) *reinterpret_cast<uint4*>(la + a_px[i] * PB + a_part[i] * 16) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_ROUNDS; ++i) if (b_px[i] >= 0) *reinterpret_cast<uint4*>(lb + b_px[i] * PB + b_part[i] * 16) = rb[i];
+  };
+  auto compute = [&](int buf) {
+    const char* la = smem + buf * BUF_BYTES;
+    const char* lb = la + A_BYTES + tg * HWD * PB;           // this wave's kernel row
+#pragma unroll 2
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int m0 = ks * 16 + half * 8 + tr_row, m1 = m0 + 4;
+      const short8 fa = WFrag<bf16_t>::load(la + m0 * PB + wco * 64 + tr_col_b, la + m1 * PB + wco * 64 + tr_col_b);
+      const int h0 = ((m0 / TW) * HWD + (m0 % TW)) * PB + wci * 64 + tr_col_b;
+      const int h1 = ((m1 / TW) * HWD + (m1 % TW)) * PB + wci * 64 + tr_col_b;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const short8 fb = WFrag<bf16_t>::load(lb + h0 + kw * PB, lb + h1 + kw * PB);
+        acc[kw] = WFrag<bf16_t>::mfma(fa, fb, acc[kw]);
+      }
+    }
+  };
+
+  const int t_begin = blockIdx.y * a.tiles_per_split;
+  const int t_end = min(t_begin + a.tiles_per_split, a.ntiles);
+  if (t_begin < t_end) {
+    gload(t_begin);
+    swrite(0);
+    __syncthreads();
+    int cur = 0;
+    for (int t = t_begin; t < t_end; ++t) {
+      const bool more = t + 1 < t_end;
+      if (more) gload(t + 1);                          // in flight during the MFMAs below
+      compute(cur);
+      if (more) swrite(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  float* out = a.partial + (size_t)blockIdx.y * a.Co * 9 * a.Ci;
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int ci = ci0 + wci * 32 + l31;
+      if (co < a.Co) out[((size_t)co * 9 + tg * 3 + kw) * a.Ci + ci] = acc[kw][r];
+    }
+}
+
 // sum partial[nsplit][Co][TAPS][Ci] over splits and write torch layout dw[Co][Ci][TAPS]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int Co, int Ci,
                                                             int taps, float* __restrict__ dw) {
@@ -493,7 +624,7 @@ int launch_conv(const ConvArgs& a_in, hipStream_t stream) {
   a.tilesX = (int)cdiv(a.W, TW);
   constexpr int PAD = (TAPS == 9) ? 1 : 0;
   constexpr int ROWB = 32 * (int)sizeof(T) + 16;
-  constexpr size_t smem_main = (size_t)(TB * (TH + 2 * PAD) * (TW + 2 * PAD) + 2 * BN) * ROWB;
+  constexpr size_t smem_main = (size_t)TB * (TH + 2 * PAD) * ((TW + 2 * PAD) * ROWB + (sizeof(T) == 2 ? 96 : 0)) + (size_t)2 * BN * ROWB;
   constexpr size_t smem_epi = (size_t)4 * (TB * TH * TW / WM) * ((BN / WN) * sizeof(T) + 16);   // 4 wave-private output tiles
   constexpr size_t smem = smem_main > smem_epi ? smem_main : smem_epi;
   static_assert(smem >= (size_t)WM * BN * 2 * 4, "stats scratch fits");
@@ -571,20 +702,32 @@ int launch_wgrad(const void* x, const void* dz, float* partial, int64_t partial_
   const size_t wsz = (size_t)Co * TAPS * Ci * sizeof(float);
   int64_t max_split = partial_bytes / (int64_t)wsz;
   if (max_split < 1) return fail_invalid("wgrad: workspace smaller than one weight-sized slab");
-  int64_t nsplit = cdiv(512, cblocks);
+  int64_t nsplit = cdiv((IS_BF16 && TAPS == 9) ? 256 : 512, cblocks);   // pipelined kernel: one workgroup per CU
   if (nsplit > a.ntiles) nsplit = a.ntiles;
   if (nsplit > max_split) nsplit = max_split;
   if (nsplit < 1) nsplit = 1;
   a.tiles_per_split = (int)cdiv(a.ntiles, nsplit);
   nsplit = cdiv(a.ntiles, a.tiles_per_split);
-  auto kern = conv_wgrad_kernel<T, TH, TW, TAPS>;
-  static bool attr_set = false;
-  if (!attr_set && smem > 64 * 1024) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
+  if constexpr (IS_BF16 && TAPS == 9) {
+    constexpr size_t smem2 = 2 * smem;                        // double-buffered tiles, one 12-wave workgroup per CU
+    auto kern = conv_wgrad_pipe_kernel<TH, TW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)cblocks, (unsigned)nsplit), dim3(768), smem2, stream, a);
+    if (int rc = check_launch("conv_wgrad_pipe_kernel")) return rc;
+  } else {
+    auto kern = conv_wgrad_kernel<T, TH, TW, TAPS>;
+    static bool attr_set = false;
+    if (!attr_set && smem > 64 * 1024) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)cblocks, (unsigned)nsplit), dim3(256), smem, stream, a);
+    if (int rc = check_launch("conv_wgrad_kernel")) return rc;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)cblocks, (unsigned)nsplit), dim3(256), smem, stream, a);
-  if (int rc = check_launch("conv_wgrad_kernel")) return rc;
   const size_t total = (size_t)Co * TAPS * Ci;
   int blocks = (int)std::min<size_t>(cdiv(total, 256), 4096);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, (int)nsplit, Co, Ci, TAPS, dw);
