@@ -30,14 +30,16 @@ class UNet(nn.Module):
         self.out = OutConv(64, self.n_channels_middle)
 
     def forward(self, x):
-        x1 = self.inc(x)
-        x2 = self.down1(x1)
-        x3 = self.down2(x2)
-        x4 = self.down3(x3)
-        x5 = self.down4(x4)
+        # lazy=True: between these blocks activations stay "pre-BatchNorm + (scale, shift)"; every consumer below is one
+        # of this package's kernels and applies BatchNorm+ReLU on the fly (see DoubleConv.forward)
+        x1 = self.inc(x, lazy=True)
+        x2 = self.down1(x1, lazy=True)
+        x3 = self.down2(x2, lazy=True)
+        x4 = self.down3(x3, lazy=True)
+        x5 = self.down4(x4, lazy=True)
 
-        x = self.up1(x5, x4)
-        x = self.up2(x, x3)
-        x = self.up3(x, x2)
-        x = self.up4(x, x1)
+        x = self.up1(x5, x4, lazy=True)
+        x = self.up2(x, x3, lazy=True)
+        x = self.up3(x, x2, lazy=True)
+        x = self.up4(x, x1, lazy=True)
         return self.out(x)

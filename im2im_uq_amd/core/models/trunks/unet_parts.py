@@ -41,14 +41,18 @@ class DoubleConv(nn.Module):
         )
         self.compute_dtype = None
 
-    def forward(self, x):
+    def forward(self, x, lazy=False):
+        """lazy=True (used between this package's own blocks): in training the result is a *lazy activation* -- it
+        holds the pre-BatchNorm conv output and the consumers (next conv / max-pool / upsample-concat / 1x1 conv
+        kernels) apply BatchNorm+ReLU while loading it, so the normalised tensor is never written to HBM.  The
+        default returns an ordinary tensor."""
         cdt = _cdt(self)
         for ci, bi in ((0, 1), (3, 4)):
             conv, bn = self.double_conv[ci], self.double_conv[bi]
             if self.training:
                 momentum = bn.momentum if bn.momentum is not None else 0.1
-                x = nn_ops.ConvBnReluTrain.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
-                                                 bn.running_var, momentum, bn.eps, cdt)
+                x = nn_ops.conv_bn_relu_train(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
+                                              bn.running_var, momentum, bn.eps, cdt, lazy_out=(lazy or ci == 0))
                 bn.num_batches_tracked += 1
             else:
                 if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad and False):
@@ -60,7 +64,7 @@ class DoubleConv(nn.Module):
 
 class _MaxPool2(nn.Module):
     def forward(self, x):
-        return nn_ops.MaxPool2.apply(x)
+        return nn_ops.MaxPool2.apply(x)          # accepts lazy activations
 
 
 class Down(nn.Module):
@@ -73,8 +77,8 @@ class Down(nn.Module):
             DoubleConv(in_channels, out_channels)
         )
 
-    def forward(self, x):
-        return self.maxpool_conv(x)
+    def forward(self, x, lazy=False):
+        return self.maxpool_conv[1](self.maxpool_conv[0](x), lazy=lazy)
 
 
 class _BilinearUp(nn.Module):
@@ -97,10 +101,10 @@ class Up(nn.Module):
             raise NotImplementedError("bilinear=False (ConvTranspose2d upsampling) is not built yet; router.py and the "
                                       "experiment configs only ever use the bilinear default (SURVEY D2)")
 
-    def forward(self, x1, x2):
+    def forward(self, x1, x2, lazy=False):
         # x1: deep feature map, x2: skip connection.  upsample + zero-pad + cat([x2, x1]) in one kernel.
         x = nn_ops.UpsampleConcat.apply(x1, x2)
-        return self.conv(x)
+        return self.conv(x, lazy=lazy)
 
 
 class OutConv(nn.Module):

@@ -33,6 +33,8 @@ struct ConvArgs {
   float* stats;         // [mtiles][2][Co] or null
   int B, H, W, Ci, Co, tilesY, tilesX;
   int relu;             // apply ReLU after affine
+  const float* in_ss;   // [2][Ci] or null: x holds the producer's PRE-BatchNorm output z; the operand staging applies
+                        // a = max(z*scale + shift, 0) on the fly (the BatchNorm+ReLU pass is never materialised)
 };
 
 template <typename T> struct Frag;
@@ -83,6 +85,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   char* ldsA = smem;
   char* ldsB = smem + A_BYTES;                      // two weight buffers
   float* ldsS = reinterpret_cast<float*>(smem);     // stats scratch, re-uses A after the main loop
+  float* ldsSS = reinterpret_cast<float*>(smem + A_BYTES + 2 * B_BYTES);   // [2][Ci] input scale/shift (lazy BN+ReLU)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -152,7 +155,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
       ra[i] = v;
     }
   };
-  auto swrite_A = [&]() {
+  const bool lazy_in = a.in_ss != nullptr;
+  if (lazy_in) {
+    for (int i = tid; i < 2 * a.Ci; i += 256) ldsSS[i] = a.in_ss[i];
+    __syncthreads();
+  }
+  auto swrite_A = [&](int chunk) {
+    if (lazy_in) {
+      // this thread's pieces all cover the same EPP channels of the chunk: chunk*KC + (tid % PPR)*EPP ...
+      const int c0 = chunk * KC + (tid % PPR) * EPP;
+      float sc[EPP], sh[EPP];
+#pragma unroll
+      for (int k = 0; k < EPP; ++k) { sc[k] = ldsSS[c0 + k]; sh[k] = ldsSS[a.Ci + c0 + k]; }
+#pragma unroll
+      for (int i = 0; i < A_ROUNDS; ++i) {
+        if (a_goff[i] >= 0) {                        // padding / out-of-image pieces stay exactly zero
+          float v[EPP];
+          Vec16<T>::load(reinterpret_cast<const T*>(&ra[i]), v);
+#pragma unroll
+          for (int k = 0; k < EPP; ++k) v[k] = fmaxf(v[k] * sc[k] + sh[k], 0.f);
+          Vec16<T>::store(reinterpret_cast<T*>(&ra[i]), v);
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < A_ROUNDS; ++i)
       if ((HPX * PPR) % 256 == 0 || a_loff[i] >= 0) *reinterpret_cast<uint4*>(ldsA + a_loff[i]) = ra[i];
@@ -206,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         const int set = (P0 + tap) & 1;                // compile-time after unrolling
         if (tap == 0) {
           if (chunk) __syncthreads();                // everyone done reading the previous halo
-          swrite_A();
+          swrite_A(chunk);
         }
         if (set) swrite_B(rb[1], 1); else swrite_B(rb[0], 0);
         __syncthreads();
@@ -225,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     gload_B(rb[0], 0, 0);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
       if (chunk) __syncthreads();
-      swrite_A();
+      swrite_A(chunk);
       if (chunk & 1) swrite_B(rb[1], 1); else swrite_B(rb[0], 0);
       __syncthreads();
       if (chunk + 1 < nchunks) {
@@ -323,6 +348,7 @@ struct WgradArgs {
   const void* dz;    // [B][H][W][Co] T
   float* partial;    // [nsplit][Co][TAPS][Ci] fp32
   int B, H, W, Ci, Co, tilesY, tilesX, ntiles, tiles_per_split;
+  const float* x_ss; // [2][Ci] or null: x is the producer's pre-BatchNorm z; staging applies max(z*scale+shift, 0)
 };
 
 template <typename T> struct WFrag;
@@ -413,8 +439,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       const int px = p / PPR, part = p % PPR;
       const int yy = y0 + px / HWD - PAD, xx = x0 + px % HWD - PAD;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (px < HPX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
+      if (px < HPX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
         v = *reinterpret_cast<const uint4*>(xb + ((size_t)yy * a.W + xx) * a.Ci + ci0 + part * EPP);
+        if (a.x_ss) {
+          float f[EPP];
+          Vec16<T>::load(reinterpret_cast<const T*>(&v), f);
+#pragma unroll
+          for (int k = 0; k < EPP; ++k) f[k] = fmaxf(f[k] * a.x_ss[ci0 + part * EPP + k] + a.x_ss[a.Ci + ci0 + part * EPP + k], 0.f);
+          Vec16<T>::store(reinterpret_cast<T*>(&v), f);
+        }
+      }
       if (px < HPX) *reinterpret_cast<uint4*>(ldsB + px * PB + part * 16) = v;
     }
     __syncthreads();
@@ -503,6 +537,13 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
 #pragma unroll
   for (int i = 0; i < B_ROUNDS; ++i) { const int p = i * NT + tid; b_px[i] = (p < HPX * PPR) ? p / PPR : -1; b_part[i] = p % PPR; }
   uint4 ra[A_ROUNDS], rb[B_ROUNDS];
+  unsigned b_valid = 0;                              // bit i: rb[i] holds real pixels (not zero padding)
+  float xsc[EPP], xsh[EPP];                          // this thread's pieces always cover channels ci0 + (tid % 8)*8 ...
+  const bool lazy_x = a.x_ss != nullptr;
+  if (lazy_x) {
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) { xsc[k] = a.x_ss[ci0 + (tid % PPR) * EPP + k]; xsh[k] = a.x_ss[a.Ci + ci0 + (tid % PPR) * EPP + k]; }
+  }
 
   auto gload = [&](int t) {
     int tt = t;
@@ -522,13 +563,16 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
       }
       ra[i] = v;
     }
+    b_valid = 0;
 #pragma unroll
     for (int i = 0; i < B_ROUNDS; ++i) {
       uint4 v = make_uint4(0, 0, 0, 0);
       if (b_px[i] >= 0) {
         const int yy = y0 + b_px[i] / HWD - 1, xx = x0 + b_px[i] % HWD - 1;
-        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
+        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
           v = *reinterpret_cast<const uint4*>(xb + ((size_t)yy * a.W + xx) * a.Ci + b_part[i] * EPP);
+          b_valid |= 1u << i;
+        }
       }
       rb[i] = v;
     }
@@ -539,7 +583,19 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < A_ROUNDS; ++i) if (a_px[i] >= 0) *reinterpret_cast<uint4*>(la + a_px[i] * PB + a_part[i] * 16) = ra[i];
 #pragma unroll
-    for (int i = 0; i < B_ROUNDS; ++i) if (b_px[i] >= 0) *reinterpret_cast<uint4*>(lb + b_px[i] * PB + b_part[i] * 16) = rb[i];
+    for (int i = 0; i < B_ROUNDS; ++i) {
+      if (b_px[i] >= 0) {
+        uint4 v = rb[i];
+        if (lazy_x && ((b_valid >> i) & 1)) {
+          float f[EPP];
+          Vec16<T>::load(reinterpret_cast<const T*>(&v), f);
+#pragma unroll
+          for (int k = 0; k < EPP; ++k) f[k] = fmaxf(f[k] * xsc[k] + xsh[k], 0.f);
+          Vec16<T>::store(reinterpret_cast<T*>(&v), f);
+        }
+        *reinterpret_cast<uint4*>(lb + b_px[i] * PB + b_part[i] * 16) = v;
+      }
+    }
   };
   auto compute = [&](int buf) {
     const char* la = smem + buf * BUF_BYTES;
@@ -626,13 +682,14 @@ int launch_conv(const ConvArgs& a_in, hipStream_t stream) {
   constexpr int ROWB = 32 * (int)sizeof(T) + 16;
   constexpr size_t smem_main = (size_t)TB * (TH + 2 * PAD) * ((TW + 2 * PAD) * ROWB + (sizeof(T) == 2 ? 96 : 0)) + (size_t)2 * BN * ROWB;
   constexpr size_t smem_epi = (size_t)4 * (TB * TH * TW / WM) * ((BN / WN) * sizeof(T) + 16);   // 4 wave-private output tiles
-  constexpr size_t smem = smem_main > smem_epi ? smem_main : smem_epi;
-  static_assert(smem >= (size_t)WM * BN * 2 * 4, "stats scratch fits");
+  const size_t smem_in = smem_main + (a.in_ss ? (size_t)2 * a.Ci * sizeof(float) : 0);
+  const size_t smem = smem_in > smem_epi ? smem_in : smem_epi;
+  static_assert(smem_epi >= (size_t)WM * BN * 2 * 4, "stats scratch fits");
   auto kern = conv_igemm_kernel<T, TB, TH, TW, BN, WM, WN, TAPS>;
-  static bool attr_set = false;
-  if (!attr_set && smem > 64 * 1024) {
+  static size_t attr_set = 0;
+  if (smem > 64 * 1024 && smem > attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
+    attr_set = smem;
   }
   dim3 grid((unsigned)((size_t)cdiv(a.B, TB) * a.tilesY * a.tilesX), (unsigned)(a.Co / BN));
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, a);
@@ -671,9 +728,9 @@ extern "C" int64_t im2im_conv_stats_rows(int32_t B, int32_t H, int32_t W, int32_
   return im2im::cdiv(B, t.tb) * im2im::cdiv(H, t.th) * im2im::cdiv(W, t.tw);
 }
 
-extern "C" int im2im_conv_fwd(const void* x, const void* w, const float* bias, const float* scale, const float* shift,
-                              void* y, float* stats, int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co,
-                              int32_t taps, int32_t relu, int32_t dtype, im2im_stream_t stream_) {
+extern "C" int im2im_conv_fwd(const void* x, const float* in_scale_shift, const void* w, const float* bias, const float* scale,
+                              const float* shift, void* y, float* stats, int32_t B, int32_t H, int32_t W, int32_t Ci,
+                              int32_t Co, int32_t taps, int32_t relu, int32_t dtype, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(x && w && y);
   IM2IM_REQUIRE(B > 0 && H > 0 && W > 0);
@@ -682,21 +739,22 @@ extern "C" int im2im_conv_fwd(const void* x, const void* w, const float* bias, c
   IM2IM_REQUIRE(taps == 9 || taps == 1);
   IM2IM_REQUIRE(dtype == IM2IM_F32 || dtype == IM2IM_BF16);
   IM2IM_REQUIRE((scale == nullptr) == (shift == nullptr));
-  ConvArgs a{x, w, bias, scale, shift, y, stats, B, H, W, Ci, Co, 0, 0, relu};
+  IM2IM_REQUIRE(Ci <= 2048);
+  ConvArgs a{x, w, bias, scale, shift, y, stats, B, H, W, Ci, Co, 0, 0, relu, in_scale_shift};
   if (dtype == IM2IM_BF16) return taps == 9 ? dispatch_conv<bf16_t, 9>(a, stream) : dispatch_conv<bf16_t, 1>(a, stream);
   return taps == 9 ? dispatch_conv<float, 9>(a, stream) : dispatch_conv<float, 1>(a, stream);
 }
 
 namespace {
 template <typename T, int TAPS>
-int launch_wgrad(const void* x, const void* dz, float* partial, int64_t partial_bytes, float* dw, int B, int H, int W,
-                 int Ci, int Co, hipStream_t stream) {
+int launch_wgrad(const void* x, const float* x_ss, const void* dz, float* partial, int64_t partial_bytes, float* dw, int B,
+                 int H, int W, int Ci, int Co, hipStream_t stream) {
   constexpr int TH = 8, TW = 16;
   constexpr int PAD = (TAPS == 9) ? 1 : 0;
   constexpr bool IS_BF16 = sizeof(T) == 2;
   constexpr int PB = IS_BF16 ? 192 : 272;
   constexpr size_t smem = (size_t)(TH * TW + (TH + 2 * PAD) * (TW + 2 * PAD)) * PB;
-  WgradArgs a{x, dz, partial, B, H, W, Ci, Co, (int)cdiv(H, TH), (int)cdiv(W, TW), 0, 0};
+  WgradArgs a{x, dz, partial, B, H, W, Ci, Co, (int)cdiv(H, TH), (int)cdiv(W, TW), 0, 0, x_ss};
   a.ntiles = B * a.tilesY * a.tilesX;
   const int cblocks = (int)cdiv(Co, 64) * (Ci / 64);
   const size_t wsz = (size_t)Co * TAPS * Ci * sizeof(float);
@@ -745,7 +803,8 @@ extern "C" int64_t im2im_conv_wgrad_workspace_bytes(int32_t B, int32_t H, int32_
   return nsplit * (int64_t)Co * taps * Ci * (int64_t)sizeof(float);
 }
 
-extern "C" int im2im_conv_wgrad(const void* x, const void* dz, float* dw, void* workspace, int64_t workspace_bytes,
+extern "C" int im2im_conv_wgrad(const void* x, const float* x_scale_shift, const void* dz, float* dw, void* workspace,
+                                int64_t workspace_bytes,
                                 int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t taps, int32_t dtype,
                                 im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -757,10 +816,10 @@ extern "C" int im2im_conv_wgrad(const void* x, const void* dz, float* dw, void* 
   IM2IM_REQUIRE(dtype == IM2IM_F32 || dtype == IM2IM_BF16);
   float* partial = reinterpret_cast<float*>(workspace);
   if (dtype == IM2IM_BF16)
-    return taps == 9 ? launch_wgrad<bf16_t, 9>(x, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream)
-                     : launch_wgrad<bf16_t, 1>(x, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream);
-  return taps == 9 ? launch_wgrad<float, 9>(x, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream)
-                   : launch_wgrad<float, 1>(x, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream);
+    return taps == 9 ? launch_wgrad<bf16_t, 9>(x, x_scale_shift, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream)
+                     : launch_wgrad<bf16_t, 1>(x, x_scale_shift, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream);
+  return taps == 9 ? launch_wgrad<float, 9>(x, x_scale_shift, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream)
+                   : launch_wgrad<float, 1>(x, x_scale_shift, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream);
 }
 
 extern "C" int im2im_pack_conv_weight(const float* w, int32_t Co, int32_t Ci, int32_t taps, int32_t dtype, void* wf,

@@ -19,10 +19,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
                                                            float momentum, float eps, float* __restrict__ mean_invstd,
                                                            float* __restrict__ scale_shift) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  // one wave per channel: lane i holds split-row i (S <= 64), fixed-order butterfly -> deterministic
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (c >= C) return;
-  double s = 0.0, sq = 0.0;
-  for (int i = 0; i < S; ++i) { s += tmp[((size_t)i * 2 + 0) * C + c]; sq += tmp[((size_t)i * 2 + 1) * C + c]; }
+  double s = (lane < S) ? tmp[((size_t)lane * 2 + 0) * C + c] : 0.0;
+  double sq = (lane < S) ? tmp[((size_t)lane * 2 + 1) * C + c] : 0.0;
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); sq += __shfl_xor(sq, off, 64); }
+  if (lane != 0) return;
   const double mean = s / count;
   double var = sq / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -118,10 +122,13 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ tmp, int S, int C, double count,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                float* __restrict__ coef) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int i = 0; i < S; ++i) { s1 += tmp[((size_t)i * 2 + 0) * C + c]; s2 += tmp[((size_t)i * 2 + 1) * C + c]; }
+  double s1 = (lane < S) ? tmp[((size_t)lane * 2 + 0) * C + c] : 0.0;
+  double s2 = (lane < S) ? tmp[((size_t)lane * 2 + 1) * C + c] : 0.0;
+  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+  if (lane != 0) return;
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
   coef[c] = (float)(s1 / count);
@@ -194,11 +201,27 @@ __global__ __launch_bounds__(256) void sum_final_kernel(const double* __restrict
   out[k] = (float)s;
 }
 
+// lazy BatchNorm+ReLU of a producer whose normalised output was never materialised: v <- max(v*scale+shift, 0)
+template <int N>
+__device__ __forceinline__ void lazy_act(float (&v)[N], const float* __restrict__ ss, int C, int c0) {
+  if (ss) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k] * ss[c0 + k] + ss[C + c0 + k], 0.f);
+  }
+}
+// values as the consumer sees them after the storage round-trip (bf16 mode: the lazily computed activation is rounded
+// exactly like the materialised one would have been)
+template <typename T, int N>
+__device__ __forceinline__ void round_store_type(float (&v)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = to_float(from_float<T>(v[k]));
+}
+
 // ------------------------------------------------------------------------------------------------
 // MaxPool2d(2) (unet_parts.py:34), NHWC.  Ties keep the first maximum in (h, w) scan order, as torch.
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W,
-                                                            int C) {
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, const float* __restrict__ ss,
+                                                            T* __restrict__ y, int B, int H, int W, int C) {
   constexpr int N = Vec16<T>::N;
   const int Ho = H / 2, Wo = W / 2, vpr = C / N;
   const int64_t total = (int64_t)B * Ho * Wo * vpr;
@@ -214,6 +237,7 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
     Vec16<T>::load(p + C, v01);
     Vec16<T>::load(p + (int64_t)W * C, v10);
     Vec16<T>::load(p + (int64_t)W * C + C, v11);
+    lazy_act<N>(v00, ss, C, cv * N); lazy_act<N>(v01, ss, C, cv * N); lazy_act<N>(v10, ss, C, cv * N); lazy_act<N>(v11, ss, C, cv * N);
 #pragma unroll
     for (int k = 0; k < N; ++k) o[k] = fmaxf(fmaxf(v00[k], v01[k]), fmaxf(v10[k], v11[k]));
     Vec16<T>::store(y + i * N, o);
@@ -221,8 +245,9 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                            T* __restrict__ dx, int B, int H, int W, int C) {
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ x, const float* __restrict__ ss,
+                                                            const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W,
+                                                            int C) {
   constexpr int N = Vec16<T>::N;
   const int Ho = H / 2, Wo = W / 2, vpr = C / N;
   // one thread per INPUT 2x2 window position incl. the dropped odd row/col (gets zeros)
@@ -244,6 +269,10 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
       Vec16<T>::load(x + base + C, v[1]);
       Vec16<T>::load(x + base + (int64_t)W * C, v[2]);
       Vec16<T>::load(x + base + (int64_t)W * C + C, v[3]);
+      if (ss) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { lazy_act<N>(v[q], ss, C, cv * N); round_store_type<T, N>(v[q]); }
+      }
       Vec16<T>::load(dy + (((b * Ho + yo) * Wo + xo) * (int64_t)C) + cv * N, g);
 #pragma unroll
       for (int k = 0; k < N; ++k) {
@@ -283,7 +312,8 @@ __device__ __forceinline__ void bilinear_src(int dst, int in_size, int out_size,
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ deep, const T* __restrict__ skip,
+__global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ deep, const float* __restrict__ deep_ss,
+                                                         const T* __restrict__ skip, const float* __restrict__ skip_ss,
                                                          T* __restrict__ out, int B, int h, int w, int Cd, int H, int W,
                                                          int Cs) {
   constexpr int N = Vec16<T>::N;
@@ -297,8 +327,15 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ de
     const int y = (int)(r % H);
     const int64_t b = r / H;
     if (cv < vs) {
-      *reinterpret_cast<uint4*>(out + i * N) =
-          *reinterpret_cast<const uint4*>(skip + (((b * H + y) * W + x) * (int64_t)Cs) + cv * N);
+      const T* sp = skip + (((b * H + y) * W + x) * (int64_t)Cs) + cv * N;
+      if (skip_ss) {
+        float v[N];
+        Vec16<T>::load(sp, v);
+        lazy_act<N>(v, skip_ss, Cs, cv * N);
+        Vec16<T>::store(out + i * N, v);
+      } else {
+        *reinterpret_cast<uint4*>(out + i * N) = *reinterpret_cast<const uint4*>(sp);
+      }
       continue;
     }
     float o[N];
@@ -316,6 +353,10 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ de
       Vec16<T>::load(deep + (((b * h + y0) * w + x1) * (int64_t)Cd) + c, v01);
       Vec16<T>::load(deep + (((b * h + y1) * w + x0) * (int64_t)Cd) + c, v10);
       Vec16<T>::load(deep + (((b * h + y1) * w + x1) * (int64_t)Cd) + c, v11);
+      if (deep_ss) {
+        lazy_act<N>(v00, deep_ss, Cd, c); lazy_act<N>(v01, deep_ss, Cd, c); lazy_act<N>(v10, deep_ss, Cd, c); lazy_act<N>(v11, deep_ss, Cd, c);
+        round_store_type<T, N>(v00); round_store_type<T, N>(v01); round_store_type<T, N>(v10); round_store_type<T, N>(v11);
+      }
 #pragma unroll
       for (int k = 0; k < N; ++k) o[k] = ly0 * (lx0 * v00[k] + lx1 * v01[k]) + ly1 * (lx0 * v10[k] + lx1 * v11[k]);
     }
@@ -486,7 +527,7 @@ extern "C" int im2im_bn_finalize(const float* partial, int64_t R, int32_t C, int
   int rc;
   const int S = launch_reduce_stage1(partial, R, 2 * (int64_t)C, (double*)ws, stream, &rc);
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, stream, (const double*)ws, S, (int)C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, stream, (const double*)ws, S, (int)C,
                      (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean_invstd, scale_shift);
   return check_launch("bn_finalize_kernel");
 }
@@ -537,7 +578,7 @@ extern "C" int im2im_bn_relu_bwd(const void* da, const void* z, const float* sca
     int rc;
     const int S = launch_reduce_stage1(partial, cdiv(M, rpb), 2 * (int64_t)C, tmp, stream, &rc);
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, stream, (const double*)tmp, S, (int)C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, stream, (const double*)tmp, S, (int)C,
                        (double)M, dgamma, dbeta, coef);
     if (int rc2 = check_launch("bn_bwd_finalize_kernel")) return rc2;
     const int64_t nvec = M * C / Vec16<T>::N;
@@ -575,31 +616,32 @@ extern "C" int im2im_colsum(const void* x, float* out, int64_t M, int32_t C, int
   });
 }
 
-extern "C" int im2im_maxpool2_fwd(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype,
-                                  im2im_stream_t stream_) {
+extern "C" int im2im_maxpool2_fwd(const void* x, const float* in_scale_shift, void* y, int32_t B, int32_t H, int32_t W,
+                                  int32_t C, int32_t dtype, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(x && y && B > 0 && H >= 2 && W >= 2 && C > 0 && C % 8 == 0);
   return for_dtype(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
     const int64_t n = (int64_t)B * (H / 2) * (W / 2) * (C / Vec16<T>::N);
-    hipLaunchKernelGGL(maxpool2_fwd_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, stream, (const T*)x, (T*)y, B, H, W, C);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, stream, (const T*)x, in_scale_shift, (T*)y, B, H, W, C);
     return check_launch("maxpool2_fwd_kernel");
   });
 }
 
-extern "C" int im2im_maxpool2_bwd(const void* x, const void* dy, void* dx, int32_t B, int32_t H, int32_t W, int32_t C,
-                                  int32_t dtype, im2im_stream_t stream_) {
+extern "C" int im2im_maxpool2_bwd(const void* x, const float* in_scale_shift, const void* dy, void* dx, int32_t B, int32_t H,
+                                  int32_t W, int32_t C, int32_t dtype, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(x && dy && dx && B > 0 && H >= 2 && W >= 2 && C > 0 && C % 8 == 0);
   return for_dtype(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
     const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / Vec16<T>::N);
-    hipLaunchKernelGGL(maxpool2_bwd_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, stream, (const T*)x, (const T*)dy, (T*)dx, B, H, W, C);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, stream, (const T*)x, in_scale_shift, (const T*)dy, (T*)dx, B, H, W, C);
     return check_launch("maxpool2_bwd_kernel");
   });
 }
 
-extern "C" int im2im_upsample2x_concat_fwd(const void* deep, const void* skip, void* out, int32_t B, int32_t h, int32_t w,
+extern "C" int im2im_upsample2x_concat_fwd(const void* deep, const float* deep_scale_shift, const void* skip,
+                                           const float* skip_scale_shift, void* out, int32_t B, int32_t h, int32_t w,
                                            int32_t Cd, int32_t H, int32_t W, int32_t Cs, int32_t dtype, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(deep && skip && out && B > 0 && h > 0 && w > 0 && H >= 2 * h && W >= 2 * w);
@@ -607,7 +649,7 @@ extern "C" int im2im_upsample2x_concat_fwd(const void* deep, const void* skip, v
   return for_dtype(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
     const int64_t n = (int64_t)B * H * W * ((Cs + Cd) / Vec16<T>::N);
-    hipLaunchKernelGGL(upcat_fwd_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, stream, (const T*)deep, (const T*)skip, (T*)out, B, h, w, Cd, H, W, Cs);
+    hipLaunchKernelGGL(upcat_fwd_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, stream, (const T*)deep, deep_scale_shift, (const T*)skip, skip_scale_shift, (T*)out, B, h, w, Cd, H, W, Cs);
     return check_launch("upcat_fwd_kernel");
   });
 }

@@ -7,7 +7,7 @@
 
 namespace im2im {
 
-constexpr int REDUCE_MAX_S = 64;
+constexpr int REDUCE_MAX_S = 64;   // must stay <= 64: the finalize kernels give one lane to each split row
 
 inline int reduce_splits(int64_t R) {
   int64_t s = cdiv(R, 16);

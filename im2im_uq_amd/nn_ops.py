@@ -117,8 +117,9 @@ def pack_weight(w: torch.Tensor, dtype, want_wd=True):
     return wf, wd
 
 
-def conv_fwd(x, wf, bias=None, scale_shift=None, relu=False, want_stats=False):
-    """x [B,H,W,Ci], wf [Co,taps,Ci] -> y [B,H,W,Co] (+ stats [R,2,Co])."""
+def conv_fwd(x, wf, bias=None, scale_shift=None, relu=False, want_stats=False, in_ss=None):
+    """x [B,H,W,Ci], wf [Co,taps,Ci] -> y [B,H,W,Co] (+ stats [R,2,Co]).  in_ss [2,Ci]: x is a producer's pre-BN z and
+    the kernel applies max(z*scale+shift, 0) while staging it (lazy BatchNorm+ReLU)."""
     b, h, w_, ci = x.shape
     co, taps = wf.shape[0], wf.shape[1]
     y = torch.empty((b, h, w_, co), dtype=x.dtype, device=x.device)
@@ -130,15 +131,15 @@ def conv_fwd(x, wf, bias=None, scale_shift=None, relu=False, want_stats=False):
     if scale_shift is not None:
         sc, sh = scale_shift[0], scale_shift[1]
     ev = TIMER.wrap(_tile_name("igemm", h, w_, co, taps, x.dtype), 2.0 * b * h * w_ * co * ci * taps, x.device) if TIMER else None
-    check(lib.im2im_conv_fwd(dptr(x), dptr(wf), dptr(bias), dptr(sc), dptr(sh), dptr(y), dptr(stats), b, h, w_, ci, co, taps,
-                             int(relu), _DT[x.dtype], stream_ptr(x.device)), "im2im_conv_fwd")
+    check(lib.im2im_conv_fwd(dptr(x), dptr(in_ss), dptr(wf), dptr(bias), dptr(sc), dptr(sh), dptr(y), dptr(stats), b, h, w_, ci, co,
+                             taps, int(relu), _DT[x.dtype], stream_ptr(x.device)), "im2im_conv_fwd")
     if ev is not None:
         ev.record(torch.cuda.current_stream(x.device))
     return (y, stats) if want_stats else y
 
 
-def conv_wgrad(x, dz, taps):
-    """x [B,H,W,Ci], dz [B,H,W,Co] -> dw [Co,Ci,taps] fp32."""
+def conv_wgrad(x, dz, taps, x_ss=None):
+    """x [B,H,W,Ci], dz [B,H,W,Co] -> dw [Co,Ci,taps] fp32 (x_ss: lazy BatchNorm+ReLU of x, as in conv_fwd)."""
     b, h, w_, ci = x.shape
     co = dz.shape[3]
     nbytes = lib.im2im_conv_wgrad_workspace_bytes(b, h, w_, ci, co, taps)
@@ -147,7 +148,7 @@ def conv_wgrad(x, dz, taps):
     ws = _Scratch.get(nbytes, x.device)
     dw = torch.empty((co, ci, taps), dtype=F32, device=x.device)
     ev = TIMER.wrap(_tile_name("wgrad", h, w_, co, taps, x.dtype), 2.0 * b * h * w_ * co * ci * taps, x.device) if TIMER else None
-    check(lib.im2im_conv_wgrad(dptr(x), dptr(dz), dptr(dw), dptr(ws), ws.numel(), b, h, w_, ci, co, taps, _DT[x.dtype],
+    check(lib.im2im_conv_wgrad(dptr(x), dptr(x_ss), dptr(dz), dptr(dw), dptr(ws), ws.numel(), b, h, w_, ci, co, taps, _DT[x.dtype],
                                stream_ptr(x.device)), "im2im_conv_wgrad")
     if ev is not None:
         ev.record(torch.cuda.current_stream(x.device))
@@ -237,12 +238,21 @@ def smallconv_wgrad(s_nchw, l_nhwc, l_major, want_bias):
 
 
 # ----------------------------------------------------------------------------------------- autograd
-class ConvBnReluTrain(torch.autograd.Function):
-    """conv3x3(pad 1, bias) -> BatchNorm2d(batch statistics) -> ReLU  (unet_parts.py:16-18 / 19-21), train mode.
+LAZY_ATTR = "_im2im_lazy_ss"
 
-    The conv epilogue emits the per-channel partial sums, so BatchNorm statistics cost no extra pass over
-    the activation.  The conv bias shifts the batch mean and cancels in the normalised output, so its
-    gradient is identically zero here (the reference's autograd produces rounding noise around zero)."""
+
+def lazy_ss(x):
+    """scale/shift [2,C] of a *lazy activation*: a tensor that physically holds the pre-BatchNorm conv output z and
+    stands for a = relu(z*scale + shift).  Only the HIP consumers in this module understand it (they apply the
+    transform while staging their operand); anything else must call materialize()."""
+    return getattr(x, LAZY_ATTR, None)
+
+
+class ConvStats(torch.autograd.Function):
+    """conv3x3(pad 1, bias) with BatchNorm batch statistics from the conv epilogue (unet_parts.py:16-17 / 19-20).
+    Returns the pre-BN output z plus the BatchNorm coefficients; the normalisation itself is applied lazily by the
+    consumers (BnReluLazy below carries its gradient).  The conv bias shifts the batch mean and cancels in the
+    normalised output, so its gradient is identically zero here (the reference's autograd yields rounding noise)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, cdt):
@@ -250,6 +260,7 @@ class ConvBnReluTrain(torch.autograd.Function):
         co, ci = weight.shape[0], weight.shape[1]
         small = ci <= 8
         b, _, h, w_ = x.shape
+        in_ss = lazy_ss(x)
         if small:
             xin = x.detach().to(F32).contiguous()
             _, wd = pack_weight(weight, F32)
@@ -258,28 +269,72 @@ class ConvBnReluTrain(torch.autograd.Function):
         else:
             xin = nhwc(x.detach(), cdt)
             wf, wd = pack_weight(weight, cdt)
-            z, stats = conv_fwd(xin, wf, bias.detach(), want_stats=True)
+            z, stats = conv_fwd(xin, wf, bias.detach(), want_stats=True, in_ss=in_ss)
         mean_invstd, scale_shift = bn_finalize(stats, b * h * w_, gamma.detach(), beta.detach(), running_mean, running_var,
                                                momentum, eps)
-        a = bn_relu_apply(z, scale_shift)
         ctx.small = small
-        ctx.save_for_backward(xin, z, scale_shift, mean_invstd, wd if wd is not None else torch.empty(0), bias)
-        return nchw(a)
+        ctx.has_in_ss = in_ss is not None
+        ctx.save_for_backward(xin, wd if wd is not None else torch.empty(0), in_ss if in_ss is not None else torch.empty(0))
+        zz = nchw(z)
+        ctx.mark_non_differentiable(scale_shift, mean_invstd)
+        return zz, scale_shift, mean_invstd
 
     @staticmethod
-    def backward(ctx, da):
-        xin, z, scale_shift, mean_invstd, wd, bias = ctx.saved_tensors
-        da = nhwc(da, z.dtype)
-        dz, dgamma, dbeta = bn_relu_bwd(da, z, scale_shift, mean_invstd)
+    def backward(ctx, dz, _g1, _g2):
+        xin, wd, in_ss = ctx.saved_tensors
+        in_ss = in_ss if ctx.has_in_ss else None
+        dz = nhwc(dz, xin.dtype if not ctx.small else dz.dtype)
         dx = None
         if ctx.small:
             dw, _ = smallconv_wgrad(xin, dz, l_major=True, want_bias=False)
             dw = dw.view(dz.shape[3], xin.shape[1], 3, 3)
         else:
-            dw = conv_wgrad(xin, dz, 9).view(dz.shape[3], xin.shape[3], 3, 3)
+            dw = conv_wgrad(xin, dz, 9, x_ss=in_ss).view(dz.shape[3], xin.shape[3], 3, 3)
             if ctx.needs_input_grad[0]:
-                dx = nchw(conv_fwd(dz, wd))
-        return dx, dw, torch.zeros_like(bias), dgamma, dbeta, None, None, None, None, None
+                dx = nchw(conv_fwd(dz, wd))               # gradient w.r.t. the (lazy) input activation
+        return dx, dw, None, None, None, None, None, None, None, None
+
+
+class BnReluLazy(torch.autograd.Function):
+    """a = relu(BatchNorm_train(z)) WITHOUT materialising a: forward returns an alias of z tagged with the BatchNorm
+    scale/shift; backward is the full BatchNorm+ReLU backward (dz, dgamma, dbeta) from the summed gradient of all
+    consumers (unet_parts.py:17-18 / 20-21)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, scale_shift, mean_invstd):
+        ctx.save_for_backward(z, scale_shift, mean_invstd)
+        return z.detach().view_as(z)
+
+    @staticmethod
+    def backward(ctx, da):
+        z, scale_shift, mean_invstd = ctx.saved_tensors
+        zz = nhwc(z)
+        dz, dgamma, dbeta = bn_relu_bwd(nhwc(da, zz.dtype), zz, scale_shift, mean_invstd)
+        return nchw(dz), dgamma, dbeta, None, None
+
+
+class Materialize(torch.autograd.Function):
+    """turn a lazy activation into a plain tensor (one BatchNorm+ReLU pass); identity for the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, scale_shift):
+        return nchw(bn_relu_apply(nhwc(x.detach()), scale_shift))
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def materialize(x):
+    ss = lazy_ss(x)
+    return x if ss is None else Materialize.apply(x, ss)
+
+
+def conv_bn_relu_train(x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, cdt, lazy_out=False):
+    z, scale_shift, mean_invstd = ConvStats.apply(x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, cdt)
+    a = BnReluLazy.apply(z, gamma, beta, scale_shift, mean_invstd)
+    setattr(a, LAZY_ATTR, scale_shift)
+    return a if lazy_out else materialize(a)
 
 
 def conv_bn_relu_eval(x, weight, bias, gamma, beta, running_mean, running_var, eps, cdt, cache=None):
@@ -298,36 +353,42 @@ def conv_bn_relu_eval(x, weight, bias, gamma, beta, running_mean, running_var, e
 class MaxPool2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
+        ss = lazy_ss(x)
         xin = nhwc(x.detach())
         b, h, w_, c = xin.shape
         y = torch.empty((b, h // 2, w_ // 2, c), dtype=xin.dtype, device=xin.device)
-        check(lib.im2im_maxpool2_fwd(dptr(xin), dptr(y), b, h, w_, c, _DT[xin.dtype], stream_ptr(xin.device)), "im2im_maxpool2_fwd")
-        ctx.save_for_backward(xin)
+        check(lib.im2im_maxpool2_fwd(dptr(xin), dptr(ss), dptr(y), b, h, w_, c, _DT[xin.dtype], stream_ptr(xin.device)),
+              "im2im_maxpool2_fwd")
+        ctx.has_ss = ss is not None
+        ctx.save_for_backward(xin, ss if ss is not None else torch.empty(0))
         return nchw(y)
 
     @staticmethod
     def backward(ctx, dy):
-        (xin,) = ctx.saved_tensors
+        xin, ss = ctx.saved_tensors
+        ss = ss if ctx.has_ss else None
         dy = nhwc(dy, xin.dtype)
         b, h, w_, c = xin.shape
         dx = torch.empty_like(xin)
-        check(lib.im2im_maxpool2_bwd(dptr(xin), dptr(dy), dptr(dx), b, h, w_, c, _DT[xin.dtype], stream_ptr(xin.device)),
+        check(lib.im2im_maxpool2_bwd(dptr(xin), dptr(ss), dptr(dy), dptr(dx), b, h, w_, c, _DT[xin.dtype], stream_ptr(xin.device)),
               "im2im_maxpool2_bwd")
         return nchw(dx)
 
 
 class UpsampleConcat(torch.autograd.Function):
-    """cat([skip, zero_pad(bilinear x2 align_corners(deep))], dim=1)  (unet_parts.py:58-68) in one pass."""
+    """cat([skip, zero_pad(bilinear x2 align_corners(deep))], dim=1)  (unet_parts.py:58-68) in one pass; both inputs
+    may be lazy activations."""
 
     @staticmethod
     def forward(ctx, deep, skip):
+        dss, sss = lazy_ss(deep), lazy_ss(skip)
         d = nhwc(deep.detach())
         s = nhwc(skip.detach(), d.dtype)
         b, h, w_, cd = d.shape
         _, hh, ww, cs = s.shape
         out = torch.empty((b, hh, ww, cs + cd), dtype=d.dtype, device=d.device)
-        check(lib.im2im_upsample2x_concat_fwd(dptr(d), dptr(s), dptr(out), b, h, w_, cd, hh, ww, cs, _DT[d.dtype],
-                                              stream_ptr(d.device)), "im2im_upsample2x_concat_fwd")
+        check(lib.im2im_upsample2x_concat_fwd(dptr(d), dptr(dss), dptr(s), dptr(sss), dptr(out), b, h, w_, cd, hh, ww, cs,
+                                              _DT[d.dtype], stream_ptr(d.device)), "im2im_upsample2x_concat_fwd")
         ctx.shape = (b, h, w_, cd, hh, ww, cs)
         return nchw(out)
 
@@ -343,22 +404,25 @@ class UpsampleConcat(torch.autograd.Function):
 
 
 class Conv1x1(torch.autograd.Function):
-    """OutConv (unet_parts.py:87-94): 1x1 conv with bias on the MFMA kernel (taps = 1)."""
+    """OutConv (unet_parts.py:87-94): 1x1 conv with bias on the MFMA kernel (taps = 1); input may be lazy."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, cdt):
+        ss = lazy_ss(x)
         xin = nhwc(x.detach(), cdt)
         wf, wd = pack_weight(weight, cdt)
-        y = conv_fwd(xin, wf, bias.detach())
-        ctx.save_for_backward(xin, wd)
+        y = conv_fwd(xin, wf, bias.detach(), in_ss=ss)
+        ctx.has_ss = ss is not None
+        ctx.save_for_backward(xin, wd, ss if ss is not None else torch.empty(0))
         return nchw(y)
 
     @staticmethod
     def backward(ctx, dy):
-        xin, wd = ctx.saved_tensors
+        xin, wd, ss = ctx.saved_tensors
+        ss = ss if ctx.has_ss else None
         dy = nhwc(dy, xin.dtype)
         dx = nchw(conv_fwd(dy, wd)) if ctx.needs_input_grad[0] else None
-        dw = conv_wgrad(xin, dy, 1).view(dy.shape[3], xin.shape[3], 1, 1)
+        dw = conv_wgrad(xin, dy, 1, x_ss=ss).view(dy.shape[3], xin.shape[3], 1, 1)
         return dx, dw, colsum(dy), None
 
 

@@ -101,20 +101,24 @@ int im2im_pack_conv_weight(const float* w, int32_t Co, int32_t Ci, int32_t taps,
  *   BatchNorm, unet_parts.py:17,20);  relu != 0: v = max(v,0) (unet_parts.py:18,21)
  *   stats (may be NULL): [rows][2][Co] fp32 per-tile partial sums and sums of squares of the STORED
  *   values over valid pixels, rows = im2im_conv_stats_rows(B,H,W,Co): train-mode BatchNorm statistics
- *   without re-reading y.  dgrad uses the same entry point with x = dz and wf = wd. */
+ *   without re-reading y.  dgrad uses the same entry point with x = dz and wf = wd.
+ *   in_scale_shift (may be NULL): fp32 [2][Ci].  When given, x holds the PRE-BatchNorm output z of the producing
+ *   layer and every consumer applies a = max(z*scale + shift, 0) while staging its operand ("lazy" BatchNorm+ReLU,
+ *   unet_parts.py:17-18): the normalised activation is never written to HBM.  Same option on im2im_conv_wgrad
+ *   (x_scale_shift), im2im_maxpool2_* (in_scale_shift) and im2im_upsample2x_concat_fwd (deep/skip_scale_shift). */
 int64_t im2im_conv_stats_rows(int32_t B, int32_t H, int32_t W, int32_t Co);
-int im2im_conv_fwd(const void* x, const void* wf, const float* bias, const float* scale,
-                   const float* shift, void* y, float* stats, int32_t B, int32_t H, int32_t W,
-                   int32_t Ci, int32_t Co, int32_t taps, int32_t relu, int32_t dtype,
-                   im2im_stream_t stream);
+int im2im_conv_fwd(const void* x, const float* in_scale_shift, const void* wf, const float* bias,
+                   const float* scale, const float* shift, void* y, float* stats, int32_t B,
+                   int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t taps, int32_t relu,
+                   int32_t dtype, im2im_stream_t stream);
 
 /* dw[co][ci][tap] (fp32, torch layout) = sum_{b,h,w} dz[b,h,w,co] * x[b,h+kh-1,w+kw-1,ci]
  *   Ci % 64 == 0, Co % 32 == 0.  workspace: im2im_conv_wgrad_workspace_bytes(...) bytes (split-K slabs,
  *   reduced deterministically). */
 int64_t im2im_conv_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t taps);
-int im2im_conv_wgrad(const void* x, const void* dz, float* dw, void* workspace, int64_t workspace_bytes,
-                     int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t taps,
-                     int32_t dtype, im2im_stream_t stream);
+int im2im_conv_wgrad(const void* x, const float* x_scale_shift, const void* dz, float* dw, void* workspace,
+                     int64_t workspace_bytes, int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                     int32_t taps, int32_t dtype, im2im_stream_t stream);
 
 
 /* Shared scratch for the deterministic two-stage "sum over pixels" reductions: bytes needed to reduce
@@ -154,16 +158,17 @@ int im2im_colsum(const void* x, float* out, int64_t M, int32_t C, int32_t dtype,
                  int64_t ws_bytes, im2im_stream_t stream);
 
 /* MaxPool2d(2) (unet_parts.py:34), NHWC; ties keep the first maximum in (h,w) order. */
-int im2im_maxpool2_fwd(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C,
-                       int32_t dtype, im2im_stream_t stream);
-int im2im_maxpool2_bwd(const void* x, const void* dy, void* dx, int32_t B, int32_t H, int32_t W,
+int im2im_maxpool2_fwd(const void* x, const float* in_scale_shift, void* y, int32_t B, int32_t H, int32_t W,
                        int32_t C, int32_t dtype, im2im_stream_t stream);
+int im2im_maxpool2_bwd(const void* x, const float* in_scale_shift, const void* dy, void* dx, int32_t B,
+                       int32_t H, int32_t W, int32_t C, int32_t dtype, im2im_stream_t stream);
 
 /* Up-block input (unet_parts.py:58-68): out = cat([skip, zero_pad(bilinear_x2_align_corners(deep))])
  * on the channel axis, NHWC.  deep [B][h][w][Cd], skip [B][H][W][Cs], out [B][H][W][Cs+Cd], H >= 2h, W >= 2w.
  * bwd: dskip = dout[..., :Cs]; ddeep = transpose of the interpolation (gathered, no atomics). */
-int im2im_upsample2x_concat_fwd(const void* deep, const void* skip, void* out, int32_t B, int32_t h,
-                                int32_t w, int32_t Cd, int32_t H, int32_t W, int32_t Cs, int32_t dtype,
+int im2im_upsample2x_concat_fwd(const void* deep, const float* deep_scale_shift, const void* skip,
+                                const float* skip_scale_shift, void* out, int32_t B, int32_t h, int32_t w,
+                                int32_t Cd, int32_t H, int32_t W, int32_t Cs, int32_t dtype,
                                 im2im_stream_t stream);
 int im2im_upsample2x_concat_bwd(const void* dout, void* ddeep, void* dskip, int32_t B, int32_t h,
                                 int32_t w, int32_t Cd, int32_t H, int32_t W, int32_t Cs, int32_t dtype,

@@ -152,7 +152,7 @@ def test_backward_gradients_vs_oracle_fp32():
     from oracle import model as om
     model = build(1, "fp32")
     model.train()
-    x, y = om.det_images(3, 1, 32, 32, salt=5)
+    x, y = om.det_images(3, 1, 64, 64, salt=5)     # 64x64: 48 samples per channel at the bottleneck BatchNorm
     pred = model(x.to(DEV))
     loss = model.loss_fn(pred, y.to(DEV))
     loss.backward()
@@ -167,7 +167,7 @@ def test_backward_gradients_vs_oracle_fp32():
         ref = leaves[name].grad
         if ".double_conv.0.bias" in name or ".double_conv.3.bias" in name:
             # conv bias in front of train-mode BatchNorm: gradient is analytically zero; reference has fp noise
-            assert float(p.grad.abs().max()) == 0.0 and float(ref.abs().max()) < 1e-5
+            assert (p.grad is None or float(p.grad.abs().max()) == 0.0) and float(ref.abs().max()) < 1e-5
             continue
         worst[name] = rel_l2(p.grad.cpu(), ref)
     bad = {k: v for k, v in worst.items() if v > 2e-3}
@@ -275,3 +275,30 @@ def test_full_size_320_smoke_properties_bf16():
         lo, mid, hi = model.nested_sets_from_output(out, 1.0)
     assert out.shape == (2, 3, 1, 320, 320) and bool(torch.isfinite(out).all())
     assert bool((lo <= mid).all()) and bool((mid <= hi).all())
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_lazy_batchnorm_path_is_bit_identical_to_materialised(dt):
+    """UNet.forward keeps activations lazy (pre-BatchNorm z + scale/shift applied by the consumer kernels); chaining the
+    same blocks through their public, materialising forward must give bit-identical outputs and parameter gradients."""
+    from oracle import model as om
+    x, y = om.det_images(3, 1, 48, 48, salt=4)
+    res = []
+    for lazy in (True, False):
+        model = build(1, dt)
+        model.train()
+        u = model.baseModel
+        xin = x.to(DEV)
+        if lazy:
+            feat = u(xin)
+        else:
+            x1 = u.inc(xin); x2 = u.down1(x1); x3 = u.down2(x2); x4 = u.down3(x3); x5 = u.down4(x4)
+            h = u.up1(x5, x4); h = u.up2(h, x3); h = u.up3(h, x2); h = u.up4(h, x1)
+            feat = u.out(h)
+        pred = model.last_layer(feat)
+        loss = model.loss_fn(pred, y.to(DEV))
+        loss.backward()
+        res.append((pred.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0])
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], res[1][1][n]), n
