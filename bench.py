@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="per-GPU training batch")
+    ap.add_argument("--batch", type=int, default=78, help="per-GPU training batch (78 = the reference's fastMRI batch_size)")
     ap.add_argument("--calib-images", type=int, default=432, help="per-GPU calibration images (3474 / 8 ~ 434)")
     ap.add_argument("--size", type=int, default=320)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])

@@ -11,7 +11,7 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libim2im_uq.so")
+LIB_PATH = os.environ.get("IM2IM_LIB") or os.path.join(_PKG, "lib", "libim2im_uq.so")   # IM2IM_LIB: A/B builds (tools/)
 
 
 class Im2ImError(RuntimeError):

@@ -17,6 +17,9 @@
 // LDS rows are padded by 16 B so ds_read_b128 operand fetches are (nearly) conflict free.
 #include "common.h"
 #include "dtypes.h"
+#ifndef IM2IM_SETPRIO
+#define IM2IM_SETPRIO 0
+#endif
 #include <type_traits>
 
 namespace {
@@ -206,10 +209,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
       for (int mt = 0; mt < MT; ++mt) fa[mt] = Frag<T>::load(pa + aoff[mt], ks, half);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) fb[nt] = Frag<T>::load(pb + boff[nt], ks, half);
+#if IM2IM_SETPRIO
+      __builtin_amdgcn_s_setprio(1);               // the co-resident wave of the other workgroup is in its staging phase
+#endif
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Frag<T>::mfma(fa[mt], fb[nt], acc[mt][nt]);
+#if IM2IM_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
   };
 

@@ -274,6 +274,7 @@ class ConvStats(torch.autograd.Function):
                                                momentum, eps)
         ctx.small = small
         ctx.has_in_ss = in_ss is not None
+        ctx.set_materialize_grads(False)              # no zero tensors for the two non-differentiable outputs
         ctx.save_for_backward(xin, wd if wd is not None else torch.empty(0), in_ss if in_ss is not None else torch.empty(0))
         zz = nchw(z)
         ctx.mark_non_differentiable(scale_shift, mean_invstd)
