@@ -55,17 +55,28 @@ __global__ __launch_bounds__(256) void bn_fold_eval_kernel(const float* __restri
   scale_shift[C + c] = beta[c] + ((conv_bias ? conv_bias[c] : 0.f) - rm[c]) * sc;
 }
 
-// a = relu(z*scale + shift), [M][C]
+// a = relu(z*scale + shift), [M][C].  When C/N divides 256 every thread keeps ONE channel vector for the whole
+// grid-stride loop (no per-element integer division, scale/shift live in registers).
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict__ z, const float* __restrict__ scale_shift,
                                                              T* __restrict__ a, int64_t nvec, int C) {
   constexpr int N = Vec16<T>::N;
+  const int vpr = C / N;
+  const bool fixed = (256 % vpr) == 0;
+  int c0 = (int)((blockIdx.x * 256u + threadIdx.x) % (unsigned)vpr) * N;
+  float sc[N], sh[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) { sc[k] = scale_shift[c0 + k]; sh[k] = scale_shift[C + c0 + k]; }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-    const int c0 = (int)((i * N) % C);
+    if (!fixed) {
+      c0 = (int)(i % vpr) * N;
+#pragma unroll
+      for (int k = 0; k < N; ++k) { sc[k] = scale_shift[c0 + k]; sh[k] = scale_shift[C + c0 + k]; }
+    }
     float v[N];
     Vec16<T>::load(z + i * N, v);
 #pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k] * scale_shift[c0 + k] + scale_shift[C + c0 + k], 0.f);
+    for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k] * sc[k] + sh[k], 0.f);
     Vec16<T>::store(a + i * N, v);
   }
 }
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
   coef[C + c] = (float)(s2 / count);
 }
 
-// backward pass 2: dz = scale * (g - dbeta/M - xhat * dgamma/M)
+// backward pass 2: dz = scale * (g - dbeta/M - xhat * dgamma/M); per-thread channel vector as in bn_relu_apply
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restrict__ da, const T* __restrict__ z,
                                                                  const float* __restrict__ scale_shift,
@@ -143,18 +154,29 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restr
                                                                  const float* __restrict__ coef, T* __restrict__ dz,
                                                                  int64_t nvec, int C) {
   constexpr int N = Vec16<T>::N;
+  const int vpr = C / N;
+  const bool fixed = (256 % vpr) == 0;
+  int c0 = (int)((blockIdx.x * 256u + threadIdx.x) % (unsigned)vpr) * N;
+  float sc[N], sh[N], mu[N], is[N], k1[N], k2[N];
+  auto load_coef = [&]() {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      sc[k] = scale_shift[c0 + k]; sh[k] = scale_shift[C + c0 + k];
+      mu[k] = mean_invstd[c0 + k]; is[k] = mean_invstd[C + c0 + k];
+      k1[k] = coef[c0 + k]; k2[k] = coef[C + c0 + k];
+    }
+  };
+  load_coef();
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-    const int c0 = (int)((i * N) % C);
+    if (!fixed) { c0 = (int)(i % vpr) * N; load_coef(); }
     float g[N], zz[N], o[N];
     Vec16<T>::load(da + i * N, g);
     Vec16<T>::load(z + i * N, zz);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      const int c = c0 + k;
-      const float sc = scale_shift[c];
-      const float gg = (zz[k] * sc + scale_shift[C + c] > 0.f) ? g[k] : 0.f;
-      const float xhat = (zz[k] - mean_invstd[c]) * mean_invstd[C + c];
-      o[k] = sc * (gg - coef[c] - xhat * coef[C + c]);
+      const float gg = (zz[k] * sc[k] + sh[k] > 0.f) ? g[k] : 0.f;
+      const float xhat = (zz[k] - mu[k]) * is[k];
+      o[k] = sc[k] * (gg - k1[k] - xhat * k2[k]);
     }
     Vec16<T>::store(dz + i * N, o);
   }
@@ -219,81 +241,96 @@ __device__ __forceinline__ void round_store_type(float (&v)[N]) {
 
 // ------------------------------------------------------------------------------------------------
 // MaxPool2d(2) (unet_parts.py:34), NHWC.  Ties keep the first maximum in (h, w) scan order, as torch.
+// Index helper for the NHWC side kernels: blockIdx.y walks image rows (b, y), threads walk the row's 16-byte
+// vectors; vector index -> (x, channel vector) by shift/mask when C/N is a power of two (32-bit division otherwise).
+struct RowVec {
+  int vpr, vshift;
+  __device__ __forceinline__ void split(int idx, int& x, int& cv) const {
+    if (vshift >= 0) { x = idx >> vshift; cv = idx & (vpr - 1); }
+    else { x = (int)((unsigned)idx / (unsigned)vpr); cv = idx - x * vpr; }
+  }
+};
+inline RowVec make_rowvec(int vpr) {
+  int sh = -1;
+  if ((vpr & (vpr - 1)) == 0) { sh = 0; while ((1 << sh) < vpr) ++sh; }
+  return RowVec{vpr, sh};
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, const float* __restrict__ ss,
-                                                            T* __restrict__ y, int B, int H, int W, int C) {
+                                                            T* __restrict__ y, int B, int H, int W, int C, RowVec rv) {
   constexpr int N = Vec16<T>::N;
-  const int Ho = H / 2, Wo = W / 2, vpr = C / N;
-  const int64_t total = (int64_t)B * Ho * Wo * vpr;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % vpr);
-    int64_t r = i / vpr;
-    const int xo = (int)(r % Wo); r /= Wo;
-    const int yo = (int)(r % Ho);
-    const int64_t b = r / Ho;
-    const T* p = x + (((b * H + 2 * yo) * W + 2 * xo) * (int64_t)C) + cv * N;
-    float v00[N], v01[N], v10[N], v11[N], o[N];
-    Vec16<T>::load(p, v00);
-    Vec16<T>::load(p + C, v01);
-    Vec16<T>::load(p + (int64_t)W * C, v10);
-    Vec16<T>::load(p + (int64_t)W * C + C, v11);
-    lazy_act<N>(v00, ss, C, cv * N); lazy_act<N>(v01, ss, C, cv * N); lazy_act<N>(v10, ss, C, cv * N); lazy_act<N>(v11, ss, C, cv * N);
+  const int Ho = H / 2, Wo = W / 2;
+  const int rowvecs = Wo * rv.vpr;
+  for (int row = blockIdx.y; row < B * Ho; row += gridDim.y) {
+    const int b = row / Ho, yo = row - b * Ho;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < rowvecs; idx += gridDim.x * 256) {
+      int xo, cv;
+      rv.split(idx, xo, cv);
+      const T* p = x + ((((int64_t)b * H + 2 * yo) * W + 2 * xo) * (int64_t)C) + cv * N;
+      float v00[N], v01[N], v10[N], v11[N], o[N];
+      Vec16<T>::load(p, v00);
+      Vec16<T>::load(p + C, v01);
+      Vec16<T>::load(p + (int64_t)W * C, v10);
+      Vec16<T>::load(p + (int64_t)W * C + C, v11);
+      lazy_act<N>(v00, ss, C, cv * N); lazy_act<N>(v01, ss, C, cv * N); lazy_act<N>(v10, ss, C, cv * N); lazy_act<N>(v11, ss, C, cv * N);
 #pragma unroll
-    for (int k = 0; k < N; ++k) o[k] = fmaxf(fmaxf(v00[k], v01[k]), fmaxf(v10[k], v11[k]));
-    Vec16<T>::store(y + i * N, o);
+      for (int k = 0; k < N; ++k) o[k] = fmaxf(fmaxf(v00[k], v01[k]), fmaxf(v10[k], v11[k]));
+      Vec16<T>::store(y + (((int64_t)row * Wo + xo) * C) + cv * N, o);
+    }
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ x, const float* __restrict__ ss,
                                                             const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W,
-                                                            int C) {
+                                                            int C, RowVec rv) {
   constexpr int N = Vec16<T>::N;
-  const int Ho = H / 2, Wo = W / 2, vpr = C / N;
+  const int Ho = H / 2, Wo = W / 2;
   // one thread per INPUT 2x2 window position incl. the dropped odd row/col (gets zeros)
   const int Hc = (H + 1) / 2, Wc = (W + 1) / 2;
-  const int64_t total = (int64_t)B * Hc * Wc * vpr;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % vpr);
-    int64_t r = i / vpr;
-    const int xo = (int)(r % Wc); r /= Wc;
-    const int yo = (int)(r % Hc);
-    const int64_t b = r / Hc;
-    const int64_t base = (((b * H + 2 * yo) * W + 2 * xo) * (int64_t)C) + cv * N;
-    float z[N];
+  const int rowvecs = Wc * rv.vpr;
+  for (int row = blockIdx.y; row < B * Hc; row += gridDim.y) {
+    const int b = row / Hc, yo = row - b * Hc;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < rowvecs; idx += gridDim.x * 256) {
+      int xo, cv;
+      rv.split(idx, xo, cv);
+      const int64_t base = ((((int64_t)b * H + 2 * yo) * W + 2 * xo) * (int64_t)C) + cv * N;
+      float z[N];
 #pragma unroll
-    for (int k = 0; k < N; ++k) z[k] = 0.f;
-    if (yo < Ho && xo < Wo) {
-      float v[4][N], g[N], o[4][N];
-      Vec16<T>::load(x + base, v[0]);
-      Vec16<T>::load(x + base + C, v[1]);
-      Vec16<T>::load(x + base + (int64_t)W * C, v[2]);
-      Vec16<T>::load(x + base + (int64_t)W * C + C, v[3]);
-      if (ss) {
+      for (int k = 0; k < N; ++k) z[k] = 0.f;
+      if (yo < Ho && xo < Wo) {
+        float v[4][N], g[N], o[4][N];
+        Vec16<T>::load(x + base, v[0]);
+        Vec16<T>::load(x + base + C, v[1]);
+        Vec16<T>::load(x + base + (int64_t)W * C, v[2]);
+        Vec16<T>::load(x + base + (int64_t)W * C + C, v[3]);
+        if (ss) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { lazy_act<N>(v[q], ss, C, cv * N); round_store_type<T, N>(v[q]); }
-      }
-      Vec16<T>::load(dy + (((b * Ho + yo) * Wo + xo) * (int64_t)C) + cv * N, g);
-#pragma unroll
-      for (int k = 0; k < N; ++k) {
-        int am = 0; float m = v[0][k];
-        if (v[1][k] > m) { m = v[1][k]; am = 1; }
-        if (v[2][k] > m) { m = v[2][k]; am = 2; }
-        if (v[3][k] > m) { m = v[3][k]; am = 3; }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o[q][k] = (am == q) ? g[k] : 0.f;
-      }
-      Vec16<T>::store(dx + base, o[0]);
-      Vec16<T>::store(dx + base + C, o[1]);
-      Vec16<T>::store(dx + base + (int64_t)W * C, o[2]);
-      Vec16<T>::store(dx + base + (int64_t)W * C + C, o[3]);
-    } else {
-      // odd tail: positions not covered by any window
-      for (int dyy = 0; dyy < 2; ++dyy)
-        for (int dxx = 0; dxx < 2; ++dxx) {
-          const int yy = 2 * yo + dyy, xx = 2 * xo + dxx;
-          if (yy < H && xx < W) Vec16<T>::store(dx + (((b * H + yy) * W + xx) * (int64_t)C) + cv * N, z);
+          for (int q = 0; q < 4; ++q) { lazy_act<N>(v[q], ss, C, cv * N); round_store_type<T, N>(v[q]); }
         }
+        Vec16<T>::load(dy + ((((int64_t)b * Ho + yo) * Wo + xo) * (int64_t)C) + cv * N, g);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          int am = 0; float m = v[0][k];
+          if (v[1][k] > m) { m = v[1][k]; am = 1; }
+          if (v[2][k] > m) { m = v[2][k]; am = 2; }
+          if (v[3][k] > m) { m = v[3][k]; am = 3; }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q][k] = (am == q) ? g[k] : 0.f;
+        }
+        Vec16<T>::store(dx + base, o[0]);
+        Vec16<T>::store(dx + base + C, o[1]);
+        Vec16<T>::store(dx + base + (int64_t)W * C, o[2]);
+        Vec16<T>::store(dx + base + (int64_t)W * C + C, o[3]);
+      } else {
+        // odd tail: positions not covered by any window
+        for (int dyy = 0; dyy < 2; ++dyy)
+          for (int dxx = 0; dxx < 2; ++dxx) {
+            const int yy = 2 * yo + dyy, xx = 2 * xo + dxx;
+            if (yy < H && xx < W) Vec16<T>::store(dx + ((((int64_t)b * H + yy) * W + xx) * (int64_t)C) + cv * N, z);
+          }
+      }
     }
   }
 }
@@ -315,103 +352,124 @@ template <typename T>
 __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ deep, const float* __restrict__ deep_ss,
                                                          const T* __restrict__ skip, const float* __restrict__ skip_ss,
                                                          T* __restrict__ out, int B, int h, int w, int Cd, int H, int W,
-                                                         int Cs) {
+                                                         int Cs, RowVec rv) {
   constexpr int N = Vec16<T>::N;
-  const int Ct = Cs + Cd, vpr = Ct / N, vs = Cs / N;
+  const int Ct = Cs + Cd, vs = Cs / N;
   const int py = (H - 2 * h) / 2, px = (W - 2 * w) / 2;
-  const int64_t total = (int64_t)B * H * W * vpr;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % vpr);
-    int64_t r = i / vpr;
-    const int x = (int)(r % W); r /= W;
-    const int y = (int)(r % H);
-    const int64_t b = r / H;
-    if (cv < vs) {
-      const T* sp = skip + (((b * H + y) * W + x) * (int64_t)Cs) + cv * N;
-      if (skip_ss) {
-        float v[N];
-        Vec16<T>::load(sp, v);
-        lazy_act<N>(v, skip_ss, Cs, cv * N);
-        Vec16<T>::store(out + i * N, v);
+  const int rowvecs = W * rv.vpr;                              // rv.vpr = Ct / N
+  for (int row = blockIdx.y; row < B * H; row += gridDim.y) {
+    const int b = row / H, y = row - b * H;
+    const int uy = y - py;
+    const bool row_in = uy >= 0 && uy < 2 * h;
+    int y0 = 0, y1 = 0; float ly0 = 0.f, ly1 = 0.f;
+    if (row_in) bilinear_src(uy, h, 2 * h, y0, y1, ly0, ly1);
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < rowvecs; idx += gridDim.x * 256) {
+      int x, cv;
+      rv.split(idx, x, cv);
+      T* op = out + ((int64_t)row * W + x) * Ct + cv * N;
+      if (cv < vs) {
+        const T* sp = skip + (((int64_t)row * W + x) * (int64_t)Cs) + cv * N;
+        if (skip_ss) {
+          float v[N];
+          Vec16<T>::load(sp, v);
+          lazy_act<N>(v, skip_ss, Cs, cv * N);
+          Vec16<T>::store(op, v);
+        } else {
+          *reinterpret_cast<uint4*>(op) = *reinterpret_cast<const uint4*>(sp);
+        }
+        continue;
+      }
+      float o[N];
+      const int ux = x - px;
+      if (!row_in || ux < 0 || ux >= 2 * w) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) o[k] = 0.f;
       } else {
-        *reinterpret_cast<uint4*>(out + i * N) = *reinterpret_cast<const uint4*>(sp);
-      }
-      continue;
-    }
-    float o[N];
-    const int uy = y - py, ux = x - px;
-    if (uy < 0 || uy >= 2 * h || ux < 0 || ux >= 2 * w) {
+        int x0, x1; float lx0, lx1;
+        bilinear_src(ux, w, 2 * w, x0, x1, lx0, lx1);
+        const int c = (cv - vs) * N;
+        float v00[N], v01[N], v10[N], v11[N];
+        Vec16<T>::load(deep + ((((int64_t)b * h + y0) * w + x0) * (int64_t)Cd) + c, v00);
+        Vec16<T>::load(deep + ((((int64_t)b * h + y0) * w + x1) * (int64_t)Cd) + c, v01);
+        Vec16<T>::load(deep + ((((int64_t)b * h + y1) * w + x0) * (int64_t)Cd) + c, v10);
+        Vec16<T>::load(deep + ((((int64_t)b * h + y1) * w + x1) * (int64_t)Cd) + c, v11);
+        if (deep_ss) {
+          lazy_act<N>(v00, deep_ss, Cd, c); lazy_act<N>(v01, deep_ss, Cd, c); lazy_act<N>(v10, deep_ss, Cd, c); lazy_act<N>(v11, deep_ss, Cd, c);
+          round_store_type<T, N>(v00); round_store_type<T, N>(v01); round_store_type<T, N>(v10); round_store_type<T, N>(v11);
+        }
 #pragma unroll
-      for (int k = 0; k < N; ++k) o[k] = 0.f;
-    } else {
-      int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
-      bilinear_src(uy, h, 2 * h, y0, y1, ly0, ly1);
-      bilinear_src(ux, w, 2 * w, x0, x1, lx0, lx1);
-      const int c = (cv - vs) * N;
-      float v00[N], v01[N], v10[N], v11[N];
-      Vec16<T>::load(deep + (((b * h + y0) * w + x0) * (int64_t)Cd) + c, v00);
-      Vec16<T>::load(deep + (((b * h + y0) * w + x1) * (int64_t)Cd) + c, v01);
-      Vec16<T>::load(deep + (((b * h + y1) * w + x0) * (int64_t)Cd) + c, v10);
-      Vec16<T>::load(deep + (((b * h + y1) * w + x1) * (int64_t)Cd) + c, v11);
-      if (deep_ss) {
-        lazy_act<N>(v00, deep_ss, Cd, c); lazy_act<N>(v01, deep_ss, Cd, c); lazy_act<N>(v10, deep_ss, Cd, c); lazy_act<N>(v11, deep_ss, Cd, c);
-        round_store_type<T, N>(v00); round_store_type<T, N>(v01); round_store_type<T, N>(v10); round_store_type<T, N>(v11);
+        for (int k = 0; k < N; ++k) o[k] = ly0 * (lx0 * v00[k] + lx1 * v01[k]) + ly1 * (lx0 * v10[k] + lx1 * v11[k]);
       }
-#pragma unroll
-      for (int k = 0; k < N; ++k) o[k] = ly0 * (lx0 * v00[k] + lx1 * v01[k]) + ly1 * (lx0 * v10[k] + lx1 * v11[k]);
+      Vec16<T>::store(op, o);
     }
-    Vec16<T>::store(out + i * N, o);
   }
 }
 
-// backward: dskip = dout[..., :Cs] (copy), ddeep gathered (deterministic, no atomics)
+// backward: dskip = dout[..., :Cs] (copy), ddeep gathered (deterministic, no atomics).
+// grid.y walks the H skip rows then the h deep rows of every image.
 template <typename T>
 __global__ __launch_bounds__(256) void upcat_bwd_kernel(const T* __restrict__ dout, T* __restrict__ ddeep,
                                                          T* __restrict__ dskip, int B, int h, int w, int Cd, int H, int W,
-                                                         int Cs) {
+                                                         int Cs, RowVec rvs, RowVec rvd) {
   constexpr int N = Vec16<T>::N;
-  const int Ct = Cs + Cd, vs = Cs / N, vd = Cd / N;
+  const int Ct = Cs + Cd;
   const int py = (H - 2 * h) / 2, px = (W - 2 * w) / 2;
-  const int64_t n_skip = (int64_t)B * H * W * vs, n_deep = (int64_t)B * h * w * vd;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_skip + n_deep; i += (int64_t)gridDim.x * 256) {
-    if (i < n_skip) {
-      const int cv = (int)(i % vs);
-      const int64_t pix = i / vs;
-      *reinterpret_cast<uint4*>(dskip + i * N) = *reinterpret_cast<const uint4*>(dout + pix * Ct + cv * N);
+  const int rows_skip = B * H, rows_deep = B * h;
+  for (int row = blockIdx.y; row < rows_skip + rows_deep; row += gridDim.y) {
+    if (row < rows_skip) {
+      const int rowvecs = W * rvs.vpr;
+      for (int idx = blockIdx.x * 256 + threadIdx.x; idx < rowvecs; idx += gridDim.x * 256) {
+        int x, cv;
+        rvs.split(idx, x, cv);
+        const int64_t pix = (int64_t)row * W + x;
+        *reinterpret_cast<uint4*>(dskip + pix * Cs + cv * N) = *reinterpret_cast<const uint4*>(dout + pix * Ct + cv * N);
+      }
       continue;
     }
-    const int64_t j = i - n_skip;
-    const int cv = (int)(j % vd);
-    int64_t r = j / vd;
-    const int xi = (int)(r % w); r /= w;
-    const int yi = (int)(r % h);
-    const int64_t b = r / h;
-    float acc[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) acc[k] = 0.f;
+    const int r = row - rows_skip;
+    const int b = r / h, yi = r - b * h;
     // output rows whose source index pair can contain yi: uy in [2*yi-2, 2*yi+3]
-    for (int uy = max(0, 2 * yi - 2); uy <= min(2 * h - 1, 2 * yi + 3); ++uy) {
-      int y0, y1; float ly0, ly1;
-      bilinear_src(uy, h, 2 * h, y0, y1, ly0, ly1);
-      const float wy = (y0 == yi ? ly0 : 0.f) + (y1 == yi ? ly1 : 0.f);
-      if (wy == 0.f) continue;
-      const int y = uy + py;
-      if (y < 0 || y >= H) continue;
-      for (int ux = max(0, 2 * xi - 2); ux <= min(2 * w - 1, 2 * xi + 3); ++ux) {
+    float wy[6]; int ys[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      const int uy = 2 * yi - 2 + t;
+      wy[t] = 0.f; ys[t] = -1;
+      if (uy >= 0 && uy <= 2 * h - 1) {
+        int y0, y1; float ly0, ly1;
+        bilinear_src(uy, h, 2 * h, y0, y1, ly0, ly1);
+        wy[t] = (y0 == yi ? ly0 : 0.f) + (y1 == yi ? ly1 : 0.f);
+        const int y = uy + py;
+        if (wy[t] != 0.f && y >= 0 && y < H) ys[t] = y;
+      }
+    }
+    const int rowvecs = w * rvd.vpr;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < rowvecs; idx += gridDim.x * 256) {
+      int xi, cv;
+      rvd.split(idx, xi, cv);
+      float acc[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc[k] = 0.f;
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int ux = 2 * xi - 2 + u;
+        if (ux < 0 || ux > 2 * w - 1) continue;
         int x0, x1; float lx0, lx1;
         bilinear_src(ux, w, 2 * w, x0, x1, lx0, lx1);
         const float wx = (x0 == xi ? lx0 : 0.f) + (x1 == xi ? lx1 : 0.f);
-        if (wx == 0.f) continue;
         const int x = ux + px;
-        if (x < 0 || x >= W) continue;
-        float g[N];
-        Vec16<T>::load(dout + (((b * H + y) * W + x) * (int64_t)Ct) + Cs + cv * N, g);
-        const float ww = wy * wx;
+        if (wx == 0.f || x < 0 || x >= W) continue;
 #pragma unroll
-        for (int k = 0; k < N; ++k) acc[k] += ww * g[k];
+        for (int t = 0; t < 6; ++t) {
+          if (ys[t] < 0) continue;
+          float g[N];
+          Vec16<T>::load(dout + ((((int64_t)b * H + ys[t]) * W + x) * (int64_t)Ct) + Cs + cv * N, g);
+          const float ww = wy[t] * wx;
+#pragma unroll
+          for (int k = 0; k < N; ++k) acc[k] += ww * g[k];
+        }
       }
+      Vec16<T>::store(ddeep + (((int64_t)r * w + xi) * (int64_t)Cd) + cv * N, acc);
     }
-    Vec16<T>::store(ddeep + j * N, acc);
   }
 }
 
@@ -510,6 +568,15 @@ template <typename F> int for_dtype(int dtype, F f) {
   if (dtype == IM2IM_BF16) return f((bf16_t*)nullptr);
   if (dtype == IM2IM_F32) return f((float*)nullptr);
   return fail_invalid("dtype");
+}
+inline dim3 row_grid(int rowvecs, int64_t rows) {
+  int gx = (int)cdiv(rowvecs, 256);
+  if (gx > 64) gx = 64;
+  if (gx < 1) gx = 1;
+  int64_t gy = rows;
+  if (gy > 65535) gy = 65535;
+  if (gy < 1) gy = 1;
+  return dim3((unsigned)gx, (unsigned)gy);
 }
 inline int ew_blocks(int64_t n) { int64_t b = cdiv(n, 256); if (b > 256 * 32) b = 256 * 32; if (b < 1) b = 1; return (int)b; }
 
@@ -622,8 +689,8 @@ extern "C" int im2im_maxpool2_fwd(const void* x, const float* in_scale_shift, vo
   IM2IM_REQUIRE(x && y && B > 0 && H >= 2 && W >= 2 && C > 0 && C % 8 == 0);
   return for_dtype(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
-    const int64_t n = (int64_t)B * (H / 2) * (W / 2) * (C / Vec16<T>::N);
-    hipLaunchKernelGGL(maxpool2_fwd_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, stream, (const T*)x, in_scale_shift, (T*)y, B, H, W, C);
+    const RowVec rv = make_rowvec(C / Vec16<T>::N);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel<T>, row_grid((W / 2) * rv.vpr, B * (H / 2)), dim3(256), 0, stream, (const T*)x, in_scale_shift, (T*)y, B, H, W, C, rv);
     return check_launch("maxpool2_fwd_kernel");
   });
 }
@@ -634,8 +701,8 @@ extern "C" int im2im_maxpool2_bwd(const void* x, const float* in_scale_shift, co
   IM2IM_REQUIRE(x && dy && dx && B > 0 && H >= 2 && W >= 2 && C > 0 && C % 8 == 0);
   return for_dtype(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
-    const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / Vec16<T>::N);
-    hipLaunchKernelGGL(maxpool2_bwd_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, stream, (const T*)x, in_scale_shift, (const T*)dy, (T*)dx, B, H, W, C);
+    const RowVec rv = make_rowvec(C / Vec16<T>::N);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<T>, row_grid(((W + 1) / 2) * rv.vpr, B * ((H + 1) / 2)), dim3(256), 0, stream, (const T*)x, in_scale_shift, (const T*)dy, (T*)dx, B, H, W, C, rv);
     return check_launch("maxpool2_bwd_kernel");
   });
 }
@@ -648,8 +715,8 @@ extern "C" int im2im_upsample2x_concat_fwd(const void* deep, const float* deep_s
   IM2IM_REQUIRE(Cd > 0 && Cs > 0 && Cd % 8 == 0 && Cs % 8 == 0);
   return for_dtype(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
-    const int64_t n = (int64_t)B * H * W * ((Cs + Cd) / Vec16<T>::N);
-    hipLaunchKernelGGL(upcat_fwd_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, stream, (const T*)deep, deep_scale_shift, (const T*)skip, skip_scale_shift, (T*)out, B, h, w, Cd, H, W, Cs);
+    const RowVec rv = make_rowvec((Cs + Cd) / Vec16<T>::N);
+    hipLaunchKernelGGL(upcat_fwd_kernel<T>, row_grid(W * rv.vpr, B * H), dim3(256), 0, stream, (const T*)deep, deep_scale_shift, (const T*)skip, skip_scale_shift, (T*)out, B, h, w, Cd, H, W, Cs, rv);
     return check_launch("upcat_fwd_kernel");
   });
 }
@@ -661,8 +728,8 @@ extern "C" int im2im_upsample2x_concat_bwd(const void* dout, void* ddeep, void* 
   IM2IM_REQUIRE(Cd > 0 && Cs > 0 && Cd % 8 == 0 && Cs % 8 == 0);
   return for_dtype(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
-    const int64_t n = (int64_t)B * H * W * (Cs / Vec16<T>::N) + (int64_t)B * h * w * (Cd / Vec16<T>::N);
-    hipLaunchKernelGGL(upcat_bwd_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, stream, (const T*)dout, (T*)ddeep, (T*)dskip, B, h, w, Cd, H, W, Cs);
+    const RowVec rvs = make_rowvec(Cs / Vec16<T>::N), rvd = make_rowvec(Cd / Vec16<T>::N);
+    hipLaunchKernelGGL(upcat_bwd_kernel<T>, row_grid(W * rvs.vpr, B * H + B * h), dim3(256), 0, stream, (const T*)dout, (T*)ddeep, (T*)dskip, B, h, w, Cd, H, W, Cs, rvs, rvd);
     return check_launch("upcat_bwd_kernel");
   });
 }
