@@ -225,12 +225,27 @@ __global__ __launch_bounds__(256) void sum_final_kernel(const double* __restrict
 
 // lazy BatchNorm+ReLU of a producer whose normalised output was never materialised: v <- max(v*scale+shift, 0)
 template <int N>
-__device__ __forceinline__ void lazy_act(float (&v)[N], const float* __restrict__ ss, int C, int c0) {
-  if (ss) {
+struct LazySS {                       // N scale and N shift values of one channel vector, fetched with 16-byte loads
+  float sc[N], sh[N];
+  bool on;
+  __device__ __forceinline__ LazySS(const float* __restrict__ ss, int C, int c0) : on(ss != nullptr) {
+    if (on) {
 #pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k] * ss[c0 + k] + ss[C + c0 + k], 0.f);
+      for (int k = 0; k < N; k += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(ss + c0 + k);
+        const float4 b = *reinterpret_cast<const float4*>(ss + C + c0 + k);
+        sc[k] = a.x; sc[k + 1] = a.y; sc[k + 2] = a.z; sc[k + 3] = a.w;
+        sh[k] = b.x; sh[k + 1] = b.y; sh[k + 2] = b.z; sh[k + 3] = b.w;
+      }
+    }
   }
-}
+  __device__ __forceinline__ void apply(float (&v)[N]) const {
+    if (on) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k] * sc[k] + sh[k], 0.f);
+    }
+  }
+};
 // values as the consumer sees them after the storage round-trip (bf16 mode: the lazily computed activation is rounded
 // exactly like the materialised one would have been)
 template <typename T, int N>
@@ -273,7 +288,8 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
       Vec16<T>::load(p + C, v01);
       Vec16<T>::load(p + (int64_t)W * C, v10);
       Vec16<T>::load(p + (int64_t)W * C + C, v11);
-      lazy_act<N>(v00, ss, C, cv * N); lazy_act<N>(v01, ss, C, cv * N); lazy_act<N>(v10, ss, C, cv * N); lazy_act<N>(v11, ss, C, cv * N);
+      const LazySS<N> lz(ss, C, cv * N);
+      lz.apply(v00); lz.apply(v01); lz.apply(v10); lz.apply(v11);
 #pragma unroll
       for (int k = 0; k < N; ++k) o[k] = fmaxf(fmaxf(v00[k], v01[k]), fmaxf(v10[k], v11[k]));
       Vec16<T>::store(y + (((int64_t)row * Wo + xo) * C) + cv * N, o);
@@ -306,8 +322,9 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
         Vec16<T>::load(x + base + (int64_t)W * C, v[2]);
         Vec16<T>::load(x + base + (int64_t)W * C + C, v[3]);
         if (ss) {
+          const LazySS<N> lz(ss, C, cv * N);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { lazy_act<N>(v[q], ss, C, cv * N); round_store_type<T, N>(v[q]); }
+          for (int q = 0; q < 4; ++q) { lz.apply(v[q]); round_store_type<T, N>(v[q]); }
         }
         Vec16<T>::load(dy + ((((int64_t)b * Ho + yo) * Wo + xo) * (int64_t)C) + cv * N, g);
 #pragma unroll
@@ -352,11 +369,34 @@ template <typename T>
 __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ deep, const float* __restrict__ deep_ss,
                                                          const T* __restrict__ skip, const float* __restrict__ skip_ss,
                                                          T* __restrict__ out, int B, int h, int w, int Cd, int H, int W,
-                                                         int Cs, RowVec rv) {
+                                                         int Cs, RowVec rvs, RowVec rvd) {
   constexpr int N = Vec16<T>::N;
-  const int Ct = Cs + Cd, vs = Cs / N;
+  const int Ct = Cs + Cd;
   const int py = (H - 2 * h) / 2, px = (W - 2 * w) / 2;
-  const int rowvecs = W * rv.vpr;                              // rv.vpr = Ct / N
+  // blockIdx.z == 0: the skip half (copy / lazy activation); == 1: the upsampled half.  Waves are uniform in work.
+  if (blockIdx.z == 0) {
+    const int rowvecs = W * rvs.vpr;
+    for (int row = blockIdx.y; row < B * H; row += gridDim.y) {
+      for (int idx = blockIdx.x * 256 + threadIdx.x; idx < rowvecs; idx += gridDim.x * 256) {
+        int x, cv;
+        rvs.split(idx, x, cv);
+        const int64_t pix = (int64_t)row * W + x;
+        const T* sp = skip + pix * Cs + cv * N;
+        T* op = out + pix * Ct + cv * N;
+        if (skip_ss) {
+          float v[N];
+          Vec16<T>::load(sp, v);
+          const LazySS<N> lz(skip_ss, Cs, cv * N);
+          lz.apply(v);
+          Vec16<T>::store(op, v);
+        } else {
+          *reinterpret_cast<uint4*>(op) = *reinterpret_cast<const uint4*>(sp);
+        }
+      }
+    }
+    return;
+  }
+  const int rowvecs = W * rvd.vpr;
   for (int row = blockIdx.y; row < B * H; row += gridDim.y) {
     const int b = row / H, y = row - b * H;
     const int uy = y - py;
@@ -365,20 +405,8 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ de
     if (row_in) bilinear_src(uy, h, 2 * h, y0, y1, ly0, ly1);
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < rowvecs; idx += gridDim.x * 256) {
       int x, cv;
-      rv.split(idx, x, cv);
-      T* op = out + ((int64_t)row * W + x) * Ct + cv * N;
-      if (cv < vs) {
-        const T* sp = skip + (((int64_t)row * W + x) * (int64_t)Cs) + cv * N;
-        if (skip_ss) {
-          float v[N];
-          Vec16<T>::load(sp, v);
-          lazy_act<N>(v, skip_ss, Cs, cv * N);
-          Vec16<T>::store(op, v);
-        } else {
-          *reinterpret_cast<uint4*>(op) = *reinterpret_cast<const uint4*>(sp);
-        }
-        continue;
-      }
+      rvd.split(idx, x, cv);
+      T* op = out + ((int64_t)row * W + x) * Ct + Cs + cv * N;
       float o[N];
       const int ux = x - px;
       if (!row_in || ux < 0 || ux >= 2 * w) {
@@ -387,14 +415,15 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ de
       } else {
         int x0, x1; float lx0, lx1;
         bilinear_src(ux, w, 2 * w, x0, x1, lx0, lx1);
-        const int c = (cv - vs) * N;
+        const int c = cv * N;
         float v00[N], v01[N], v10[N], v11[N];
         Vec16<T>::load(deep + ((((int64_t)b * h + y0) * w + x0) * (int64_t)Cd) + c, v00);
         Vec16<T>::load(deep + ((((int64_t)b * h + y0) * w + x1) * (int64_t)Cd) + c, v01);
         Vec16<T>::load(deep + ((((int64_t)b * h + y1) * w + x0) * (int64_t)Cd) + c, v10);
         Vec16<T>::load(deep + ((((int64_t)b * h + y1) * w + x1) * (int64_t)Cd) + c, v11);
         if (deep_ss) {
-          lazy_act<N>(v00, deep_ss, Cd, c); lazy_act<N>(v01, deep_ss, Cd, c); lazy_act<N>(v10, deep_ss, Cd, c); lazy_act<N>(v11, deep_ss, Cd, c);
+          const LazySS<N> lz(deep_ss, Cd, c);
+          lz.apply(v00); lz.apply(v01); lz.apply(v10); lz.apply(v11);
           round_store_type<T, N>(v00); round_store_type<T, N>(v01); round_store_type<T, N>(v10); round_store_type<T, N>(v11);
         }
 #pragma unroll
@@ -715,8 +744,10 @@ extern "C" int im2im_upsample2x_concat_fwd(const void* deep, const float* deep_s
   IM2IM_REQUIRE(Cd > 0 && Cs > 0 && Cd % 8 == 0 && Cs % 8 == 0);
   return for_dtype(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
-    const RowVec rv = make_rowvec((Cs + Cd) / Vec16<T>::N);
-    hipLaunchKernelGGL(upcat_fwd_kernel<T>, row_grid(W * rv.vpr, B * H), dim3(256), 0, stream, (const T*)deep, deep_scale_shift, (const T*)skip, skip_scale_shift, (T*)out, B, h, w, Cd, H, W, Cs, rv);
+    const RowVec rvs = make_rowvec(Cs / Vec16<T>::N), rvd = make_rowvec(Cd / Vec16<T>::N);
+    dim3 grid = row_grid(W * std::max(rvs.vpr, rvd.vpr), B * H);
+    grid.z = 2;
+    hipLaunchKernelGGL(upcat_fwd_kernel<T>, grid, dim3(256), 0, stream, (const T*)deep, deep_scale_shift, (const T*)skip, skip_scale_shift, (T*)out, B, h, w, Cd, H, W, Cs, rvs, rvd);
     return check_launch("upcat_fwd_kernel");
   });
 }
