@@ -62,7 +62,10 @@ template <> struct Frag<float> {
   }
 };
 
-template <typename T, int TB, int TH, int TW, int BN, int WM, int WN, int TAPS>
+// EPI: 0 = (+bias) store only [data-gradient, 1x1 conv]; 1 = +bias, store, BatchNorm partial statistics [train forward];
+//      2 = folded BatchNorm affine + ReLU [eval forward].  Compile-time so the 128 values per lane pay only for what
+//      the launch needs (the generic epilogue was ~10 VALU per value; the data-gradient needs ~1).
+template <typename T, int TB, int TH, int TW, int BN, int WM, int WN, int TAPS, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int PAD = (TAPS == 9) ? 1 : 0;
   constexpr int HH = TH + 2 * PAD, HWD = TW + 2 * PAD, HPI = HH * HWD, HPX = TB * HPI;   // halo pixels per image / per tile
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int EPR = WCOLS / EPP;                            // 16-byte pieces per row
   constexpr int ROWS_PER_PASS = 64 / EPR;
   T* __restrict__ yg = reinterpret_cast<T*>(a.y);
-  const bool want_stats = a.stats != nullptr;
+  constexpr bool want_stats = (EPI == 1);
   __syncthreads();                                           // every wave is done reading the operand buffers
   char* wbuf = smem + wave * WBYTES;
   float st_s[NT], st_q[NT];
@@ -289,24 +292,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     const int nl = (wn * NT + nt) * 32 + l31;                  // channel within the block tile
     const int n = n0 + nl;
     const float bias_v = a.bias ? a.bias[n] : 0.f;
-    const float sc = a.scale ? a.scale[n] : 1.f;
-    const float sh = a.shift ? a.shift[n] : 0.f;
+    float sc = 1.f, sh = 0.f;
+    if constexpr (EPI == 2) { sc = a.scale[n]; sh = a.shift[n]; }
     float s = 0.f, sq = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int m = wm * WROWS + row;
-        const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
         float v = acc[mt][nt][r] + bias_v;
-        v = v * sc + sh;
-        if (a.relu) v = fmaxf(v, 0.f);
+        if constexpr (EPI == 2) {
+          v = v * sc + sh;
+          if (a.relu) v = fmaxf(v, 0.f);
+        }
         const T tv = from_float<T>(v);
         *reinterpret_cast<T*>(wbuf + row * WP + (nt * 32 + l31) * (int)sizeof(T)) = tv;
-        if (bb < a.B && yy < a.H && xx < a.W) {
-          const float fv = to_float(tv);
-          s += fv; sq += fv * fv;
+        if constexpr (want_stats) {
+          const int m = wm * WROWS + row;
+          const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
+          if (bb < a.B && yy < a.H && xx < a.W) {
+            const float fv = to_float(tv);
+            s += fv; sq += fv * fv;
+          }
         }
       }
     }
@@ -609,15 +616,17 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
   auto compute = [&](int buf) {
     const char* la = smem + buf * BUF_BYTES;
     const char* lb = la + A_BYTES + tg * HWD * PB;           // this wave's kernel row
-#pragma unroll 2
+    // k-step ks covers tile row ks (TW == 16): every address below is lane base + compile-time constant, so the fully
+    // unrolled loop has no address arithmetic (it was ~5 VALU per MFMA when only partially unrolled)
+    static_assert(TW == 16, "k-step == one 16-pixel tile row");
+    const char* pa = la + (half * 8 + tr_row) * PB + wco * 64 + tr_col_b;
+    const char* pb = lb + (half * 8 + tr_row) * PB + wci * 64 + tr_col_b;
+#pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      const int m0 = ks * 16 + half * 8 + tr_row, m1 = m0 + 4;
-      const short8 fa = WFrag<bf16_t>::load(la + m0 * PB + wco * 64 + tr_col_b, la + m1 * PB + wco * 64 + tr_col_b);
-      const int h0 = ((m0 / TW) * HWD + (m0 % TW)) * PB + wci * 64 + tr_col_b;
-      const int h1 = ((m1 / TW) * HWD + (m1 % TW)) * PB + wci * 64 + tr_col_b;
+      const short8 fa = WFrag<bf16_t>::load(pa + ks * 16 * PB, pa + (ks * 16 + 4) * PB);
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
-        const short8 fb = WFrag<bf16_t>::load(lb + h0 + kw * PB, lb + h1 + kw * PB);
+        const short8 fb = WFrag<bf16_t>::load(pb + (ks * HWD + kw) * PB, pb + (ks * HWD + kw + 4) * PB);
         acc[kw] = WFrag<bf16_t>::mfma(fa, fb, acc[kw]);
       }
     }
@@ -682,8 +691,8 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
   }
 }
 
-template <typename T, int TB, int TH, int TW, int BN, int WM, int WN, int TAPS>
-int launch_conv(const ConvArgs& a_in, hipStream_t stream) {
+template <typename T, int TB, int TH, int TW, int BN, int WM, int WN, int TAPS, int EPI>
+int launch_conv_epi(const ConvArgs& a_in, hipStream_t stream) {
   ConvArgs a = a_in;
   a.tilesY = (int)cdiv(a.H, TH);
   a.tilesX = (int)cdiv(a.W, TW);
@@ -694,7 +703,7 @@ int launch_conv(const ConvArgs& a_in, hipStream_t stream) {
   const size_t smem_in = smem_main + (a.in_ss ? (size_t)2 * a.Ci * sizeof(float) : 0);
   const size_t smem = smem_in > smem_epi ? smem_in : smem_epi;
   static_assert(smem_epi >= (size_t)WM * BN * 2 * 4, "stats scratch fits");
-  auto kern = conv_igemm_kernel<T, TB, TH, TW, BN, WM, WN, TAPS>;
+  auto kern = conv_igemm_kernel<T, TB, TH, TW, BN, WM, WN, TAPS, EPI>;
   static size_t attr_set = 0;
   if (smem > 64 * 1024 && smem > attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -703,6 +712,13 @@ int launch_conv(const ConvArgs& a_in, hipStream_t stream) {
   dim3 grid((unsigned)((size_t)cdiv(a.B, TB) * a.tilesY * a.tilesX), (unsigned)(a.Co / BN));
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, a);
   return check_launch("conv_igemm_kernel");
+}
+
+template <typename T, int TB, int TH, int TW, int BN, int WM, int WN, int TAPS>
+int launch_conv(const ConvArgs& a, hipStream_t stream) {
+  if (a.stats) return launch_conv_epi<T, TB, TH, TW, BN, WM, WN, TAPS, 1>(a, stream);
+  if (a.scale) return launch_conv_epi<T, TB, TH, TW, BN, WM, WN, TAPS, 2>(a, stream);
+  return launch_conv_epi<T, TB, TH, TW, BN, WM, WN, TAPS, 0>(a, stream);
 }
 
 // pixel-tile shape per problem: 16x16 for the large-extent levels, 8x8 (8x16 when Cout == 32) for the
@@ -748,6 +764,7 @@ extern "C" int im2im_conv_fwd(const void* x, const float* in_scale_shift, const 
   IM2IM_REQUIRE(taps == 9 || taps == 1);
   IM2IM_REQUIRE(dtype == IM2IM_F32 || dtype == IM2IM_BF16);
   IM2IM_REQUIRE((scale == nullptr) == (shift == nullptr));
+  IM2IM_REQUIRE(!(stats && scale));                              // statistics describe the raw conv output
   IM2IM_REQUIRE(Ci <= 2048);
   ConvArgs a{x, w, bias, scale, shift, y, stats, B, H, W, Ci, Co, 0, 0, relu, in_scale_shift};
   if (dtype == IM2IM_BF16) return taps == 9 ? dispatch_conv<bf16_t, 9>(a, stream) : dispatch_conv<bf16_t, 1>(a, stream);
