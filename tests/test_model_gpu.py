@@ -302,3 +302,43 @@ def test_lazy_batchnorm_path_is_bit_identical_to_materialised(dt):
     assert torch.equal(res[0][0], res[1][0])
     for n in res[0][1]:
         assert torch.equal(res[0][1][n], res[1][1][n]), n
+
+
+def test_two_input_channels_train_step_vs_oracle_fp32():
+    """BSBCM-style n_in = 2 (bsbcm config.yml:16-17): loss and first-layer gradients of one train step vs the oracle."""
+    from oracle import model as om
+    model = build(2, "fp32")
+    model.train()
+    x, y = om.det_images(2, 2, 48, 48, salt=6)
+    y = y[:, :1]
+    loss = model.loss_fn(model(x.to(DEV)), y.to(DEV))
+    loss.backward()
+    st = om.det_state(2, 1)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in st.items() if om.is_param(k)}
+    work = dict(st); work.update(leaves)
+    ref = om.quantile_loss(om.model_forward(x, work, training=True), y, PARAMS)
+    ref.backward()
+    assert loss.item() == pytest.approx(ref.item(), rel=2e-5)
+    for k in ("baseModel.inc.double_conv.0.weight", "baseModel.inc.double_conv.1.weight", "last_layer.upper.weight"):
+        p = dict(model.named_parameters())[k]
+        assert rel_l2(p.grad.cpu(), leaves[k].grad) < 5e-3, k
+
+
+@pytest.mark.parametrize("n_in,hw,batch", [(1, 1024, 1), (2, 512, 2)])
+def test_large_image_configs_run_bf16(n_in, hw, batch):
+    """BASELINE configs[3] (1024x1024 tiles) and configs[4] (512x512, two input channels) as synthetic shapes: one bf16
+    train step and an eval forward run, shapes right and results finite."""
+    from im2im_uq_amd import nn_ops
+    torch.manual_seed(0)
+    model = build(n_in, "bf16")
+    opt = nn_ops.FusedAdam(model.parameters(), lr=1e-4)
+    x = torch.randn(batch, n_in, hw, hw, device=DEV)
+    y = torch.rand(batch, 1, hw, hw, device=DEV)
+    model.train()
+    loss = model.loss_fn(model(x), y)
+    opt.zero_grad(); loss.backward(); opt.step()
+    assert np.isfinite(loss.item())
+    model.eval()
+    with torch.no_grad():
+        out = model(x[:1])
+    assert out.shape == (1, 3, 1, hw, hw) and bool(torch.isfinite(out).all())
