@@ -42,11 +42,11 @@ SIGNATURES = {
     "im2im_hb_mu_plus": (_f64, [_f64, _i64, _f64, _i32]),
     "im2im_pack_conv_weight": (_i32, [_ptr, _i32, _i32, _i32, _i32, _ptr, _ptr, _ptr]),
     "im2im_conv_stats_rows": (_i64, [_i32, _i32, _i32, _i32]),
-    "im2im_conv_fwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
+    "im2im_conv_fwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_conv_wgrad_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "im2im_conv_wgrad": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_reduce_workspace_bytes": (_i64, [_i64]),
-    "im2im_bn_finalize": (_i32, [_ptr, _i64, _i32, _i64, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _ptr, _ptr, _ptr, _ptr]),
+    "im2im_bn_finalize": (_i32, [_ptr, _i64, _i32, _i64, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _i32, _ptr, _ptr, _ptr, _ptr]),
     "im2im_bn_fold_eval": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _f32, _i32, _ptr, _ptr]),
     "im2im_bn_relu_apply": (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr]),
     "im2im_bn_bwd_workspace_bytes": (_i64, [_i64, _i32]),
@@ -58,7 +58,7 @@ SIGNATURES = {
     "im2im_upsample2x_concat_fwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_upsample2x_concat_bwd": (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_smallconv_tiles": (_i64, [_i32, _i32, _i32]),
-    "im2im_smallconv_s2l_fwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
+    "im2im_smallconv_s2l_fwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_smallconv_l2s_fwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_smallconv_wgrad_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "im2im_smallconv_wgrad": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr, _i64, _ptr]),

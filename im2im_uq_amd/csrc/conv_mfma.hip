@@ -36,6 +36,7 @@ struct ConvArgs {
   float* stats;         // [mtiles][2][Co] or null
   int B, H, W, Ci, Co, tilesY, tilesX;
   int relu;             // apply ReLU after affine
+  const float* center;  // [Co] or null: subtracted from the stored output (see im2im_conv_fwd)
   const float* in_ss;   // [2][Ci] or null: x holds the producer's PRE-BatchNorm output z; the operand staging applies
                         // a = max(z*scale + shift, 0) on the fly (the BatchNorm+ReLU pass is never materialised)
 };
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   for (int nt = 0; nt < NT; ++nt) {
     const int nl = (wn * NT + nt) * 32 + l31;                  // channel within the block tile
     const int n = n0 + nl;
-    const float bias_v = a.bias ? a.bias[n] : 0.f;
+    const float bias_v = (a.bias ? a.bias[n] : 0.f) - (a.center ? a.center[n] : 0.f);
     float sc = 1.f, sh = 0.f;
     if constexpr (EPI == 2) { sc = a.scale[n]; sh = a.shift[n]; }
     float s = 0.f, sq = 0.f;
@@ -753,9 +754,9 @@ extern "C" int64_t im2im_conv_stats_rows(int32_t B, int32_t H, int32_t W, int32_
   return im2im::cdiv(B, t.tb) * im2im::cdiv(H, t.th) * im2im::cdiv(W, t.tw);
 }
 
-extern "C" int im2im_conv_fwd(const void* x, const float* in_scale_shift, const void* w, const float* bias, const float* scale,
-                              const float* shift, void* y, float* stats, int32_t B, int32_t H, int32_t W, int32_t Ci,
-                              int32_t Co, int32_t taps, int32_t relu, int32_t dtype, im2im_stream_t stream_) {
+extern "C" int im2im_conv_fwd(const void* x, const float* in_scale_shift, const void* w, const float* bias, const float* center,
+                              const float* scale, const float* shift, void* y, float* stats, int32_t B, int32_t H, int32_t W,
+                              int32_t Ci, int32_t Co, int32_t taps, int32_t relu, int32_t dtype, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(x && w && y);
   IM2IM_REQUIRE(B > 0 && H > 0 && W > 0);
@@ -766,7 +767,7 @@ extern "C" int im2im_conv_fwd(const void* x, const float* in_scale_shift, const 
   IM2IM_REQUIRE((scale == nullptr) == (shift == nullptr));
   IM2IM_REQUIRE(!(stats && scale));                              // statistics describe the raw conv output
   IM2IM_REQUIRE(Ci <= 2048);
-  ConvArgs a{x, w, bias, scale, shift, y, stats, B, H, W, Ci, Co, 0, 0, relu, in_scale_shift};
+  ConvArgs a{x, w, bias, scale, shift, y, stats, B, H, W, Ci, Co, 0, 0, relu, center, in_scale_shift};
   if (dtype == IM2IM_BF16) return taps == 9 ? dispatch_conv<bf16_t, 9>(a, stream) : dispatch_conv<bf16_t, 1>(a, stream);
   return taps == 9 ? dispatch_conv<float, 9>(a, stream) : dispatch_conv<float, 1>(a, stream);
 }

@@ -17,8 +17,8 @@ using namespace im2im;
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ tmp, int S, int C, double count,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                           float momentum, float eps, float* __restrict__ mean_invstd,
-                                                           float* __restrict__ scale_shift) {
+                                                           float momentum, float eps, int centered,
+                                                           float* __restrict__ mean_invstd, float* __restrict__ scale_shift) {
   // one wave per channel: lane i holds split-row i (S <= 64), fixed-order butterfly -> deterministic
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   scale_shift[C + c] = beta[c] - (float)mean * sc;
   if (running_mean) {
     const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    // centered: the statistics describe z - running_mean(old); the true batch mean adds it back
+    const float true_mean = (float)mean + (centered ? running_mean[c] : 0.f);
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * true_mean;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
   }
 }
@@ -616,15 +618,16 @@ extern "C" int64_t im2im_reduce_workspace_bytes(int64_t K) { return im2im::reduc
 
 extern "C" int im2im_bn_finalize(const float* partial, int64_t R, int32_t C, int64_t count, const float* gamma,
                                  const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                 float* mean_invstd, float* scale_shift, void* ws, im2im_stream_t stream_) {
+                                 int32_t centered, float* mean_invstd, float* scale_shift, void* ws, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(partial && gamma && beta && mean_invstd && scale_shift && ws && R > 0 && C > 0 && count > 0);
   IM2IM_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+  IM2IM_REQUIRE(!centered || running_mean);
   int rc;
   const int S = launch_reduce_stage1(partial, R, 2 * (int64_t)C, (double*)ws, stream, &rc);
   if (rc) return rc;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, stream, (const double*)ws, S, (int)C,
-                     (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean_invstd, scale_shift);
+                     (double)count, gamma, beta, running_mean, running_var, momentum, eps, (int)centered, mean_invstd, scale_shift);
   return check_launch("bn_finalize_kernel");
 }
 

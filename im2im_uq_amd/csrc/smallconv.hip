@@ -49,6 +49,7 @@ struct S2LArgs {
   const float* in;      // [B][CS][H][W]
   const float* w;       // [CS][9][CL]
   const float* bias;    // [CL] | null
+  const float* center;  // [CL] | null (subtracted from the stored output)
   const float* scale_shift;   // [2][CL] | null
   void* out;            // [B][H][W][CL] T
   float* stats;         // [blk][2][CL] | null
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void smallconv_s2l_kernel(S2LArgs a) {
   const int ty = tid / TS, tx = tid % TS;
   float acc[CL];
 #pragma unroll
-  for (int l = 0; l < CL; ++l) acc[l] = a.bias ? a.bias[l] : 0.f;
+  for (int l = 0; l < CL; ++l) acc[l] = (a.bias ? a.bias[l] : 0.f) - (a.center ? a.center[l] : 0.f);
   for (int s = 0; s < a.CS; ++s) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -304,12 +305,13 @@ extern "C" int64_t im2im_smallconv_tiles(int32_t B, int32_t H, int32_t W) {
   return (int64_t)B * im2im::cdiv(H, TS) * im2im::cdiv(W, TS);
 }
 
-extern "C" int im2im_smallconv_s2l_fwd(const float* in, const float* w, const float* bias, const float* scale_shift, void* out,
+extern "C" int im2im_smallconv_s2l_fwd(const float* in, const float* w, const float* bias, const float* center,
+                                       const float* scale_shift, void* out,
                                        float* stats, int32_t B, int32_t H, int32_t W, int32_t CS, int32_t CL, int32_t relu,
                                        int32_t flip, int32_t dtype, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(in && w && out && B > 0 && H > 0 && W > 0 && CS >= 1 && CS <= CS_MAX);
-  S2LArgs a{in, w, bias, scale_shift, out, stats, B, H, W, CS, (int)cdiv(H, TS), (int)cdiv(W, TS), relu, flip};
+  S2LArgs a{in, w, bias, center, scale_shift, out, stats, B, H, W, CS, (int)cdiv(H, TS), (int)cdiv(W, TS), relu, flip};
   return for_dtype_cl(dtype, CL, [&](auto* tag, auto cl) {
     using T = std::remove_pointer_t<decltype(tag)>;
     hipLaunchKernelGGL((smallconv_s2l_kernel<T, decltype(cl)::value>), dim3((unsigned)(B * a.tilesY * a.tilesX)), dim3(256), 0, stream, a);

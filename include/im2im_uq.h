@@ -102,13 +102,17 @@ int im2im_pack_conv_weight(const float* w, int32_t Co, int32_t Ci, int32_t taps,
  *   stats (may be NULL): [rows][2][Co] fp32 per-tile partial sums and sums of squares of the STORED
  *   values over valid pixels, rows = im2im_conv_stats_rows(B,H,W,Co): train-mode BatchNorm statistics
  *   without re-reading y.  dgrad uses the same entry point with x = dz and wf = wd.
+ *   center (may be NULL): fp32 [Co] subtracted from the stored output.  The bf16 train path passes the layer's
+ *   running_mean so the pre-BatchNorm tensor is stored roughly zero-mean (BatchNorm is shift invariant; bf16 rounding
+ *   is then relative to the spread of a channel instead of its offset); im2im_bn_finalize(centered = 1) adds it back
+ *   into the running-mean update.
  *   in_scale_shift (may be NULL): fp32 [2][Ci].  When given, x holds the PRE-BatchNorm output z of the producing
  *   layer and every consumer applies a = max(z*scale + shift, 0) while staging its operand ("lazy" BatchNorm+ReLU,
  *   unet_parts.py:17-18): the normalised activation is never written to HBM.  Same option on im2im_conv_wgrad
  *   (x_scale_shift), im2im_maxpool2_* (in_scale_shift) and im2im_upsample2x_concat_fwd (deep/skip_scale_shift). */
 int64_t im2im_conv_stats_rows(int32_t B, int32_t H, int32_t W, int32_t Co);
 int im2im_conv_fwd(const void* x, const float* in_scale_shift, const void* wf, const float* bias,
-                   const float* scale, const float* shift, void* y, float* stats, int32_t B,
+                   const float* center, const float* scale, const float* shift, void* y, float* stats, int32_t B,
                    int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t taps, int32_t relu,
                    int32_t dtype, im2im_stream_t stream);
 
@@ -141,7 +145,8 @@ int64_t im2im_reduce_workspace_bytes(int64_t K);
  */
 int im2im_bn_finalize(const float* partial, int64_t R, int32_t C, int64_t count, const float* gamma,
                       const float* beta, float* running_mean, float* running_var, float momentum,
-                      float eps, float* mean_invstd, float* scale_shift, void* ws, im2im_stream_t stream);
+                      float eps, int32_t centered, float* mean_invstd, float* scale_shift, void* ws,
+                      im2im_stream_t stream);
 int im2im_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, const float* conv_bias, float eps, int32_t C,
                        float* scale_shift, im2im_stream_t stream);
@@ -188,8 +193,8 @@ int im2im_upsample2x_concat_bwd(const void* dout, void* ddeep, void* dskip, int3
  *   dbias [CS]|NULL = sum_px S[s][px].
  */
 int64_t im2im_smallconv_tiles(int32_t B, int32_t H, int32_t W);
-int im2im_smallconv_s2l_fwd(const float* in, const float* w, const float* bias, const float* scale_shift,
-                            void* out, float* stats, int32_t B, int32_t H, int32_t W, int32_t CS,
+int im2im_smallconv_s2l_fwd(const float* in, const float* w, const float* bias, const float* center,
+                            const float* scale_shift, void* out, float* stats, int32_t B, int32_t H, int32_t W, int32_t CS,
                             int32_t CL, int32_t relu, int32_t flip, int32_t dtype, im2im_stream_t stream);
 int im2im_smallconv_l2s_fwd(const void* in, const float* w, const float* bias, float* out, int32_t B,
                             int32_t H, int32_t W, int32_t CL, int32_t CS, int32_t dtype,

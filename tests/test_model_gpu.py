@@ -342,3 +342,31 @@ def test_large_image_configs_run_bf16(n_in, hw, batch):
     with torch.no_grad():
         out = model(x[:1])
     assert out.shape == (1, 3, 1, hw, hw) and bool(torch.isfinite(out).all())
+
+
+def test_bf16_centering_reduces_train_mode_rounding_error():
+    """Opt-in nn_ops.BF16_CENTERING: bf16 train mode stores z - running_mean instead of z (BatchNorm is shift invariant);
+    once the running mean has warmed up the stored tensor is ~zero-mean per channel.  Measured against the fp32 mode on
+    the same weights the centred error is smaller (4.8 % vs 5.8 % here); both paths must stay within the 8 % bf16 bound."""
+    import copy
+    from im2im_uq_amd import nn_ops
+    from oracle import model as om
+    x, _ = om.det_images(4, 1, 96, 96, salt=7)
+    x = x.to(DEV)
+    base = build(1, "fp32")
+    base.train()
+    with torch.no_grad():
+        for _ in range(25):                      # warm the running statistics up on this batch
+            base(x)
+    outs = {}
+    for tag, dt, centering in (("fp32", "fp32", False), ("on", "bf16", True), ("off", "bf16", False)):
+        nn_ops.set_compute_dtype(dt)
+        nn_ops.BF16_CENTERING = centering
+        m = copy.deepcopy(base)
+        m.train()
+        with torch.no_grad():
+            outs[tag] = m(x).float().cpu()
+    nn_ops.BF16_CENTERING = False
+    e_on, e_off = rel_l2(outs["on"], outs["fp32"]), rel_l2(outs["off"], outs["fp32"])
+    print("bf16 train-forward error vs fp32: centred", e_on, "un-centred", e_off)
+    assert e_on < e_off < 8e-2
