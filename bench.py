@@ -53,7 +53,7 @@ def cpu_baseline(hw, batch, steps):
     om.train_steps(st, [(x, y)] * steps, PARAMS, lr=1e-4)
     dt_train = time.perf_counter() - t0
     # calibration inner loop on pre-materialised outputs: per-lambda batched-64 loop as the reference runs it
-    n_cal, n_lam = 64, 20
+    n_cal, n_lam = 256, 200
     out, lab = oc.synth_outputs(n_cal, 1, hw, hw, seed=0)
     lambdas = torch.linspace(0, 6, n_lam)
     t0 = time.perf_counter()
@@ -66,7 +66,7 @@ def cpu_baseline(hw, batch, steps):
                   f"({dt_train:.1f} s)",
         "calib_scoring": {"value": n_cal * n_lam / dt_cal, "unit": "image*lambda/s",
                           "imgs_per_s_at_1000_lambdas": n_cal * n_lam / dt_cal / 1000.0,
-                          "sample": f"{n_cal} images x {n_lam} lambdas ({dt_cal:.1f} s); the reference re-reads 16 B/px "
+                          "sample": f"{n_cal} images x {n_lam} lambdas ({dt_cal:.2f} s); the reference re-reads 16 B/px "
                                     f"per lambda, so 1000 lambdas cost 1000x one"},
     }
 
@@ -238,7 +238,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(hw, 4, 3)
+        cpu = cpu_baseline(hw, 4, 8)
 
     if rank == 0:
         line = {
