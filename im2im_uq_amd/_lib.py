@@ -43,7 +43,13 @@ SIGNATURES = {
     "im2im_pack_conv_weight": (_i32, [_ptr, _i32, _i32, _i32, _i32, _ptr, _ptr, _ptr]),
     "im2im_conv_stats_rows": (_i64, [_i32, _i32, _i32, _i32]),
     "im2im_conv_fwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
+    # x, in_ss, x_hi, in_ss_hi, Ci_lo, wf, bias, center, scale, shift, y, y_hi, Co_lo, stats, B, H, W, Ci, Co, taps, relu, dtype, stream
+    "im2im_conv_fwd_split": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr,
+                                    _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_conv_wgrad_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    # x, x_ss, x_hi, x_ss_hi, Ci_lo, dz, dw, ws, ws_bytes, B, H, W, Ci, Co, taps, dtype, stream
+    "im2im_conv_wgrad_split": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _i64, _i32, _i32, _i32, _i32, _i32, _i32,
+                                      _i32, _ptr]),
     "im2im_conv_wgrad": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_reduce_workspace_bytes": (_i64, [_i64]),
     "im2im_bn_finalize": (_i32, [_ptr, _i64, _i32, _i64, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _i32, _ptr, _ptr, _ptr, _ptr]),

@@ -41,8 +41,9 @@ class DoubleConv(nn.Module):
         )
         self.compute_dtype = None
 
-    def forward(self, x, lazy=False):
-        """lazy=True (used between this package's own blocks): in training the result is a *lazy activation* -- it
+    def forward(self, x, lazy=False, x_hi=None):
+        """x_hi: second half of the input channels when the caller did not concatenate them (Up.forward).
+        lazy=True (used between this package's own blocks): in training the result is a *lazy activation* -- it
         holds the pre-BatchNorm conv output and the consumers (next conv / max-pool / upsample-concat / 1x1 conv
         kernels) apply BatchNorm+ReLU while loading it, so the normalised tensor is never written to HBM.  The
         default returns an ordinary tensor."""
@@ -52,13 +53,14 @@ class DoubleConv(nn.Module):
             if self.training:
                 momentum = bn.momentum if bn.momentum is not None else 0.1
                 x = nn_ops.conv_bn_relu_train(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
-                                              bn.running_var, momentum, bn.eps, cdt, lazy_out=(lazy or ci == 0))
+                                              bn.running_var, momentum, bn.eps, cdt, lazy_out=(lazy or ci == 0), x_hi=x_hi)
                 bn.num_batches_tracked += 1
             else:
                 if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad and False):
                     raise NotImplementedError("eval-mode backward through the fused conv+BN kernel is not implemented")
                 x = nn_ops.conv_bn_relu_eval(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
-                                             bn.running_var, bn.eps, cdt)
+                                             bn.running_var, bn.eps, cdt, x_hi=x_hi)
+            x_hi = None
         return x
 
 
@@ -102,7 +104,12 @@ class Up(nn.Module):
                                       "experiment configs only ever use the bilinear default (SURVEY D2)")
 
     def forward(self, x1, x2, lazy=False):
-        # x1: deep feature map, x2: skip connection.  upsample + zero-pad + cat([x2, x1]) in one kernel.
+        # x1: deep feature map, x2: skip connection.  cat([x2, pad(up(x1))]) is not materialised: the first conv reads the
+        # skip half in place and the upsampled half from its own tensor (odd widths fall back to one fused
+        # upsample + pad + concat kernel).
+        if nn_ops.can_split_concat(x1, x2):
+            up = nn_ops.Upsample2x.apply(x1, x2.shape[2], x2.shape[3])
+            return self.conv(x2, lazy=lazy, x_hi=up)
         x = nn_ops.UpsampleConcat.apply(x1, x2)
         return self.conv(x, lazy=lazy)
 

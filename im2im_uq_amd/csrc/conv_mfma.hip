@@ -39,6 +39,12 @@ struct ConvArgs {
   const float* center;  // [Co] or null: subtracted from the stored output (see im2im_conv_fwd)
   const float* in_ss;   // [2][Ci] or null: x holds the producer's PRE-BatchNorm output z; the operand staging applies
                         // a = max(z*scale + shift, 0) on the fly (the BatchNorm+ReLU pass is never materialised)
+  // channel-split operands (the Up block's torch.cat([skip, up], 1) is never materialised, unet_parts.py:68):
+  const void* x_hi;     // null, or: input channels [Ci_lo, Ci) live here (pixel stride Ci - Ci_lo == Ci_lo), [0, Ci_lo) in x
+  const float* in_ss_hi;// [2][Ci - Ci_lo] or null: lazy BatchNorm+ReLU of x_hi (in_ss then describes x's Ci_lo channels)
+  int Ci_lo;
+  void* y_hi;           // null, or: output channels [Co_lo, Co) go here (pixel stride Co - Co_lo), [0, Co_lo) to y
+  int Co_lo;
 };
 
 template <typename T> struct Frag;
@@ -107,6 +113,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 
   const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
+  const bool split_in = a.x_hi != nullptr;
+  const int xstride = split_in ? a.Ci_lo : a.Ci;       // pixel stride of the source tensor(s)
 
   // per-lane LDS byte offsets of this lane's A rows / B rows
   int aoff[MT], boff[NT];
@@ -132,7 +140,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   // the compiler use scalar-base addressing and keeps the unrolled loop free of index arithmetic).
   //   halo piece i:  xg_tile + a_goff[i] + chunk*KC      (a_goff < 0: outside the image/batch -> zeros)
   //   weight piece i: wg_tile + b_goff[i] + tap*Ci + chunk*KC
-  const T* __restrict__ xg_tile = xg + (size_t)b0 * a.H * a.W * a.Ci;
+  const T* __restrict__ xg_tile = xg + (size_t)b0 * a.H * a.W * xstride;
+  const T* __restrict__ xh_tile = reinterpret_cast<const T*>(a.x_hi) + (size_t)b0 * a.H * a.W * xstride;
   const T* __restrict__ wg_tile = wg + (size_t)n0 * TAPS * a.Ci;
   int a_goff[A_ROUNDS], a_loff[A_ROUNDS], b_goff[B_ROUNDS], b_loff[B_ROUNDS];
 #pragma unroll
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     const int tb = px / HPI, pi = px % HPI;
     const int yy = y0 + pi / HWD - PAD, xx = x0 + pi % HWD - PAD;
     const bool ok = px < HPX && b0 + tb < a.B && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-    a_goff[i] = ok ? (((tb * a.H + yy) * a.W + xx) * a.Ci + part * EPP) : -1;
+    a_goff[i] = ok ? (((tb * a.H + yy) * a.W + xx) * xstride + part * EPP) : -1;
     a_loff[i] = (px < HPX) ? tb * HIMGB + (pi / HWD) * HROWB + (pi % HWD) * ROWB + part * 16 : -1;
   }
 #pragma unroll
@@ -154,7 +163,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   }
 
   auto gload_A = [&](int chunk) {
-    const T* src = xg_tile + chunk * KC;
+    const int c = chunk * KC;
+    const T* src = (split_in && c >= a.Ci_lo) ? xh_tile + (c - a.Ci_lo) : xg_tile + c;
 #pragma unroll
     for (int i = 0; i < A_ROUNDS; ++i) {
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -162,12 +172,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
       ra[i] = v;
     }
   };
-  const bool lazy_in = a.in_ss != nullptr;
-  if (lazy_in) {
-    for (int i = tid; i < 2 * a.Ci; i += 256) ldsSS[i] = a.in_ss[i];
+  const bool lazy_lo = a.in_ss != nullptr, lazy_hi = a.in_ss_hi != nullptr;
+  if (lazy_lo || lazy_hi) {
+    // ldsSS = [scale over the Ci logical channels][shift ...]; a source without coefficients is never looked up
+    const int clo = split_in ? a.Ci_lo : a.Ci, chi = a.Ci - clo;
+    if (lazy_lo) for (int i = tid; i < clo; i += 256) { ldsSS[i] = a.in_ss[i]; ldsSS[a.Ci + i] = a.in_ss[clo + i]; }
+    if (lazy_hi) for (int i = tid; i < chi; i += 256) { ldsSS[clo + i] = a.in_ss_hi[i]; ldsSS[a.Ci + clo + i] = a.in_ss_hi[chi + i]; }
     __syncthreads();
   }
   auto swrite_A = [&](int chunk) {
+    const bool lazy_in = (split_in && chunk * KC >= a.Ci_lo) ? lazy_hi : lazy_lo;
     if (lazy_in) {
       // this thread's pieces all cover the same EPP channels of the chunk: chunk*KC + (tid % PPR)*EPP ...
       const int c0 = chunk * KC + (tid % PPR) * EPP;
@@ -283,7 +297,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int WBYTES = WROWS * WP;
   constexpr int EPR = WCOLS / EPP;                            // 16-byte pieces per row
   constexpr int ROWS_PER_PASS = 64 / EPR;
-  T* __restrict__ yg = reinterpret_cast<T*>(a.y);
+  // this wave's WCOLS output channels start at ncol; with a split destination they all belong to one of the tensors
+  const int ncol = n0 + wn * WCOLS;
+  const bool to_hi = a.y_hi != nullptr && ncol >= a.Co_lo;
+  T* __restrict__ yg = reinterpret_cast<T*>(to_hi ? a.y_hi : a.y) + (to_hi ? ncol - a.Co_lo : ncol);
+  const int ystride = a.y_hi == nullptr ? a.Co : (to_hi ? a.Co - a.Co_lo : a.Co_lo);
   constexpr bool want_stats = (EPI == 1);
   __syncthreads();                                           // every wave is done reading the operand buffers
   char* wbuf = smem + wave * WBYTES;
@@ -329,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     const int m = wm * WROWS + row;
     const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
     if (bb < a.B && yy < a.H && xx < a.W)
-      *reinterpret_cast<uint4*>(yg + (((size_t)bb * a.H + yy) * a.W + xx) * a.Co + n0 + wn * WCOLS + piece * EPP) = v;
+      *reinterpret_cast<uint4*>(yg + (((size_t)bb * a.H + yy) * a.W + xx) * ystride + piece * EPP) = v;
   }
   if (want_stats) {
     __syncthreads();                                         // the stats scratch aliases wave 0's tile
@@ -366,6 +384,23 @@ struct WgradArgs {
   float* partial;    // [nsplit][Co][TAPS][Ci] fp32
   int B, H, W, Ci, Co, tilesY, tilesX, ntiles, tiles_per_split;
   const float* x_ss; // [2][Ci] or null: x is the producer's pre-BatchNorm z; staging applies max(z*scale+shift, 0)
+  const void* x_hi;  // null, or: input channels [Ci_lo, Ci) live here (see ConvArgs); x_ss_hi = its lazy coefficients
+  const float* x_ss_hi;
+  int Ci_lo;
+};
+
+// source tensor of a 64-channel input block: base pointer (at the block's first channel), pixel stride, lazy coefficients
+template <typename T> struct WgradSrc {
+  const T* x; int stride; const float* sc; const float* sh;
+  __device__ __forceinline__ WgradSrc(const WgradArgs& a, int ci0) {
+    const bool split = a.x_hi != nullptr, hi = split && ci0 >= a.Ci_lo;
+    stride = split ? a.Ci_lo : a.Ci;
+    const int c = hi ? ci0 - a.Ci_lo : ci0;
+    x = reinterpret_cast<const T*>(hi ? a.x_hi : a.x) + c;
+    const float* ss = hi ? a.x_ss_hi : a.x_ss;
+    sc = ss ? ss + c : nullptr;
+    sh = ss ? ss + stride + c : nullptr;
+  }
 };
 
 template <typename T> struct WFrag;
@@ -411,7 +446,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int half = lane >> 5, l31 = lane & 31;
   const int ci_tiles = a.Ci / CT;
   const int co0 = (blockIdx.x / ci_tiles) * CT, ci0 = (blockIdx.x % ci_tiles) * CT;   // Co may be 32 mod 64: masked
-  const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
+  const WgradSrc<T> xs(a, ci0);
+  const T* __restrict__ xg = xs.x;
   const T* __restrict__ dzg = reinterpret_cast<const T*>(a.dz);
 
   f32x16 acc[TAPS];
@@ -435,7 +471,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int ty_id = tt % a.tilesY;
     const int b = tt / a.tilesY;
     const int y0 = ty_id * TH, x0 = tx_id * TW;
-    const T* xb = xg + (size_t)b * a.H * a.W * a.Ci;
+    const T* xb = xg + (size_t)b * a.H * a.W * xs.stride;
     const T* dzb = dzg + (size_t)b * a.H * a.W * a.Co;
     if (t != t_begin) __syncthreads();
     // stage dz tile
@@ -457,12 +493,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       const int yy = y0 + px / HWD - PAD, xx = x0 + px % HWD - PAD;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (px < HPX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
-        v = *reinterpret_cast<const uint4*>(xb + ((size_t)yy * a.W + xx) * a.Ci + ci0 + part * EPP);
-        if (a.x_ss) {
+        v = *reinterpret_cast<const uint4*>(xb + ((size_t)yy * a.W + xx) * xs.stride + part * EPP);
+        if (xs.sc) {
           float f[EPP];
           Vec16<T>::load(reinterpret_cast<const T*>(&v), f);
 #pragma unroll
-          for (int k = 0; k < EPP; ++k) f[k] = fmaxf(f[k] * a.x_ss[ci0 + part * EPP + k] + a.x_ss[a.Ci + ci0 + part * EPP + k], 0.f);
+          for (int k = 0; k < EPP; ++k) f[k] = fmaxf(f[k] * xs.sc[part * EPP + k] + xs.sh[part * EPP + k], 0.f);
           Vec16<T>::store(reinterpret_cast<T*>(&v), f);
         }
       }
@@ -534,7 +570,8 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
   const int half = lane >> 5, l31 = lane & 31;
   const int ci_tiles = a.Ci / CT;
   const int co0 = (blockIdx.x / ci_tiles) * CT, ci0 = (blockIdx.x % ci_tiles) * CT;
-  const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
+  const WgradSrc<T> xs(a, ci0);
+  const T* __restrict__ xg = xs.x;
   const T* __restrict__ dzg = reinterpret_cast<const T*>(a.dz);
 
   f32x16 acc[3];
@@ -556,10 +593,10 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
   uint4 ra[A_ROUNDS], rb[B_ROUNDS];
   unsigned b_valid = 0;                              // bit i: rb[i] holds real pixels (not zero padding)
   float xsc[EPP], xsh[EPP];                          // this thread's pieces always cover channels ci0 + (tid % 8)*8 ...
-  const bool lazy_x = a.x_ss != nullptr;
+  const bool lazy_x = xs.sc != nullptr;
   if (lazy_x) {
 #pragma unroll
-    for (int k = 0; k < EPP; ++k) { xsc[k] = a.x_ss[ci0 + (tid % PPR) * EPP + k]; xsh[k] = a.x_ss[a.Ci + ci0 + (tid % PPR) * EPP + k]; }
+    for (int k = 0; k < EPP; ++k) { xsc[k] = xs.sc[(tid % PPR) * EPP + k]; xsh[k] = xs.sh[(tid % PPR) * EPP + k]; }
   }
 
   auto gload = [&](int t) {
@@ -568,7 +605,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
     const int ty_id = tt % a.tilesY;
     const int b = tt / a.tilesY;
     const int y0 = ty_id * TH, x0 = tx_id * TW;
-    const T* xb = xg + (size_t)b * a.H * a.W * a.Ci + ci0;
+    const T* xb = xg + (size_t)b * a.H * a.W * xs.stride;
     const T* dzb = dzg + (size_t)b * a.H * a.W * a.Co + co0;
 #pragma unroll
     for (int i = 0; i < A_ROUNDS; ++i) {
@@ -587,7 +624,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
       if (b_px[i] >= 0) {
         const int yy = y0 + b_px[i] / HWD - 1, xx = x0 + b_px[i] % HWD - 1;
         if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
-          v = *reinterpret_cast<const uint4*>(xb + ((size_t)yy * a.W + xx) * a.Ci + b_part[i] * EPP);
+          v = *reinterpret_cast<const uint4*>(xb + ((size_t)yy * a.W + xx) * xs.stride + b_part[i] * EPP);
           b_valid |= 1u << i;
         }
       }
@@ -701,7 +738,7 @@ int launch_conv_epi(const ConvArgs& a_in, hipStream_t stream) {
   constexpr int ROWB = 32 * (int)sizeof(T) + 16;
   constexpr size_t smem_main = (size_t)TB * (TH + 2 * PAD) * ((TW + 2 * PAD) * ROWB + (sizeof(T) == 2 ? 96 : 0)) + (size_t)2 * BN * ROWB;
   constexpr size_t smem_epi = (size_t)4 * (TB * TH * TW / WM) * ((BN / WN) * sizeof(T) + 16);   // 4 wave-private output tiles
-  const size_t smem_in = smem_main + (a.in_ss ? (size_t)2 * a.Ci * sizeof(float) : 0);
+  const size_t smem_in = smem_main + ((a.in_ss || a.in_ss_hi) ? (size_t)2 * a.Ci * sizeof(float) : 0);
   const size_t smem = smem_in > smem_epi ? smem_in : smem_epi;
   static_assert(smem_epi >= (size_t)WM * BN * 2 * 4, "stats scratch fits");
   auto kern = conv_igemm_kernel<T, TB, TH, TW, BN, WM, WN, TAPS, EPI>;
@@ -757,8 +794,29 @@ extern "C" int64_t im2im_conv_stats_rows(int32_t B, int32_t H, int32_t W, int32_
 extern "C" int im2im_conv_fwd(const void* x, const float* in_scale_shift, const void* w, const float* bias, const float* center,
                               const float* scale, const float* shift, void* y, float* stats, int32_t B, int32_t H, int32_t W,
                               int32_t Ci, int32_t Co, int32_t taps, int32_t relu, int32_t dtype, im2im_stream_t stream_) {
+  return im2im_conv_fwd_split(x, in_scale_shift, nullptr, nullptr, Ci, w, bias, center, scale, shift, y, nullptr, Co, stats, B, H, W,
+                              Ci, Co, taps, relu, dtype, stream_);
+}
+
+extern "C" int im2im_conv_fwd_split(const void* x, const float* in_scale_shift, const void* x_hi, const float* in_scale_shift_hi,
+                                    int32_t Ci_lo, const void* w, const float* bias, const float* center, const float* scale,
+                                    const float* shift, void* y, void* y_hi, int32_t Co_lo, float* stats, int32_t B, int32_t H,
+                                    int32_t W, int32_t Ci, int32_t Co, int32_t taps, int32_t relu, int32_t dtype,
+                                    im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(x && w && y);
+  if (x_hi) {
+    IM2IM_REQUIRE(Ci_lo > 0 && Ci_lo % 32 == 0 && Ci == 2 * Ci_lo);   // both sources share one pixel stride
+  } else {
+    IM2IM_REQUIRE(in_scale_shift_hi == nullptr);
+    Ci_lo = Ci;
+  }
+  if (y_hi) {
+    IM2IM_REQUIRE(Co_lo > 0 && Co_lo % 64 == 0 && Co_lo < Co && (Co - Co_lo) % 64 == 0);   // a wave's 32/64 columns never straddle
+    IM2IM_REQUIRE(stats == nullptr && scale == nullptr);
+  } else {
+    Co_lo = Co;
+  }
   IM2IM_REQUIRE(B > 0 && H > 0 && W > 0);
   IM2IM_REQUIRE(Ci > 0 && Ci % 32 == 0);
   IM2IM_REQUIRE(Co > 0 && Co % 32 == 0);
@@ -767,21 +825,22 @@ extern "C" int im2im_conv_fwd(const void* x, const float* in_scale_shift, const 
   IM2IM_REQUIRE((scale == nullptr) == (shift == nullptr));
   IM2IM_REQUIRE(!(stats && scale));                              // statistics describe the raw conv output
   IM2IM_REQUIRE(Ci <= 2048);
-  ConvArgs a{x, w, bias, scale, shift, y, stats, B, H, W, Ci, Co, 0, 0, relu, center, in_scale_shift};
+  ConvArgs a{x, w, bias, scale, shift, y, stats, B, H, W, Ci, Co, 0, 0, relu, center, in_scale_shift,
+             x_hi, in_scale_shift_hi, Ci_lo, y_hi, Co_lo};
   if (dtype == IM2IM_BF16) return taps == 9 ? dispatch_conv<bf16_t, 9>(a, stream) : dispatch_conv<bf16_t, 1>(a, stream);
   return taps == 9 ? dispatch_conv<float, 9>(a, stream) : dispatch_conv<float, 1>(a, stream);
 }
 
 namespace {
 template <typename T, int TAPS>
-int launch_wgrad(const void* x, const float* x_ss, const void* dz, float* partial, int64_t partial_bytes, float* dw, int B,
-                 int H, int W, int Ci, int Co, hipStream_t stream) {
+int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float* x_ss_hi, int Ci_lo, const void* dz, float* partial,
+                 int64_t partial_bytes, float* dw, int B, int H, int W, int Ci, int Co, hipStream_t stream) {
   constexpr int TH = 8, TW = 16;
   constexpr int PAD = (TAPS == 9) ? 1 : 0;
   constexpr bool IS_BF16 = sizeof(T) == 2;
   constexpr int PB = IS_BF16 ? 192 : 272;
   constexpr size_t smem = (size_t)(TH * TW + (TH + 2 * PAD) * (TW + 2 * PAD)) * PB;
-  WgradArgs a{x, dz, partial, B, H, W, Ci, Co, (int)cdiv(H, TH), (int)cdiv(W, TW), 0, 0, x_ss};
+  WgradArgs a{x, dz, partial, B, H, W, Ci, Co, (int)cdiv(H, TH), (int)cdiv(W, TW), 0, 0, x_ss, x_hi, x_ss_hi, Ci_lo};
   a.ntiles = B * a.tilesY * a.tilesX;
   const int cblocks = (int)cdiv(Co, 64) * (Ci / 64);
   const size_t wsz = (size_t)Co * TAPS * Ci * sizeof(float);
@@ -834,8 +893,22 @@ extern "C" int im2im_conv_wgrad(const void* x, const float* x_scale_shift, const
                                 int64_t workspace_bytes,
                                 int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t taps, int32_t dtype,
                                 im2im_stream_t stream_) {
+  return im2im_conv_wgrad_split(x, x_scale_shift, nullptr, nullptr, Ci, dz, dw, workspace, workspace_bytes, B, H, W, Ci, Co, taps,
+                                dtype, stream_);
+}
+
+extern "C" int im2im_conv_wgrad_split(const void* x, const float* x_scale_shift, const void* x_hi, const float* x_scale_shift_hi,
+                                      int32_t Ci_lo, const void* dz, float* dw, void* workspace, int64_t workspace_bytes,
+                                      int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t taps, int32_t dtype,
+                                      im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(x && dz && dw && workspace);
+  if (x_hi) {
+    IM2IM_REQUIRE(Ci_lo > 0 && Ci_lo % 64 == 0 && Ci == 2 * Ci_lo);   // a 64-channel block never straddles the two sources
+  } else {
+    IM2IM_REQUIRE(x_scale_shift_hi == nullptr);
+    Ci_lo = Ci;
+  }
   IM2IM_REQUIRE(B > 0 && H > 0 && W > 0);
   IM2IM_REQUIRE(Ci > 0 && Ci % 64 == 0);
   IM2IM_REQUIRE(Co > 0 && Co % 32 == 0);
@@ -843,10 +916,10 @@ extern "C" int im2im_conv_wgrad(const void* x, const float* x_scale_shift, const
   IM2IM_REQUIRE(dtype == IM2IM_F32 || dtype == IM2IM_BF16);
   float* partial = reinterpret_cast<float*>(workspace);
   if (dtype == IM2IM_BF16)
-    return taps == 9 ? launch_wgrad<bf16_t, 9>(x, x_scale_shift, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream)
-                     : launch_wgrad<bf16_t, 1>(x, x_scale_shift, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream);
-  return taps == 9 ? launch_wgrad<float, 9>(x, x_scale_shift, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream)
-                   : launch_wgrad<float, 1>(x, x_scale_shift, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream);
+    return taps == 9 ? launch_wgrad<bf16_t, 9>(x, x_scale_shift, x_hi, x_scale_shift_hi, Ci_lo, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream)
+                     : launch_wgrad<bf16_t, 1>(x, x_scale_shift, x_hi, x_scale_shift_hi, Ci_lo, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream);
+  return taps == 9 ? launch_wgrad<float, 9>(x, x_scale_shift, x_hi, x_scale_shift_hi, Ci_lo, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream)
+                   : launch_wgrad<float, 1>(x, x_scale_shift, x_hi, x_scale_shift_hi, Ci_lo, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream);
 }
 
 extern "C" int im2im_pack_conv_weight(const float* w, int32_t Co, int32_t Ci, int32_t taps, int32_t dtype, void* wf,

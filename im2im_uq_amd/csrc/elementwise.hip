@@ -376,7 +376,8 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ de
   const int Ct = Cs + Cd;
   const int py = (H - 2 * h) / 2, px = (W - 2 * w) / 2;
   // blockIdx.z == 0: the skip half (copy / lazy activation); == 1: the upsampled half.  Waves are uniform in work.
-  if (blockIdx.z == 0) {
+  // Cs == 0 (no skip half, grid.z == 1): every block upsamples.
+  if (blockIdx.z == 0 && Cs > 0) {
     const int rowvecs = W * rvs.vpr;
     for (int row = blockIdx.y; row < B * H; row += gridDim.y) {
       for (int idx = blockIdx.x * 256 + threadIdx.x; idx < rowvecs; idx += gridDim.x * 256) {
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(256) void upcat_bwd_kernel(const T* __restrict__ do
   constexpr int N = Vec16<T>::N;
   const int Ct = Cs + Cd;
   const int py = (H - 2 * h) / 2, px = (W - 2 * w) / 2;
-  const int rows_skip = B * H, rows_deep = B * h;
+  const int rows_skip = Cs > 0 ? B * H : 0, rows_deep = B * h;
   for (int row = blockIdx.y; row < rows_skip + rows_deep; row += gridDim.y) {
     if (row < rows_skip) {
       const int rowvecs = W * rvs.vpr;
@@ -743,13 +744,14 @@ extern "C" int im2im_upsample2x_concat_fwd(const void* deep, const float* deep_s
                                            const float* skip_scale_shift, void* out, int32_t B, int32_t h, int32_t w,
                                            int32_t Cd, int32_t H, int32_t W, int32_t Cs, int32_t dtype, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  IM2IM_REQUIRE(deep && skip && out && B > 0 && h > 0 && w > 0 && H >= 2 * h && W >= 2 * w);
-  IM2IM_REQUIRE(Cd > 0 && Cs > 0 && Cd % 8 == 0 && Cs % 8 == 0);
+  IM2IM_REQUIRE(deep && out && B > 0 && h > 0 && w > 0 && H >= 2 * h && W >= 2 * w);
+  IM2IM_REQUIRE(Cd > 0 && Cs >= 0 && Cd % 8 == 0 && Cs % 8 == 0);
+  IM2IM_REQUIRE((Cs > 0) == (skip != nullptr));
   return for_dtype(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
-    const RowVec rvs = make_rowvec(Cs / Vec16<T>::N), rvd = make_rowvec(Cd / Vec16<T>::N);
+    const RowVec rvd = make_rowvec(Cd / Vec16<T>::N), rvs = Cs > 0 ? make_rowvec(Cs / Vec16<T>::N) : rvd;
     dim3 grid = row_grid(W * std::max(rvs.vpr, rvd.vpr), B * H);
-    grid.z = 2;
+    grid.z = Cs > 0 ? 2 : 1;
     hipLaunchKernelGGL(upcat_fwd_kernel<T>, grid, dim3(256), 0, stream, (const T*)deep, deep_scale_shift, (const T*)skip, skip_scale_shift, (T*)out, B, h, w, Cd, H, W, Cs, rvs, rvd);
     return check_launch("upcat_fwd_kernel");
   });
@@ -758,12 +760,13 @@ extern "C" int im2im_upsample2x_concat_fwd(const void* deep, const float* deep_s
 extern "C" int im2im_upsample2x_concat_bwd(const void* dout, void* ddeep, void* dskip, int32_t B, int32_t h, int32_t w,
                                            int32_t Cd, int32_t H, int32_t W, int32_t Cs, int32_t dtype, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  IM2IM_REQUIRE(dout && ddeep && dskip && B > 0 && h > 0 && w > 0 && H >= 2 * h && W >= 2 * w);
-  IM2IM_REQUIRE(Cd > 0 && Cs > 0 && Cd % 8 == 0 && Cs % 8 == 0);
+  IM2IM_REQUIRE(dout && ddeep && B > 0 && h > 0 && w > 0 && H >= 2 * h && W >= 2 * w);
+  IM2IM_REQUIRE(Cd > 0 && Cs >= 0 && Cd % 8 == 0 && Cs % 8 == 0);
+  IM2IM_REQUIRE((Cs > 0) == (dskip != nullptr));
   return for_dtype(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
-    const RowVec rvs = make_rowvec(Cs / Vec16<T>::N), rvd = make_rowvec(Cd / Vec16<T>::N);
-    hipLaunchKernelGGL(upcat_bwd_kernel<T>, row_grid(W * rvs.vpr, B * H + B * h), dim3(256), 0, stream, (const T*)dout, (T*)ddeep, (T*)dskip, B, h, w, Cd, H, W, Cs, rvs, rvd);
+    const RowVec rvd = make_rowvec(Cd / Vec16<T>::N), rvs = Cs > 0 ? make_rowvec(Cs / Vec16<T>::N) : rvd;
+    hipLaunchKernelGGL(upcat_bwd_kernel<T>, row_grid(Cs > 0 ? W * rvs.vpr : w * rvd.vpr, (Cs > 0 ? B * H : 0) + B * h), dim3(256), 0, stream, (const T*)dout, (T*)ddeep, (T*)dskip, B, h, w, Cd, H, W, Cs, rvs, rvd);
     return check_launch("upcat_bwd_kernel");
   });
 }

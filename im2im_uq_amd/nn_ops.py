@@ -122,12 +122,25 @@ BF16_CENTERING = False    # opt-in: bf16 train mode stores z - running_mean (im2
                           # whose rounding points the bf16-emulating oracle reproduces
 
 
-def conv_fwd(x, wf, bias=None, scale_shift=None, relu=False, want_stats=False, in_ss=None, center=None):
+def conv_fwd(x, wf, bias=None, scale_shift=None, relu=False, want_stats=False, in_ss=None, center=None, x_hi=None,
+             in_ss_hi=None, split_out=0):
     """x [B,H,W,Ci], wf [Co,taps,Ci] -> y [B,H,W,Co] (+ stats [R,2,Co]).  in_ss [2,Ci]: x is a producer's pre-BN z and
-    the kernel applies max(z*scale+shift, 0) while staging it (lazy BatchNorm+ReLU)."""
+    the kernel applies max(z*scale+shift, 0) while staging it (lazy BatchNorm+ReLU).
+    x_hi: second half of the input channels (the concatenation [x, x_hi] is never materialised); split_out = Co_lo > 0:
+    the output is returned as two tensors (channels [0,Co_lo) and [Co_lo,Co))."""
     b, h, w_, ci = x.shape
+    ci_lo = ci
+    if x_hi is not None:
+        if x_hi.shape != x.shape or x_hi.dtype != x.dtype:
+            raise _lib.Im2ImError(f"conv_fwd: split input halves must match, got {tuple(x.shape)} and {tuple(x_hi.shape)}")
+        ci = 2 * ci
     co, taps = wf.shape[0], wf.shape[1]
-    y = torch.empty((b, h, w_, co), dtype=x.dtype, device=x.device)
+    y_hi = None
+    if split_out:
+        y = torch.empty((b, h, w_, split_out), dtype=x.dtype, device=x.device)
+        y_hi = torch.empty((b, h, w_, co - split_out), dtype=x.dtype, device=x.device)
+    else:
+        y = torch.empty((b, h, w_, co), dtype=x.dtype, device=x.device)
     stats = None
     if want_stats:
         rows = lib.im2im_conv_stats_rows(b, h, w_, co)
@@ -136,16 +149,23 @@ def conv_fwd(x, wf, bias=None, scale_shift=None, relu=False, want_stats=False, i
     if scale_shift is not None:
         sc, sh = scale_shift[0], scale_shift[1]
     ev = TIMER.wrap(_tile_name("igemm", h, w_, co, taps, x.dtype), 2.0 * b * h * w_ * co * ci * taps, x.device) if TIMER else None
-    check(lib.im2im_conv_fwd(dptr(x), dptr(in_ss), dptr(wf), dptr(bias), dptr(center), dptr(sc), dptr(sh), dptr(y), dptr(stats), b, h, w_, ci, co,
-                             taps, int(relu), _DT[x.dtype], stream_ptr(x.device)), "im2im_conv_fwd")
+    check(lib.im2im_conv_fwd_split(dptr(x), dptr(in_ss), dptr(x_hi), dptr(in_ss_hi), ci_lo, dptr(wf), dptr(bias), dptr(center),
+                                   dptr(sc), dptr(sh), dptr(y), dptr(y_hi), int(split_out), dptr(stats), b, h, w_, ci, co,
+                                   taps, int(relu), _DT[x.dtype], stream_ptr(x.device)), "im2im_conv_fwd_split")
     if ev is not None:
         ev.record(torch.cuda.current_stream(x.device))
+    if split_out:
+        return y, y_hi
     return (y, stats) if want_stats else y
 
 
-def conv_wgrad(x, dz, taps, x_ss=None):
-    """x [B,H,W,Ci], dz [B,H,W,Co] -> dw [Co,Ci,taps] fp32 (x_ss: lazy BatchNorm+ReLU of x, as in conv_fwd)."""
+def conv_wgrad(x, dz, taps, x_ss=None, x_hi=None, x_ss_hi=None):
+    """x [B,H,W,Ci], dz [B,H,W,Co] -> dw [Co,Ci,taps] fp32 (x_ss: lazy BatchNorm+ReLU of x, as in conv_fwd; x_hi: second
+    half of the input channels as in conv_fwd)."""
     b, h, w_, ci = x.shape
+    ci_lo = ci
+    if x_hi is not None:
+        ci = 2 * ci
     co = dz.shape[3]
     nbytes = lib.im2im_conv_wgrad_workspace_bytes(b, h, w_, ci, co, taps)
     if nbytes < 0:
@@ -153,8 +173,8 @@ def conv_wgrad(x, dz, taps, x_ss=None):
     ws = _Scratch.get(nbytes, x.device)
     dw = torch.empty((co, ci, taps), dtype=F32, device=x.device)
     ev = TIMER.wrap(_tile_name("wgrad", h, w_, co, taps, x.dtype), 2.0 * b * h * w_ * co * ci * taps, x.device) if TIMER else None
-    check(lib.im2im_conv_wgrad(dptr(x), dptr(x_ss), dptr(dz), dptr(dw), dptr(ws), ws.numel(), b, h, w_, ci, co, taps, _DT[x.dtype],
-                               stream_ptr(x.device)), "im2im_conv_wgrad")
+    check(lib.im2im_conv_wgrad_split(dptr(x), dptr(x_ss), dptr(x_hi), dptr(x_ss_hi), ci_lo, dptr(dz), dptr(dw), dptr(ws), ws.numel(),
+                                     b, h, w_, ci, co, taps, _DT[x.dtype], stream_ptr(x.device)), "im2im_conv_wgrad_split")
     if ev is not None:
         ev.record(torch.cuda.current_stream(x.device))
     return dw
@@ -260,12 +280,15 @@ class ConvStats(torch.autograd.Function):
     normalised output, so its gradient is identically zero here (the reference's autograd yields rounding noise)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, cdt):
+    def forward(ctx, x, x_hi, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, cdt):
+        """x_hi (or None): second half of the input channels -- the Up block's cat([skip, up]) without the copy."""
         _gpu(x, "input")
         co, ci = weight.shape[0], weight.shape[1]
         small = ci <= 8
         b, _, h, w_ = x.shape
         in_ss = lazy_ss(x)
+        in_ss_hi = lazy_ss(x_hi) if x_hi is not None else None
+        xin_hi = nhwc(x_hi.detach(), cdt) if x_hi is not None else None
         center = running_mean if (BF16_CENTERING and cdt == BF16 and running_mean is not None) else None
         if small:
             xin = x.detach().to(F32).contiguous()
@@ -275,31 +298,40 @@ class ConvStats(torch.autograd.Function):
         else:
             xin = nhwc(x.detach(), cdt)
             wf, wd = pack_weight(weight, cdt)
-            z, stats = conv_fwd(xin, wf, bias.detach(), want_stats=True, in_ss=in_ss, center=center)
+            z, stats = conv_fwd(xin, wf, bias.detach(), want_stats=True, in_ss=in_ss, center=center, x_hi=xin_hi, in_ss_hi=in_ss_hi)
         mean_invstd, scale_shift = bn_finalize(stats, b * h * w_, gamma.detach(), beta.detach(), running_mean, running_var,
                                                momentum, eps, centered=center is not None)
         ctx.small = small
-        ctx.has_in_ss = in_ss is not None
+        ctx.has = (in_ss is not None, xin_hi is not None, in_ss_hi is not None)
         ctx.set_materialize_grads(False)              # no zero tensors for the two non-differentiable outputs
-        ctx.save_for_backward(xin, wd if wd is not None else torch.empty(0), in_ss if in_ss is not None else torch.empty(0))
+        none = torch.empty(0)
+        ctx.save_for_backward(xin, wd if wd is not None else none, in_ss if in_ss is not None else none,
+                              xin_hi if xin_hi is not None else none, in_ss_hi if in_ss_hi is not None else none)
         zz = nchw(z)
         ctx.mark_non_differentiable(scale_shift, mean_invstd)
         return zz, scale_shift, mean_invstd
 
     @staticmethod
     def backward(ctx, dz, _g1, _g2):
-        xin, wd, in_ss = ctx.saved_tensors
-        in_ss = in_ss if ctx.has_in_ss else None
+        xin, wd, in_ss, xin_hi, in_ss_hi = ctx.saved_tensors
+        in_ss = in_ss if ctx.has[0] else None
+        xin_hi = xin_hi if ctx.has[1] else None
+        in_ss_hi = in_ss_hi if ctx.has[2] else None
         dz = nhwc(dz, xin.dtype if not ctx.small else dz.dtype)
-        dx = None
+        dx = dx_hi = None
         if ctx.small:
             dw, _ = smallconv_wgrad(xin, dz, l_major=True, want_bias=False)
             dw = dw.view(dz.shape[3], xin.shape[1], 3, 3)
         else:
-            dw = conv_wgrad(xin, dz, 9, x_ss=in_ss).view(dz.shape[3], xin.shape[3], 3, 3)
-            if ctx.needs_input_grad[0]:
+            ci = xin.shape[3] * (2 if xin_hi is not None else 1)
+            dw = conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi).view(dz.shape[3], ci, 3, 3)
+            if xin_hi is not None:
+                # the data-gradient lands directly in d(skip) and d(up): no concatenated gradient tensor
+                dx, dx_hi = conv_fwd(dz, wd, split_out=xin.shape[3])
+                dx, dx_hi = nchw(dx), nchw(dx_hi)
+            elif ctx.needs_input_grad[0]:
                 dx = nchw(conv_fwd(dz, wd))               # gradient w.r.t. the (lazy) input activation
-        return dx, dw, None, None, None, None, None, None, None, None
+        return dx, dx_hi, dw, None, None, None, None, None, None, None, None
 
 
 class BnReluLazy(torch.autograd.Function):
@@ -337,14 +369,14 @@ def materialize(x):
     return x if ss is None else Materialize.apply(x, ss)
 
 
-def conv_bn_relu_train(x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, cdt, lazy_out=False):
-    z, scale_shift, mean_invstd = ConvStats.apply(x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, cdt)
+def conv_bn_relu_train(x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, cdt, lazy_out=False, x_hi=None):
+    z, scale_shift, mean_invstd = ConvStats.apply(x, x_hi, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, cdt)
     a = BnReluLazy.apply(z, gamma, beta, scale_shift, mean_invstd)
     setattr(a, LAZY_ATTR, scale_shift)
     return a if lazy_out else materialize(a)
 
 
-def conv_bn_relu_eval(x, weight, bias, gamma, beta, running_mean, running_var, eps, cdt, cache=None):
+def conv_bn_relu_eval(x, weight, bias, gamma, beta, running_mean, running_var, eps, cdt, cache=None, x_hi=None):
     """eval mode: BatchNorm folded into the conv epilogue (one kernel, no intermediate)."""
     _gpu(x, "input")
     co, ci = weight.shape[0], weight.shape[1]
@@ -354,7 +386,8 @@ def conv_bn_relu_eval(x, weight, bias, gamma, beta, running_mean, running_var, e
         _, wd = pack_weight(weight, F32)
         return nchw(smallconv_s2l(xin, wd, None, fold, co, cdt, relu=True, flip=True))
     wf, _ = pack_weight(weight, cdt, want_wd=False)
-    return nchw(conv_fwd(nhwc(x.detach(), cdt), wf, None, fold, relu=True))
+    return nchw(conv_fwd(nhwc(x.detach(), cdt), wf, None, fold, relu=True,
+                         x_hi=nhwc(x_hi.detach(), cdt) if x_hi is not None else None))
 
 
 class MaxPool2(torch.autograd.Function):
@@ -408,6 +441,40 @@ class UpsampleConcat(torch.autograd.Function):
         check(lib.im2im_upsample2x_concat_bwd(dptr(dout), dptr(ddeep), dptr(dskip), b, h, w_, cd, hh, ww, cs, _DT[dout.dtype],
                                               stream_ptr(dout.device)), "im2im_upsample2x_concat_bwd")
         return nchw(ddeep), nchw(dskip)
+
+
+SPLIT_CONCAT = True       # Up blocks: the first conv reads [skip, upsampled] from two tensors instead of a concatenated copy
+
+
+def can_split_concat(deep, skip) -> bool:
+    """the split-operand kernels need both halves equally wide and a multiple of 64 channels (true for the reference
+    UNet with bilinear=True: 512+512, 256+256, 128+128, 64+64)."""
+    return SPLIT_CONCAT and deep.shape[1] == skip.shape[1] and skip.shape[1] % 64 == 0
+
+
+class Upsample2x(torch.autograd.Function):
+    """zero_pad(bilinear x2 align_corners(deep)) to the skip extent (unet_parts.py:58-66) -- the half of the Up-block
+    concatenation that has to be computed; the skip half is read in place by the consumer conv (conv_fwd x_hi=...)."""
+
+    @staticmethod
+    def forward(ctx, deep, hh, ww):
+        dss = lazy_ss(deep)
+        d = nhwc(deep.detach())
+        b, h, w_, cd = d.shape
+        out = torch.empty((b, hh, ww, cd), dtype=d.dtype, device=d.device)
+        check(lib.im2im_upsample2x_concat_fwd(dptr(d), dptr(dss), None, None, dptr(out), b, h, w_, cd, hh, ww, 0,
+                                              _DT[d.dtype], stream_ptr(d.device)), "im2im_upsample2x_concat_fwd")
+        ctx.shape = (b, h, w_, cd, hh, ww)
+        return nchw(out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        b, h, w_, cd, hh, ww = ctx.shape
+        dout = nhwc(dout)
+        ddeep = torch.empty((b, h, w_, cd), dtype=dout.dtype, device=dout.device)
+        check(lib.im2im_upsample2x_concat_bwd(dptr(dout), dptr(ddeep), None, b, h, w_, cd, hh, ww, 0, _DT[dout.dtype],
+                                              stream_ptr(dout.device)), "im2im_upsample2x_concat_bwd")
+        return nchw(ddeep), None, None
 
 
 class Conv1x1(torch.autograd.Function):

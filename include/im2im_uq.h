@@ -116,6 +116,20 @@ int im2im_conv_fwd(const void* x, const float* in_scale_shift, const void* wf, c
                    int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t taps, int32_t relu,
                    int32_t dtype, im2im_stream_t stream);
 
+/* Channel-split operands: the Up block's torch.cat([x2, x1], dim=1) (unet_parts.py:68) is never materialised.
+ *   x_hi (may be NULL): the convolution's input channels [Ci_lo, Ci) are read from x_hi and [0, Ci_lo) from x; both
+ *     tensors are [B][H][W][Ci_lo] (Ci == 2*Ci_lo: skip and upsampled halves of the UNet have equal width), each with
+ *     its own optional lazy coefficients (in_scale_shift [2][Ci_lo], in_scale_shift_hi [2][Ci_lo]).
+ *   y_hi (may be NULL): output channels [Co_lo, Co) are written to y_hi [B][H][W][Co-Co_lo], [0, Co_lo) to
+ *     y [B][H][W][Co_lo] (Co_lo and Co-Co_lo multiples of 64): the data-gradient of such a convolution lands
+ *     directly in d(skip) and d(upsampled) without a concatenated gradient tensor.  stats/scale/shift must be NULL.
+ *   With x_hi == y_hi == NULL this is im2im_conv_fwd. */
+int im2im_conv_fwd_split(const void* x, const float* in_scale_shift, const void* x_hi,
+                         const float* in_scale_shift_hi, int32_t Ci_lo, const void* wf, const float* bias,
+                         const float* center, const float* scale, const float* shift, void* y, void* y_hi,
+                         int32_t Co_lo, float* stats, int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                         int32_t taps, int32_t relu, int32_t dtype, im2im_stream_t stream);
+
 /* dw[co][ci][tap] (fp32, torch layout) = sum_{b,h,w} dz[b,h,w,co] * x[b,h+kh-1,w+kw-1,ci]
  *   Ci % 64 == 0, Co % 32 == 0.  workspace: im2im_conv_wgrad_workspace_bytes(...) bytes (split-K slabs,
  *   reduced deterministically). */
@@ -123,6 +137,11 @@ int64_t im2im_conv_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_
 int im2im_conv_wgrad(const void* x, const float* x_scale_shift, const void* dz, float* dw, void* workspace,
                      int64_t workspace_bytes, int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co,
                      int32_t taps, int32_t dtype, im2im_stream_t stream);
+/* weight gradient of a convolution with channel-split input (see im2im_conv_fwd_split); Ci_lo % 64 == 0. */
+int im2im_conv_wgrad_split(const void* x, const float* x_scale_shift, const void* x_hi,
+                           const float* x_scale_shift_hi, int32_t Ci_lo, const void* dz, float* dw, void* workspace,
+                           int64_t workspace_bytes, int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                           int32_t taps, int32_t dtype, im2im_stream_t stream);
 
 
 /* Shared scratch for the deterministic two-stage "sum over pixels" reductions: bytes needed to reduce
@@ -170,7 +189,9 @@ int im2im_maxpool2_bwd(const void* x, const float* in_scale_shift, const void* d
 
 /* Up-block input (unet_parts.py:58-68): out = cat([skip, zero_pad(bilinear_x2_align_corners(deep))])
  * on the channel axis, NHWC.  deep [B][h][w][Cd], skip [B][H][W][Cs], out [B][H][W][Cs+Cd], H >= 2h, W >= 2w.
- * bwd: dskip = dout[..., :Cs]; ddeep = transpose of the interpolation (gathered, no atomics). */
+ * bwd: dskip = dout[..., :Cs]; ddeep = transpose of the interpolation (gathered, no atomics).
+ * Cs == 0 (skip / skip_scale_shift / dskip NULL): plain upsample + pad, out/dout [B][H][W][Cd] -- used with
+ * im2im_conv_fwd_split, which reads the skip half in place. */
 int im2im_upsample2x_concat_fwd(const void* deep, const float* deep_scale_shift, const void* skip,
                                 const float* skip_scale_shift, void* out, int32_t B, int32_t h, int32_t w,
                                 int32_t Cd, int32_t H, int32_t W, int32_t Cs, int32_t dtype,

@@ -82,6 +82,68 @@ def test_conv_fwd_dgrad_wgrad(case, dt):
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("case", [(2, 20, 24, 64, 64), (1, 70, 66, 64, 128), (3, 16, 16, 128, 32), (1, 80, 40, 256, 64)])
+def test_split_operand_conv_is_bit_identical_to_concatenated(case, dt):
+    """The Up block's cat([skip, up], 1) (unet_parts.py:68) is not materialised: forward and weight-gradient read the
+    two halves from separate tensors (each with its own lazy BatchNorm coefficients), the data-gradient writes
+    d(skip) and d(up) separately.  Same arithmetic in the same order as on the concatenated tensor => identical bits."""
+    from im2im_uq_amd import nn_ops
+    b, h, w, c, co = case
+    lo = rnd(b, h, w, c, seed=1).to(dt).to(DEV)                    # pre-BatchNorm z of the skip (lazy)
+    hi = rnd(b, h, w, c, seed=2).abs().to(dt).to(DEV)              # upsampled half: a plain, non-negative activation
+    ss_lo = torch.stack([1.0 + 0.1 * rnd(c, seed=3), 0.2 * rnd(c, seed=4)]).to(DEV)
+    wt = rnd(co, 2 * c, 3, 3, seed=5, scale=0.05).to(DEV)
+    bias = rnd(co, seed=6).to(DEV)
+    wf, wd = nn_ops.pack_weight(wt, dt)
+    # concatenated reference operand: materialise the lazy half exactly as bn_relu_apply does, then cat
+    cat = torch.cat([nn_ops.bn_relu_apply(lo, ss_lo), hi], dim=3).contiguous()
+    y_ref, st_ref = nn_ops.conv_fwd(cat, wf, bias, want_stats=True)
+    y, st = nn_ops.conv_fwd(lo, wf, bias, want_stats=True, in_ss=ss_lo, x_hi=hi)
+    assert torch.equal(y, y_ref) and torch.equal(st, st_ref)
+    # both halves lazy
+    ss_hi = torch.stack([1.0 + 0.1 * rnd(c, seed=7), 0.2 * rnd(c, seed=8)]).to(DEV)
+    cat2 = torch.cat([nn_ops.bn_relu_apply(lo, ss_lo), nn_ops.bn_relu_apply(hi, ss_hi)], dim=3).contiguous()
+    assert torch.equal(nn_ops.conv_fwd(lo, wf, bias, in_ss=ss_lo, x_hi=hi, in_ss_hi=ss_hi), nn_ops.conv_fwd(cat2, wf, bias))
+    # eval epilogue (folded BatchNorm + ReLU) on plain halves
+    fold = torch.stack([1.0 + 0.1 * rnd(co, seed=9), 0.1 * rnd(co, seed=10)]).to(DEV)
+    cat3 = torch.cat([hi, hi.flip(0)], dim=3).contiguous()
+    assert torch.equal(nn_ops.conv_fwd(hi, wf, None, fold, relu=True, x_hi=hi.flip(0).contiguous()),
+                       nn_ops.conv_fwd(cat3, wf, None, fold, relu=True))
+    # weight gradient
+    dz = rnd(b, h, w, co, seed=11).to(dt).to(DEV)
+    assert torch.equal(nn_ops.conv_wgrad(lo, dz, 9, x_ss=ss_lo, x_hi=hi), nn_ops.conv_wgrad(cat, dz, 9))
+    assert torch.equal(nn_ops.conv_wgrad(lo, dz, 9, x_ss=ss_lo, x_hi=hi, x_ss_hi=ss_hi), nn_ops.conv_wgrad(cat2, dz, 9))
+    # data gradient split over two destination tensors
+    dx_ref = nn_ops.conv_fwd(dz, wd)
+    dx_lo, dx_hi = nn_ops.conv_fwd(dz, wd, split_out=c)
+    assert torch.equal(dx_lo, dx_ref[..., :c]) and torch.equal(dx_hi, dx_ref[..., c:])
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_upsample2x_alone_matches_concat_kernel_and_torch(dt):
+    """im2im_upsample2x_concat_* with Cs = 0: bilinear x2 (align_corners) + zero pad without the skip copy."""
+    from im2im_uq_amd import nn_ops
+    b, h, w, c, hh, ww = 2, 9, 7, 64, 19, 15
+    deep = rnd(b, c, h, w, seed=1).abs()
+    d_dev = deep.permute(0, 2, 3, 1).contiguous().to(dt).to(DEV).permute(0, 3, 1, 2).requires_grad_(True)
+    skip = torch.zeros(b, c, hh, ww).permute(0, 2, 3, 1).contiguous().to(dt).to(DEV).permute(0, 3, 1, 2)
+    up = nn_ops.Upsample2x.apply(d_dev, hh, ww)
+    cat = nn_ops.UpsampleConcat.apply(d_dev.detach(), skip)
+    assert torch.equal(up, cat[:, c:])
+    ref = F.interpolate(q(deep, dt), scale_factor=2, mode="bilinear", align_corners=True)
+    ref = F.pad(ref, [(ww - 2 * w) // 2, ww - 2 * w - (ww - 2 * w) // 2, (hh - 2 * h) // 2, hh - 2 * h - (hh - 2 * h) // 2])
+    assert rel_l2(up.detach().float().cpu(), ref) < tol(dt)
+    g = rnd(b, c, hh, ww, seed=3)
+    g_dev = g.permute(0, 2, 3, 1).contiguous().to(dt).to(DEV).permute(0, 3, 1, 2)
+    up.backward(g_dev)
+    dref = deep.clone().requires_grad_(True)
+    r = F.pad(F.interpolate(dref, scale_factor=2, mode="bilinear", align_corners=True),
+              [(ww - 2 * w) // 2, ww - 2 * w - (ww - 2 * w) // 2, (hh - 2 * h) // 2, hh - 2 * h - (hh - 2 * h) // 2])
+    r.backward(q(g, dt))
+    assert rel_l2(d_dev.grad.float().cpu(), dref.grad) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
 @pytest.mark.parametrize("shape", [(2, 1, 37, 29, 64), (1, 2, 48, 48, 64), (2, 3, 16, 20, 32), (1, 6, 33, 18, 32)])
 def test_smallconv_family(shape, dt):
     from im2im_uq_amd import nn_ops

@@ -278,13 +278,16 @@ def test_full_size_320_smoke_properties_bf16():
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
-def test_lazy_batchnorm_path_is_bit_identical_to_materialised(dt):
+def test_lazy_batchnorm_path_is_bit_identical_to_materialised(dt, monkeypatch):
     """UNet.forward keeps activations lazy (pre-BatchNorm z + scale/shift applied by the consumer kernels); chaining the
     same blocks through their public, materialising forward must give bit-identical outputs and parameter gradients."""
     from oracle import model as om
     x, y = om.det_images(3, 1, 48, 48, salt=4)
     res = []
+    from im2im_uq_amd import nn_ops
     for lazy in (True, False):
+        # the materialised arm also concatenates [skip, up] into one tensor instead of letting the conv read both halves
+        monkeypatch.setattr(nn_ops, "SPLIT_CONCAT", lazy)
         model = build(1, dt)
         model.train()
         u = model.baseModel
