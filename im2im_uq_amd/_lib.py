@@ -56,6 +56,8 @@ SIGNATURES = {
     "im2im_bn_fold_eval": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _f32, _i32, _ptr, _ptr]),
     "im2im_bn_relu_apply": (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr]),
     "im2im_bn_bwd_workspace_bytes": (_i64, [_i64, _i32]),
+    "im2im_bn_relu_pool_bwd_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
+    "im2im_bn_relu_pool_bwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr, _i64, _ptr]),
     "im2im_bn_relu_bwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i64, _ptr]),
     "im2im_colsum_workspace_bytes": (_i64, [_i64, _i32]),
     "im2im_colsum": (_i32, [_ptr, _ptr, _i64, _i32, _i32, _ptr, _i64, _ptr]),

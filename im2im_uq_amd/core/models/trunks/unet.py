@@ -32,11 +32,13 @@ class UNet(nn.Module):
     def forward(self, x):
         # lazy=True: between these blocks activations stay "pre-BatchNorm + (scale, shift)"; every consumer below is one
         # of this package's kernels and applies BatchNorm+ReLU on the fly (see DoubleConv.forward)
-        x1 = self.inc(x, lazy=True)
-        x2 = self.down1(x1, lazy=True)
-        x3 = self.down2(x2, lazy=True)
-        x4 = self.down3(x3, lazy=True)
-        x5 = self.down4(x4, lazy=True)
+        # pool=True: a skip block also hands back MaxPool2d(2) of its output for the next Down block (pooled=True), so the
+        # pooling's backward and the skip-gradient accumulation fold into that block's BatchNorm backward kernels
+        x1, p1 = self.inc(x, lazy=True, pool=True)
+        x2, p2 = self.down1(p1, lazy=True, pool=True, pooled=True)
+        x3, p3 = self.down2(p2, lazy=True, pool=True, pooled=True)
+        x4, p4 = self.down3(p3, lazy=True, pool=True, pooled=True)
+        x5 = self.down4(p4, lazy=True, pooled=True)
 
         x = self.up1(x5, x4, lazy=True)
         x = self.up2(x, x3, lazy=True)

@@ -41,8 +41,10 @@ class DoubleConv(nn.Module):
         )
         self.compute_dtype = None
 
-    def forward(self, x, lazy=False, x_hi=None):
+    def forward(self, x, lazy=False, x_hi=None, pool=False):
         """x_hi: second half of the input channels when the caller did not concatenate them (Up.forward).
+        pool=True: return (result, MaxPool2d(2)(result)) -- for a skip-connection block whose output also feeds the next
+        Down block; in training the pooling's backward is then folded into this block's BatchNorm backward.
         lazy=True (used between this package's own blocks): in training the result is a *lazy activation* -- it
         holds the pre-BatchNorm conv output and the consumers (next conv / max-pool / upsample-concat / 1x1 conv
         kernels) apply BatchNorm+ReLU while loading it, so the normalised tensor is never written to HBM.  The
@@ -53,7 +55,8 @@ class DoubleConv(nn.Module):
             if self.training:
                 momentum = bn.momentum if bn.momentum is not None else 0.1
                 x = nn_ops.conv_bn_relu_train(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
-                                              bn.running_var, momentum, bn.eps, cdt, lazy_out=(lazy or ci == 0), x_hi=x_hi)
+                                              bn.running_var, momentum, bn.eps, cdt, lazy_out=(lazy or ci == 0), x_hi=x_hi,
+                                              pool=(pool and ci == 3))
                 bn.num_batches_tracked += 1
             else:
                 if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad and False):
@@ -61,6 +64,8 @@ class DoubleConv(nn.Module):
                 x = nn_ops.conv_bn_relu_eval(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                                              bn.running_var, bn.eps, cdt, x_hi=x_hi)
             x_hi = None
+        if pool and not isinstance(x, tuple):
+            x = (x, nn_ops.MaxPool2.apply(x))
         return x
 
 
@@ -79,8 +84,11 @@ class Down(nn.Module):
             DoubleConv(in_channels, out_channels)
         )
 
-    def forward(self, x, lazy=False):
-        return self.maxpool_conv[1](self.maxpool_conv[0](x), lazy=lazy)
+    def forward(self, x, lazy=False, pool=False, pooled=False):
+        """pooled=True: x is already MaxPool2d(2) of the previous block's output (it came from that block's pool=True)."""
+        if not pooled:
+            x = self.maxpool_conv[0](x)
+        return self.maxpool_conv[1](x, lazy=lazy, pool=pool)
 
 
 class _BilinearUp(nn.Module):

@@ -355,6 +355,111 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// BatchNorm+ReLU backward of a skip-connection layer, fused with the backward of the MaxPool2d that consumes the same
+// activation (unet.py:35-38: x1..x4 feed both Down.maxpool and Up.cat).  The incoming gradient of the activation is
+//   g = da (from the Up block's conv, may be null) + scatter_to_argmax(dpool)
+// and is never written to HBM: each thread owns one 2x2 window x one channel vector, recomputes the window's
+// activations from z (lazy BatchNorm+ReLU, rounded to the storage type exactly as maxpool2_fwd saw them), finds the
+// first maximum (torch's tie rule), forms g in the storage type's rounding (what the separate add kernel would have
+// stored) and goes straight on with the BatchNorm backward.  APPLY = false: partial sums of g*mask and g*mask*xhat
+// (partial[block][2][C], fixed-order LDS combine => deterministic); APPLY = true: dz.
+// Windows include the odd last row/column (those pixels are not pooled and receive da only).
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const T* __restrict__ da, const T* __restrict__ dpool,
+                                                                const T* __restrict__ z, const float* __restrict__ scale_shift,
+                                                                const float* __restrict__ mean_invstd,
+                                                                const float* __restrict__ coef, T* __restrict__ dz,
+                                                                float* __restrict__ partial, int B, int H, int W, int C,
+                                                                RowVec rv) {
+  constexpr int N = Vec16<T>::N;
+  __shared__ float s_part[APPLY ? 1 : 256][2 * N + 1];
+  const int Ho = H / 2, Wo = W / 2, Hc = (H + 1) / 2, Wc = (W + 1) / 2;
+  const int vpr = rv.vpr;                                  // power of two, divides 256: a thread keeps one channel vector
+  const int cv = threadIdx.x & (vpr - 1);
+  const int c0 = cv * N;
+  float sc[N], sh[N], mu[N], is[N], k1[N], k2[N], s1[N], s2[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    sc[k] = scale_shift[c0 + k]; sh[k] = scale_shift[C + c0 + k];
+    mu[k] = mean_invstd[c0 + k]; is[k] = mean_invstd[C + c0 + k];
+    k1[k] = APPLY ? coef[c0 + k] : 0.f; k2[k] = APPLY ? coef[C + c0 + k] : 0.f;
+    s1[k] = 0.f; s2[k] = 0.f;
+  }
+  const int rowvecs = Wc * vpr;
+  for (int row = blockIdx.y; row < B * Hc; row += gridDim.y) {
+    const int b = row / Hc, yo = row - b * Hc;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < rowvecs; idx += gridDim.x * 256) {
+      const int xo = idx >> rv.vshift;
+      const bool pooled = yo < Ho && xo < Wo;
+      float zz[4][N], g[4][N];
+      bool ok[4];
+      int64_t off[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int yy = 2 * yo + (q >> 1), xx = 2 * xo + (q & 1);
+        ok[q] = yy < H && xx < W;
+        off[q] = ((((int64_t)b * H + yy) * W + xx) * (int64_t)C) + c0;
+        if (ok[q]) {
+          Vec16<T>::load(z + off[q], zz[q]);
+          if (da) Vec16<T>::load(da + off[q], g[q]);
+        }
+        if (!ok[q] || !da) {
+#pragma unroll
+          for (int k = 0; k < N; ++k) g[q][k] = 0.f;
+        }
+      }
+      if (pooled) {
+        float gp[N], a[4][N];
+        Vec16<T>::load(dpool + ((((int64_t)b * Ho + yo) * Wo + xo) * (int64_t)C) + c0, gp);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int k = 0; k < N; ++k) a[q][k] = fmaxf(zz[q][k] * sc[k] + sh[k], 0.f);
+          round_store_type<T, N>(a[q]);
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          int am = 0; float m = a[0][k];
+          if (a[1][k] > m) { m = a[1][k]; am = 1; }
+          if (a[2][k] > m) { m = a[2][k]; am = 2; }
+          if (a[3][k] > m) { m = a[3][k]; am = 3; }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) g[q][k] += (am == q) ? gp[k] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) round_store_type<T, N>(g[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (!ok[q]) continue;
+        float o[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          const float gg = (zz[q][k] * sc[k] + sh[k] > 0.f) ? g[q][k] : 0.f;
+          const float xhat = (zz[q][k] - mu[k]) * is[k];
+          if constexpr (APPLY) o[k] = sc[k] * (gg - k1[k] - xhat * k2[k]);
+          else { s1[k] += gg; s2[k] += gg * xhat; }
+        }
+        if constexpr (APPLY) Vec16<T>::store(dz + off[q], o);
+      }
+    }
+  }
+  if constexpr (!APPLY) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) { s_part[threadIdx.x][k] = s1[k]; s_part[threadIdx.x][N + k] = s2[k]; }
+    __syncthreads();
+    const int groups = 256 / vpr;
+    const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    for (int j = threadIdx.x; j < 2 * C; j += 256) {
+      const int which = j / C, c = j % C;
+      float acc = 0.f;
+      for (int gi = 0; gi < groups; ++gi) acc += s_part[gi * vpr + c / N][which * N + c % N];
+      partial[blk * 2 * C + j] = acc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Up block input (unet_parts.py:58-68): cat([skip, pad(upsample_bilinear_x2_align_corners(deep))], C)
 //   deep [B][h][w][Cd], skip [B][H][W][Cs] -> out [B][H][W][Cs+Cd]; pad offsets (H-2h)/2, (W-2w)/2.
 __device__ __forceinline__ void bilinear_src(int dst, int in_size, int out_size, int& i0, int& i1, float& l0, float& l1) {
@@ -685,6 +790,57 @@ extern "C" int im2im_bn_relu_bwd(const void* da, const void* z, const float* sca
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, stream, (const T*)da, (const T*)z,
                        scale_shift, mean_invstd, coef, (T*)dz, nvec, (int)C);
     return check_launch("bn_relu_bwd_apply_kernel");
+  });
+}
+
+namespace {
+inline dim3 pool_bwd_grid(int B, int H, int W, int vpr) {
+  const int Hc = (H + 1) / 2, Wc = (W + 1) / 2;
+  int gx = (int)cdiv((int64_t)Wc * vpr, 256);
+  if (gx > 16) gx = 16;
+  int64_t gy = std::min<int64_t>((int64_t)B * Hc, std::max<int64_t>(2048 / gx, 1));
+  return dim3((unsigned)gx, (unsigned)gy);
+}
+}  // namespace
+
+extern "C" int64_t im2im_bn_relu_pool_bwd_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C) {
+  const int64_t nblk = 2048 + 16;                               // upper bound of pool_bwd_grid's block count
+  return nblk * 2 * C * (int64_t)sizeof(float) + reduce_tmp_bytes(2 * (int64_t)C) + 2 * (int64_t)C * sizeof(float);
+}
+
+extern "C" int im2im_bn_relu_pool_bwd(const void* da, const void* dpool, const void* z, const float* scale_shift,
+                                      const float* mean_invstd, void* dz, float* dgamma, float* dbeta, int32_t B, int32_t H,
+                                      int32_t W, int32_t C, int32_t dtype, void* ws, int64_t ws_bytes, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(dpool && z && scale_shift && mean_invstd && dz && dgamma && dbeta && ws);
+  IM2IM_REQUIRE(B > 0 && H >= 2 && W >= 2 && C > 0);
+  IM2IM_REQUIRE(dtype == IM2IM_F32 || dtype == IM2IM_BF16);
+  const int n = dtype == IM2IM_BF16 ? 8 : 4;
+  IM2IM_REQUIRE(C % n == 0);
+  const int vpr = C / n;
+  IM2IM_REQUIRE((vpr & (vpr - 1)) == 0 && vpr <= 256);           // one fixed channel vector per thread
+  IM2IM_REQUIRE(ws_bytes >= im2im_bn_relu_pool_bwd_workspace_bytes(B, H, W, C));
+  const dim3 grid = pool_bwd_grid(B, H, W, vpr);
+  const int64_t nblk = (int64_t)grid.x * grid.y;
+  float* partial = (float*)ws;
+  double* tmp = (double*)((char*)ws + (int64_t)(2048 + 16) * 2 * C * sizeof(float));
+  float* coef = (float*)((char*)tmp + reduce_tmp_bytes(2 * (int64_t)C));
+  const double count = (double)B * H * W;
+  return for_dtype(dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    const RowVec rv = make_rowvec(vpr);
+    hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<T, false>), grid, dim3(256), 0, stream, (const T*)da, (const T*)dpool, (const T*)z,
+                       scale_shift, mean_invstd, (const float*)nullptr, (T*)nullptr, partial, B, H, W, (int)C, rv);
+    if (int rc = check_launch("bn_relu_pool_bwd_kernel<reduce>")) return rc;
+    int rc;
+    const int S = launch_reduce_stage1(partial, nblk, 2 * (int64_t)C, tmp, stream, &rc);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, stream, (const double*)tmp, S, (int)C,
+                       count, dgamma, dbeta, coef);
+    if (int rc2 = check_launch("bn_bwd_finalize_kernel")) return rc2;
+    hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<T, true>), grid, dim3(256), 0, stream, (const T*)da, (const T*)dpool, (const T*)z,
+                       scale_shift, mean_invstd, (const float*)coef, (T*)dz, (float*)nullptr, B, H, W, (int)C, rv);
+    return check_launch("bn_relu_pool_bwd_kernel<apply>");
   });
 }
 

@@ -222,6 +222,20 @@ def bn_relu_bwd(da, z, scale_shift, mean_invstd):
     return dz, dgamma, dbeta
 
 
+def bn_relu_pool_bwd(da, dpool, z, scale_shift, mean_invstd):
+    """BatchNorm+ReLU backward with the gradient g = da (or None) + maxpool2-backward(dpool) formed on the fly."""
+    b, h, w_, c = z.shape
+    dev = z.device
+    dz = torch.empty_like(z)
+    dgamma = torch.empty((c,), dtype=F32, device=dev)
+    dbeta = torch.empty((c,), dtype=F32, device=dev)
+    ws = _Scratch.get(lib.im2im_bn_relu_pool_bwd_workspace_bytes(b, h, w_, c), dev)
+    check(lib.im2im_bn_relu_pool_bwd(dptr(da), dptr(dpool), dptr(z), dptr(scale_shift), dptr(mean_invstd), dptr(dz), dptr(dgamma),
+                                     dptr(dbeta), b, h, w_, c, _DT[z.dtype], dptr(ws), ws.numel(), stream_ptr(dev)),
+          "im2im_bn_relu_pool_bwd")
+    return dz, dgamma, dbeta
+
+
 def colsum(x):
     c = x.shape[-1]
     m = x.numel() // c
@@ -352,6 +366,43 @@ class BnReluLazy(torch.autograd.Function):
         return nchw(dz), dgamma, dbeta, None, None
 
 
+FUSE_POOL_BWD = True      # skip layers: max-pool backward + gradient add folded into the BatchNorm backward kernels
+
+
+def can_fuse_pool_bwd(z) -> bool:
+    vpr = z.shape[1] // (8 if z.dtype == BF16 else 4)
+    return FUSE_POOL_BWD and vpr > 0 and (vpr & (vpr - 1)) == 0 and vpr <= 256 and z.shape[2] >= 2 and z.shape[3] >= 2
+
+
+class BnReluLazyPool(torch.autograd.Function):
+    """BnReluLazy for an activation that feeds a skip connection AND Down.maxpool (unet.py:35-38): returns the lazy
+    activation and MaxPool2d(2) of it; backward takes both gradients and runs ONE fused BatchNorm+ReLU backward that
+    scatters the pooled gradient to the window maxima and adds the skip gradient on the fly (no max-pool backward
+    tensor, no gradient-accumulation add)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, scale_shift, mean_invstd):
+        zz = nhwc(z.detach())
+        b, h, w_, c = zz.shape
+        y = torch.empty((b, h // 2, w_ // 2, c), dtype=zz.dtype, device=zz.device)
+        check(lib.im2im_maxpool2_fwd(dptr(zz), dptr(scale_shift), dptr(y), b, h, w_, c, _DT[zz.dtype], stream_ptr(zz.device)),
+              "im2im_maxpool2_fwd")
+        ctx.save_for_backward(z, scale_shift, mean_invstd)
+        ctx.set_materialize_grads(False)
+        return z.detach().view_as(z), nchw(y)
+
+    @staticmethod
+    def backward(ctx, da, dpool):
+        z, scale_shift, mean_invstd = ctx.saved_tensors
+        zz = nhwc(z)
+        if dpool is None:
+            dz, dgamma, dbeta = bn_relu_bwd(nhwc(da, zz.dtype), zz, scale_shift, mean_invstd)
+        else:
+            dz, dgamma, dbeta = bn_relu_pool_bwd(nhwc(da, zz.dtype) if da is not None else None, nhwc(dpool, zz.dtype), zz,
+                                                 scale_shift, mean_invstd)
+        return nchw(dz), dgamma, dbeta, None, None
+
+
 class Materialize(torch.autograd.Function):
     """turn a lazy activation into a plain tensor (one BatchNorm+ReLU pass); identity for the gradient."""
 
@@ -369,11 +420,18 @@ def materialize(x):
     return x if ss is None else Materialize.apply(x, ss)
 
 
-def conv_bn_relu_train(x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, cdt, lazy_out=False, x_hi=None):
+def conv_bn_relu_train(x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, cdt, lazy_out=False, x_hi=None,
+                       pool=False):
+    """pool=True (lazy_out only): also return MaxPool2d(2) of the activation -> (a, pooled)."""
     z, scale_shift, mean_invstd = ConvStats.apply(x, x_hi, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, cdt)
+    if pool and lazy_out and can_fuse_pool_bwd(z):
+        a, pooled = BnReluLazyPool.apply(z, gamma, beta, scale_shift, mean_invstd)
+        setattr(a, LAZY_ATTR, scale_shift)
+        return a, pooled
     a = BnReluLazy.apply(z, gamma, beta, scale_shift, mean_invstd)
     setattr(a, LAZY_ATTR, scale_shift)
-    return a if lazy_out else materialize(a)
+    a = a if lazy_out else materialize(a)
+    return (a, MaxPool2.apply(a)) if pool else a
 
 
 def conv_bn_relu_eval(x, weight, bias, gamma, beta, running_mean, running_var, eps, cdt, cache=None, x_hi=None):

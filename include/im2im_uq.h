@@ -176,6 +176,18 @@ int im2im_bn_relu_bwd(const void* da, const void* z, const float* scale_shift, c
                       void* dz, float* dgamma, float* dbeta, int64_t M, int32_t C, int32_t dtype,
                       void* ws, int64_t ws_bytes, im2im_stream_t stream);
 
+/* BatchNorm+ReLU backward of a skip-connection layer fused with the backward of the MaxPool2d(2) that consumes the
+ * same activation (unet.py:35-38; unet_parts.py:34 / 17-18,20-21): the activation's gradient
+ *   g = da (gradient from the Up block, [B][H][W][C], may be NULL) + scatter_to_window_argmax(dpool [B][H/2][W/2][C])
+ * is formed on the fly (first maximum wins, as torch; same storage-type rounding as the separate max-pool backward
+ * + add would produce) and never written to HBM.  z [B][H][W][C] pre-BN, dz out; C/(16 B / elem) a power of two.
+ * Outputs as im2im_bn_relu_bwd. */
+int64_t im2im_bn_relu_pool_bwd_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C);
+int im2im_bn_relu_pool_bwd(const void* da, const void* dpool, const void* z, const float* scale_shift,
+                           const float* mean_invstd, void* dz, float* dgamma, float* dbeta, int32_t B,
+                           int32_t H, int32_t W, int32_t C, int32_t dtype, void* ws, int64_t ws_bytes,
+                           im2im_stream_t stream);
+
 /* out[c] = sum_m x[m][c] (bias gradient of the 1x1 out conv, unet_parts.py:90). */
 int64_t im2im_colsum_workspace_bytes(int64_t M, int32_t C);
 int im2im_colsum(const void* x, float* out, int64_t M, int32_t C, int32_t dtype, void* ws,

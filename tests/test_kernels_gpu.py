@@ -224,6 +224,36 @@ def test_batchnorm_relu_fwd_bwd(shape, dt):
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("shape", [(2, 20, 24, 64), (1, 33, 31, 128), (3, 9, 8, 512)])
+@pytest.mark.parametrize("with_da", [True, False])
+def test_fused_pool_batchnorm_backward_vs_torch(shape, dt, with_da):
+    """im2im_bn_relu_pool_bwd == autograd of [a = relu(bn(z)); loss = <a, da> + <maxpool2(a), dpool>] (odd extents too)."""
+    from im2im_uq_amd import nn_ops
+    b, h, w, c = shape
+    z = q(rnd(b, h, w, c, seed=1), dt)
+    gamma, beta = 1.0 + 0.2 * rnd(c, seed=2), 0.1 * rnd(c, seed=3)
+    da = q(rnd(b, h, w, c, seed=4), dt)
+    dpool = q(rnd(b, h // 2, w // 2, c, seed=5), dt)
+    mean = z.mean(dim=(0, 1, 2))
+    var = z.var(dim=(0, 1, 2), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    ss = torch.stack([gamma * invstd, beta - mean * gamma * invstd])
+    mi = torch.stack([mean, invstd])
+    dz, dgamma, dbeta = nn_ops.bn_relu_pool_bwd(da.to(dt).to(DEV) if with_da else None, dpool.to(dt).to(DEV), z.to(dt).to(DEV),
+                                                ss.to(DEV), mi.to(DEV))
+    zr = z.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    a = F.relu(F.batch_norm(zr.permute(0, 3, 1, 2), None, None, gr, br, training=True, eps=1e-5))
+    obj = (F.max_pool2d(a, 2) * dpool.permute(0, 3, 1, 2)).sum()
+    if with_da:
+        obj = obj + (a * da.permute(0, 3, 1, 2)).sum()
+    obj.backward()
+    t = 5e-5 if dt == F32 else 2e-2
+    assert rel_l2(dz.float().cpu(), zr.grad) < t
+    assert rel_l2(dgamma.cpu(), gr.grad) < t and rel_l2(dbeta.cpu(), br.grad) < t
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
 def test_maxpool_and_upsample_concat(dt):
     from im2im_uq_amd import nn_ops
     for (b, c, h, w) in [(2, 64, 16, 20), (1, 32, 7, 9), (1, 128, 40, 40)]:

@@ -288,6 +288,8 @@ def test_lazy_batchnorm_path_is_bit_identical_to_materialised(dt, monkeypatch):
     for lazy in (True, False):
         # the materialised arm also concatenates [skip, up] into one tensor instead of letting the conv read both halves
         monkeypatch.setattr(nn_ops, "SPLIT_CONCAT", lazy)
+        # the fused max-pool/BatchNorm backward sums its statistics in another order (tolerance-checked below instead)
+        monkeypatch.setattr(nn_ops, "FUSE_POOL_BWD", False)
         model = build(1, dt)
         model.train()
         u = model.baseModel
@@ -305,6 +307,27 @@ def test_lazy_batchnorm_path_is_bit_identical_to_materialised(dt, monkeypatch):
     assert torch.equal(res[0][0], res[1][0])
     for n in res[0][1]:
         assert torch.equal(res[0][1][n], res[1][1][n]), n
+
+
+@pytest.mark.parametrize("dt,tolerance", [("fp32", 2e-5), ("bf16", 2e-2)])
+def test_fused_pool_batchnorm_backward_matches_unfused(dt, tolerance, monkeypatch):
+    """Skip layers fold MaxPool2d backward + the skip-gradient add into their BatchNorm backward (nn_ops.BnReluLazyPool).
+    Same forward bits; gradients agree with the unfused kernels up to the summation order of the BatchNorm statistics
+    (fp32: 2e-5 rel-L2; bf16: a changed last bit of dz can flip roundings downstream, 2e-2)."""
+    from oracle import model as om
+    from im2im_uq_amd import nn_ops
+    x, y = om.det_images(3, 1, 50, 46, salt=5)          # odd pooled extents on the way down: 50 -> 25 -> 12 -> 6 -> 3
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(nn_ops, "FUSE_POOL_BWD", fused)
+        model = build(1, dt)
+        model.train()
+        pred = model(x.to(DEV))
+        model.loss_fn(pred, y.to(DEV)).backward()
+        res.append((pred.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0])
+    for n in res[0][1]:
+        assert rel_l2(res[0][1][n], res[1][1][n]) < tolerance, n
 
 
 def test_two_input_channels_train_step_vs_oracle_fp32():
