@@ -7,8 +7,8 @@
 //         = the three quantile heads written straight into the [B,3,C,H,W] output
 //           (core/models/finallayers/quantile_layer.py:15-17,20);
 //   wgrad : out[s][tap][l] = sum_px L[px][l] * S[s][px+tap]  -> weight gradients of both.
-// One thread per pixel of a 16x16 tile; the small side's weights are wave-uniform, so they are fetched
-// with scalar loads and cost no LDS or vector bandwidth.
+// 16x16-pixel tiles.  s2l: one thread per (pixel, 8-channel group) so a wave stores whole NHWC rows; l2s / wgrad: one
+// thread per pixel / per wide-side channel with the small side's weights wave-uniform (scalar loads).
 #include "common.h"
 #include "dtypes.h"
 #include "reduce.h"
@@ -19,31 +19,6 @@ using namespace im2im;
 constexpr int TS = 16;                 // tile side
 constexpr int HS = TS + 2;             // halo side
 constexpr int CS_MAX = 8;
-
-// wave-level reduce-scatter of v[CL] over the 64 lanes: lane l ends with the wave sum of channel l % CL
-// (for CL == 32 both 32-lane halves are combined as well).
-template <int CL>
-__device__ __forceinline__ float wave_reduce_scatter(float (&v)[CL], int lane) {
-  float cur[CL];
-#pragma unroll
-  for (int i = 0; i < CL; ++i) cur[i] = v[i];
-  int n = CL;
-#pragma unroll
-  for (int off = CL / 2; off >= 1; off >>= 1) {
-    const bool up = (lane & off) != 0;
-#pragma unroll
-    for (int i = 0; i < off; ++i) {
-      const float send = up ? cur[i] : cur[i + off];
-      const float keep = up ? cur[i + off] : cur[i];
-      cur[i] = keep + __shfl_xor(send, off, 64);
-    }
-    n = off;
-  }
-  (void)n;
-  float r = cur[0];
-  if (CL == 32) r += __shfl_xor(r, 32, 64);
-  return r;
-}
 
 struct S2LArgs {
   const float* in;      // [B][CS][H][W]
@@ -56,9 +31,18 @@ struct S2LArgs {
   int B, H, W, CS, tilesY, tilesX, relu, flip;
 };
 
-template <typename T, int CL>
+// Thread = (pixel, group of 8 output channels): the CL/8 lanes of one pixel write 16 B each, so a wave stores whole
+// NHWC rows (8 x-adjacent pixels x 128 B for CL = 64) instead of 64 scattered 16-byte pieces.  A thread keeps its
+// channel group for all its pixels of the 16x16 tile: with one input channel the 9x8 weights stay in registers
+// (W_REGS), otherwise they are read from LDS; BatchNorm partial statistics are accumulated per thread and combined
+// over the lanes that share a channel group (xor-shuffles), then over the four waves.
+template <typename T, int CL, bool W_REGS>
 __global__ __launch_bounds__(256) void smallconv_s2l_kernel(S2LArgs a) {
+  constexpr int G = CL / 8;                 // channel groups (lanes per pixel)
+  constexpr int PPP = 256 / G;              // pixels per pass
+  constexpr int PASSES = TS * TS / PPP;
   __shared__ float s_in[CS_MAX][HS][HS + 1];
+  __shared__ __attribute__((aligned(16))) float s_w[W_REGS ? 1 : CS_MAX * 9 * CL];
   __shared__ float s_stat[4][2][CL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int t = blockIdx.x;
@@ -73,46 +57,87 @@ __global__ __launch_bounds__(256) void smallconv_s2l_kernel(S2LArgs a) {
     const int yy = y0 + hy - 1, xx = x0 + hx - 1;
     s_in[s][hy][hx] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? inb[((size_t)s * a.H + yy) * a.W + xx] : 0.f;
   }
-  __syncthreads();
-  const int ty = tid / TS, tx = tid % TS;
-  float acc[CL];
+  const int g = tid % G, c0 = g * 8;
+  float wreg[W_REGS ? 9 : 1][8];
+  if constexpr (W_REGS) {
 #pragma unroll
-  for (int l = 0; l < CL; ++l) acc[l] = (a.bias ? a.bias[l] : 0.f) - (a.center ? a.center[l] : 0.f);
-  for (int s = 0; s < a.CS; ++s) {
+    for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const float xv = s_in[s][ty + tap / 3][tx + tap % 3];
-      const float* wr = a.w + ((size_t)s * 9 + (a.flip ? 8 - tap : tap)) * CL;      // wave-uniform -> scalar loads
-#pragma unroll
-      for (int l = 0; l < CL; ++l) acc[l] += xv * wr[l];
+      for (int k = 0; k < 8; ++k) wreg[tap][k] = a.w[(size_t)(a.flip ? 8 - tap : tap) * CL + c0 + k];
+  } else {
+    for (int i = tid; i < a.CS * 9 * CL; i += 256) {
+      const int s = i / (9 * CL), r = i % (9 * CL);
+      const int tap = r / CL, l = r % CL;
+      s_w[i] = a.w[((size_t)s * 9 + (a.flip ? 8 - tap : tap)) * CL + l];
     }
   }
-  const int yy = y0 + ty, xx = x0 + tx;
-  const bool valid = yy < a.H && xx < a.W;
-  if (a.scale_shift) {
+  float b0[8], sc[8], sh[8], s1[8], s2[8];
 #pragma unroll
-    for (int l = 0; l < CL; ++l) acc[l] = acc[l] * a.scale_shift[l] + a.scale_shift[CL + l];
+  for (int k = 0; k < 8; ++k) {
+    b0[k] = (a.bias ? a.bias[c0 + k] : 0.f) - (a.center ? a.center[c0 + k] : 0.f);
+    sc[k] = a.scale_shift ? a.scale_shift[c0 + k] : 1.f;
+    sh[k] = a.scale_shift ? a.scale_shift[CL + c0 + k] : 0.f;
+    s1[k] = 0.f; s2[k] = 0.f;
   }
-  if (a.relu) {
+  __syncthreads();
+  T* outb = reinterpret_cast<T*>(a.out) + (size_t)b * a.H * a.W * CL + c0;
+#pragma unroll 2
+  for (int pass = 0; pass < PASSES; ++pass) {
+    const int px = pass * PPP + tid / G;
+    const int ty = px / TS, tx = px % TS;
+    float acc[8];
 #pragma unroll
-    for (int l = 0; l < CL; ++l) acc[l] = fmaxf(acc[l], 0.f);
-  }
-  // round to the storage type first so the statistics describe what BatchNorm will normalise
+    for (int k = 0; k < 8; ++k) acc[k] = b0[k];
+    if constexpr (W_REGS) {
 #pragma unroll
-  for (int l = 0; l < CL; ++l) acc[l] = to_float(from_float<T>(acc[l]));
-  if (valid) {
-    T* o = reinterpret_cast<T*>(a.out) + (((size_t)b * a.H + yy) * a.W + xx) * CL;
-    constexpr int N = Vec16<T>::N;
+      for (int tap = 0; tap < 9; ++tap) {
+        const float xv = s_in[0][ty + tap / 3][tx + tap % 3];
 #pragma unroll
-    for (int l = 0; l < CL; l += N) Vec16<T>::store(o + l, acc + l);
+        for (int k = 0; k < 8; ++k) acc[k] += xv * wreg[tap][k];
+      }
+    } else {
+      for (int s = 0; s < a.CS; ++s) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const float xv = s_in[s][ty + tap / 3][tx + tap % 3];
+          const float4 w0 = *reinterpret_cast<const float4*>(&s_w[(s * 9 + tap) * CL + c0]);
+          const float4 w1 = *reinterpret_cast<const float4*>(&s_w[(s * 9 + tap) * CL + c0 + 4]);
+          acc[0] += xv * w0.x; acc[1] += xv * w0.y; acc[2] += xv * w0.z; acc[3] += xv * w0.w;
+          acc[4] += xv * w1.x; acc[5] += xv * w1.y; acc[6] += xv * w1.z; acc[7] += xv * w1.w;
+        }
+      }
+    }
+    if (a.scale_shift) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = acc[k] * sc[k] + sh[k];
+    }
+    if (a.relu) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = fmaxf(acc[k], 0.f);
+    }
+    // round to the storage type first so the statistics describe what BatchNorm will normalise
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = to_float(from_float<T>(acc[k]));
+    const int yy = y0 + ty, xx = x0 + tx;
+    if (yy < a.H && xx < a.W) {
+      T* o = outb + ((size_t)yy * a.W + xx) * CL;
+      constexpr int N = Vec16<T>::N;
+#pragma unroll
+      for (int k = 0; k < 8; k += N) Vec16<T>::store(o + k, acc + k);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { s1[k] += acc[k]; s2[k] += acc[k] * acc[k]; }
+    }
   }
   if (a.stats) {
-    float sq[CL];
 #pragma unroll
-    for (int l = 0; l < CL; ++l) { if (!valid) acc[l] = 0.f; sq[l] = acc[l] * acc[l]; }
-    const float s1 = wave_reduce_scatter<CL>(acc, lane);
-    const float s2 = wave_reduce_scatter<CL>(sq, lane);
-    if (lane < CL) { s_stat[wave][0][lane] = s1; s_stat[wave][1][lane] = s2; }
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+      for (int off = G; off < 64; off <<= 1) { s1[k] += __shfl_xor(s1[k], off, 64); s2[k] += __shfl_xor(s2[k], off, 64); }
+    }
+    if (lane < G) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { s_stat[wave][0][c0 + k] = s1[k]; s_stat[wave][1][c0 + k] = s2[k]; }
+    }
     __syncthreads();
     if (tid < 2 * CL) {
       const int which = tid / CL, c = tid % CL;
@@ -314,7 +339,9 @@ extern "C" int im2im_smallconv_s2l_fwd(const float* in, const float* w, const fl
   S2LArgs a{in, w, bias, center, scale_shift, out, stats, B, H, W, CS, (int)cdiv(H, TS), (int)cdiv(W, TS), relu, flip};
   return for_dtype_cl(dtype, CL, [&](auto* tag, auto cl) {
     using T = std::remove_pointer_t<decltype(tag)>;
-    hipLaunchKernelGGL((smallconv_s2l_kernel<T, decltype(cl)::value>), dim3((unsigned)(B * a.tilesY * a.tilesX)), dim3(256), 0, stream, a);
+    const dim3 grid((unsigned)(B * a.tilesY * a.tilesX));
+    if (CS == 1) hipLaunchKernelGGL((smallconv_s2l_kernel<T, decltype(cl)::value, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((smallconv_s2l_kernel<T, decltype(cl)::value, false>), grid, dim3(256), 0, stream, a);
     return check_launch("smallconv_s2l_kernel");
   });
 }

@@ -148,30 +148,43 @@ def test_bf16_matches_reference_arithmetic_at_bf16_precision():
     assert max(errs.values()) < 0.5, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
 
 
-def test_backward_gradients_vs_oracle_fp32():
+def _oracle_grads(x, y, dtype):
     from oracle import model as om
-    model = build(1, "fp32")
-    model.train()
-    x, y = om.det_images(3, 1, 64, 64, salt=5)     # 64x64: 48 samples per channel at the bottleneck BatchNorm
-    pred = model(x.to(DEV))
-    loss = model.loss_fn(pred, y.to(DEV))
-    loss.backward()
-    st = om.det_state(1, 1)
+    st = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in om.det_state(1, 1).items()}
     leaves = {k: v.clone().requires_grad_(True) for k, v in st.items() if om.is_param(k)}
     work = dict(st); work.update(leaves)
-    ref_loss = om.quantile_loss(om.model_forward(x, work, training=True), y, PARAMS)
-    ref_loss.backward()
+    loss = om.quantile_loss(om.model_forward(x.to(dtype), work, training=True), y.to(dtype), PARAMS)
+    loss.backward()
+    return loss, {k: v.grad for k, v in leaves.items()}
+
+
+def test_backward_gradients_vs_oracle_fp32():
+    """Every parameter gradient of one train step, fp32 mode, against the oracle.  The yardstick is the oracle evaluated
+    in float64: this network's gradients are ill-conditioned in fp32 (a 1e-7 relative change of the input moves the
+    reference's own fp32 gradients by 2e-3, tools/debug_grad.py), so the HIP path has to be as close to the float64
+    truth as the reference's fp32 arithmetic is -- not bit-close to one particular fp32 evaluation order."""
+    model = build(1, "fp32")
+    model.train()
+    # seeded noise images (the smooth closed-form det_images put many max-pool windows / ReLU inputs on near-ties)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 1, 64, 64, generator=g)     # 64x64: 48 samples per channel at the bottleneck BatchNorm
+    y = torch.rand(3, 1, 64, 64, generator=g)
+    loss = model.loss_fn(model(x.to(DEV)), y.to(DEV))
+    loss.backward()
+    ref_loss, g32 = _oracle_grads(x, y, torch.float32)
+    _, g64 = _oracle_grads(x, y, torch.float64)
     assert loss.item() == pytest.approx(ref_loss.item(), rel=2e-5)
-    worst = {}
+    e_hip, e_ref = {}, {}
     for name, p in model.named_parameters():
-        ref = leaves[name].grad
         if ".double_conv.0.bias" in name or ".double_conv.3.bias" in name:
             # conv bias in front of train-mode BatchNorm: gradient is analytically zero; reference has fp noise
-            assert (p.grad is None or float(p.grad.abs().max()) == 0.0) and float(ref.abs().max()) < 1e-5
+            assert (p.grad is None or float(p.grad.abs().max()) == 0.0) and float(g32[name].abs().max()) < 1e-5
             continue
-        worst[name] = rel_l2(p.grad.cpu(), ref)
-    bad = {k: v for k, v in worst.items() if v > 2e-3}
+        e_hip[name] = rel_l2(p.grad.cpu(), g64[name])
+        e_ref[name] = rel_l2(g32[name], g64[name])
+    bad = {k: (e_hip[k], e_ref[k]) for k in e_hip if e_hip[k] > 3.0 * e_ref[k] + 5e-4}
     assert not bad, bad
+    assert max(e_hip.values()) < 2.0 * max(e_ref.values()) + 5e-4, (max(e_hip.values()), max(e_ref.values()))
 
 
 def test_g5_adam_trajectory_fp32():
