@@ -33,7 +33,7 @@ struct ConvArgs {
   const float* scale;   // [Co] or null  (mode affine)
   const float* shift;   // [Co] or null
   void* y;              // [B][H][W][Co]  T
-  float* stats;         // [mtiles][2][Co] or null
+  float* stats;         // [mtiles][3][Co] or null: per-tile (mean, M2, count) of the stored values
   int B, H, W, Ci, Co, tilesY, tilesX;
   int relu;             // apply ReLU after affine
   const float* center;  // [Co] or null: subtracted from the stored output (see im2im_conv_fwd)
@@ -68,6 +68,16 @@ template <> struct Frag<float> {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
   }
 };
+
+// (count, mean, M2) of a union of two sample sets (Chan et al.); symmetric, so both partners of a shuffle agree
+__device__ __forceinline__ void merge_moments_f32(float& n, float& m, float& q, float n2, float m2, float q2) {
+  const float nn = n + n2;
+  const float inv = nn > 0.f ? 1.f / nn : 0.f;
+  const float d = m2 - m;
+  q = q + q2 + d * d * (n * n2 * inv);
+  m = (n * m + n2 * m2) * inv;
+  n = nn;
+}
 
 // EPI: 0 = (+bias) store only [data-gradient, 1x1 conv]; 1 = +bias, store, BatchNorm partial statistics [train forward];
 //      2 = folded BatchNorm affine + ReLU [eval forward].  Compile-time so the 128 values per lane pay only for what
@@ -305,7 +315,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr bool want_stats = (EPI == 1);
   __syncthreads();                                           // every wave is done reading the operand buffers
   char* wbuf = smem + wave * WBYTES;
-  float st_s[NT], st_q[NT];
+  // BatchNorm partial statistics of this lane's values of channel nt: count, mean and M2 (sum of squared deviations).
+  // Sums are taken relative to K = the lane's first value of the channel (a sample of the data, or of its zero-padded
+  // continuation in an overhanging tile), so M2 = q - s^2/n has no catastrophic cancellation however far the channel
+  // mean is from zero.  The count only depends on the lane's rows: computed once.
+  float st_n[NT], st_m[NT], st_q[NT];
+  float cnt = 0.f;
+  if constexpr (want_stats) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = wm * WROWS + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
+        cnt += (bb < a.B && yy < a.H && xx < a.W) ? 1.f : 0.f;
+      }
+  }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int nl = (wn * NT + nt) * 32 + l31;                  // channel within the block tile
@@ -314,6 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     float sc = 1.f, sh = 0.f;
     if constexpr (EPI == 2) { sc = a.scale[n]; sh = a.shift[n]; }
     float s = 0.f, sq = 0.f;
+    const float K = to_float(from_float<T>(acc[0][nt][0] + bias_v));
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -330,13 +356,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
           const int m = wm * WROWS + row;
           const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
           if (bb < a.B && yy < a.H && xx < a.W) {
-            const float fv = to_float(tv);
-            s += fv; sq += fv * fv;
+            const float d = to_float(tv) - K;
+            s += d; sq += d * d;
           }
         }
       }
     }
-    st_s[nt] = s; st_q[nt] = sq;
+    if constexpr (want_stats) {
+      const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+      st_n[nt] = cnt; st_m[nt] = K + s * inv; st_q[nt] = fmaxf(sq - s * s * inv, 0.f);
+    }
   }
   // wave-private region: LDS operations of one wave complete in issue order, no barrier needed
 #pragma unroll
@@ -354,19 +383,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int nl = (wn * NT + nt) * 32 + l31;
-      float s = st_s[nt], sq = st_q[nt];
-      s += __shfl_xor(s, 32, 64);
-      sq += __shfl_xor(sq, 32, 64);
-      if (half == 0) { ldsS[(wm * BN + nl) * 2 + 0] = s; ldsS[(wm * BN + nl) * 2 + 1] = sq; }
+      // merge the two half-waves (rows r and r+4 of every 8), then the WM waves that share this channel
+      float n = st_n[nt], m = st_m[nt], q = st_q[nt];
+      merge_moments_f32(n, m, q, __shfl_xor(n, 32, 64), __shfl_xor(m, 32, 64), __shfl_xor(q, 32, 64));
+      if (half == 0) { ldsS[(wm * BN + nl) * 3 + 0] = n; ldsS[(wm * BN + nl) * 3 + 1] = m; ldsS[(wm * BN + nl) * 3 + 2] = q; }
     }
     __syncthreads();
     if (tid < BN) {
-      float s = 0.f, sq = 0.f;
+      float n = ldsS[tid * 3 + 0], m = ldsS[tid * 3 + 1], q = ldsS[tid * 3 + 2];
 #pragma unroll
-      for (int i = 0; i < WM; ++i) { s += ldsS[(i * BN + tid) * 2 + 0]; sq += ldsS[(i * BN + tid) * 2 + 1]; }
-      float* st = a.stats + (size_t)blockIdx.x * 2 * a.Co;
-      st[n0 + tid] = s;
-      st[a.Co + n0 + tid] = sq;
+      for (int i = 1; i < WM; ++i)
+        merge_moments_f32(n, m, q, ldsS[(i * BN + tid) * 3 + 0], ldsS[(i * BN + tid) * 3 + 1], ldsS[(i * BN + tid) * 3 + 2]);
+      float* st = a.stats + (size_t)blockIdx.x * 3 * a.Co;
+      st[n0 + tid] = m;
+      st[a.Co + n0 + tid] = q;
+      st[2 * a.Co + n0 + tid] = n;
     }
   }
 }
@@ -740,7 +771,7 @@ int launch_conv_epi(const ConvArgs& a_in, hipStream_t stream) {
   constexpr size_t smem_epi = (size_t)4 * (TB * TH * TW / WM) * ((BN / WN) * sizeof(T) + 16);   // 4 wave-private output tiles
   const size_t smem_in = smem_main + ((a.in_ss || a.in_ss_hi) ? (size_t)2 * a.Ci * sizeof(float) : 0);
   const size_t smem = smem_in > smem_epi ? smem_in : smem_epi;
-  static_assert(smem_epi >= (size_t)WM * BN * 2 * 4, "stats scratch fits");
+  static_assert(smem_epi >= (size_t)WM * BN * 3 * 4, "stats scratch fits");
   auto kern = conv_igemm_kernel<T, TB, TH, TW, BN, WM, WN, TAPS, EPI>;
   static size_t attr_set = 0;
   if (smem > 64 * 1024 && smem > attr_set) {

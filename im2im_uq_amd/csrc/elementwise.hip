@@ -11,25 +11,82 @@ using namespace im2im;
 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm2d, train mode (core/models/trunks/unet_parts.py:17,20; torch defaults eps=1e-5, momentum=0.1)
-// stage 2 of the statistics reduction: tmp[S][2][C] fp64 (sum, sum of squares) ->
-//   mean_invstd[2][C], scale_shift[2][C] (scale = gamma*invstd, shift = beta - mean*scale),
+// Batch statistics arrive as per-tile partials (mean, M2 = sum of squared deviations from that mean, n) written by the
+// conv epilogues and are merged with the pairwise update of Chan et al. in fp64 -- never as E[z^2] - E[z]^2, whose
+// cancellation costs mean^2/var digits (torch's CPU path accumulates these sums in double; this keeps parity with it).
+struct Moments { double n, mean, m2; };
+__device__ __forceinline__ Moments merge_moments(const Moments& a, const Moments& b) {
+  const double n = a.n + b.n;
+  if (n <= 0.0) return Moments{0.0, 0.0, 0.0};
+  const double d = b.mean - a.mean;
+  return Moments{n, (a.n * a.mean + b.n * b.mean) / n, a.m2 + b.m2 + d * d * (a.n * b.n / n)};
+}
+
+// stage 1: partial[R][3][C] fp32 (mean, M2, n) -> tmp[S][3][C] fp64 (n, mean, M2) per split of rows.  Two passes over the
+// split's rows (the second one hits L2): N and the split mean first, then M2 = sum M2_t + n_t (mean_t - mean)^2 -- plain
+// fp64 sums in a fixed order, no division inside the loops.  Block = 64 channels x 16 row lanes.
+__global__ __launch_bounds__(1024) void bn_stats_stage1_kernel(const float* __restrict__ partial, int64_t R, int C,
+                                                                int64_t rows_per_split, double* __restrict__ tmp) {
+  __shared__ double sh[2][16][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const bool on = c < C;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_split;
+  const int64_t r1 = (r0 + rows_per_split < R) ? r0 + rows_per_split : R;
+  double n = 0.0, a = 0.0;
+  if (on)
+    for (int64_t r = r0 + rl; r < r1; r += 16) {
+      const float* row = partial + r * 3 * C;
+      const double nt = (double)row[2 * C + c];
+      n += nt; a += nt * (double)row[c];
+    }
+  sh[0][rl][cl] = n; sh[1][rl][cl] = a;
+  __syncthreads();
+  double N = 0.0, A = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { N += sh[0][i][cl]; A += sh[1][i][cl]; }
+  const double mean = N > 0.0 ? A / N : 0.0;
+  double q = 0.0;
+  if (on)
+    for (int64_t r = r0 + rl; r < r1; r += 16) {
+      const float* row = partial + r * 3 * C;
+      const double d = (double)row[c] - mean;
+      q += (double)row[C + c] + (double)row[2 * C + c] * d * d;
+    }
+  __syncthreads();
+  sh[0][rl][cl] = q;
+  __syncthreads();
+  if (rl == 0 && on) {
+    double Q = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Q += sh[0][i][cl];
+    double* o = tmp + (int64_t)blockIdx.y * 3 * C;
+    o[c] = N; o[C + c] = mean; o[2 * C + c] = Q;
+  }
+}
+
+// stage 2: tmp[S][3][C] -> mean_invstd[2][C], scale_shift[2][C] (scale = gamma*invstd, shift = beta - mean*scale),
 //   running stats (unbiased variance, as torch).
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ tmp, int S, int C, double count,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
                                                            float momentum, float eps, int centered,
                                                            float* __restrict__ mean_invstd, float* __restrict__ scale_shift) {
-  // one wave per channel: lane i holds split-row i (S <= 64), fixed-order butterfly -> deterministic
+  // one wave per channel: lane i holds split-row i (S <= 64); the xor butterfly applies the (symmetric) merge, so every
+  // lane ends with the same, order-fixed result
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (c >= C) return;
-  double s = (lane < S) ? tmp[((size_t)lane * 2 + 0) * C + c] : 0.0;
-  double sq = (lane < S) ? tmp[((size_t)lane * 2 + 1) * C + c] : 0.0;
-  for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); sq += __shfl_xor(sq, off, 64); }
+  Moments m{0.0, 0.0, 0.0};
+  if (lane < S) { const double* row = tmp + (size_t)lane * 3 * C; m = Moments{row[c], row[C + c], row[2 * C + c]}; }
+  for (int off = 32; off > 0; off >>= 1) {
+    const Moments o{__shfl_xor(m.n, off, 64), __shfl_xor(m.mean, off, 64), __shfl_xor(m.m2, off, 64)};
+    m = merge_moments(m, o);
+  }
   if (lane != 0) return;
-  const double mean = s / count;
-  double var = sq / count - mean * mean;
-  if (var < 0.0) var = 0.0;
+  (void)count;                                             // == m.n (kept in the ABI for the caller's bookkeeping)
+  const double mean = m.mean;
+  const double var = m.n > 0.0 ? m.m2 / m.n : 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   mean_invstd[c] = (float)mean;
   mean_invstd[C + c] = invstd;
@@ -37,7 +94,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   scale_shift[c] = sc;
   scale_shift[C + c] = beta[c] - (float)mean * sc;
   if (running_mean) {
-    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    const double unbiased = m.n > 1.0 ? m.m2 / (m.n - 1.0) : var;
     // centered: the statistics describe z - running_mean(old); the true batch mean adds it back
     const float true_mean = (float)mean + (centered ? running_mean[c] : 0.f);
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * true_mean;
@@ -729,9 +786,10 @@ extern "C" int im2im_bn_finalize(const float* partial, int64_t R, int32_t C, int
   IM2IM_REQUIRE(partial && gamma && beta && mean_invstd && scale_shift && ws && R > 0 && C > 0 && count > 0);
   IM2IM_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
   IM2IM_REQUIRE(!centered || running_mean);
-  int rc;
-  const int S = launch_reduce_stage1(partial, R, 2 * (int64_t)C, (double*)ws, stream, &rc);
-  if (rc) return rc;
+  const int S = reduce_splits(R);
+  hipLaunchKernelGGL(bn_stats_stage1_kernel, dim3((unsigned)cdiv(C, 64), (unsigned)S), dim3(1024), 0, stream, partial, R, (int)C,
+                     cdiv(R, S), (double*)ws);
+  if (int rc = check_launch("bn_stats_stage1_kernel")) return rc;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, stream, (const double*)ws, S, (int)C,
                      (double)count, gamma, beta, running_mean, running_var, momentum, eps, (int)centered, mean_invstd, scale_shift);
   return check_launch("bn_finalize_kernel");

@@ -27,7 +27,7 @@ struct S2LArgs {
   const float* center;  // [CL] | null (subtracted from the stored output)
   const float* scale_shift;   // [2][CL] | null
   void* out;            // [B][H][W][CL] T
-  float* stats;         // [blk][2][CL] | null
+  float* stats;         // [blk][3][CL] | null: per-tile (mean, M2, count), see conv_mfma.hip
   int B, H, W, CS, tilesY, tilesX, relu, flip;
 };
 
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void smallconv_s2l_kernel(S2LArgs a) {
   constexpr int PASSES = TS * TS / PPP;
   __shared__ float s_in[CS_MAX][HS][HS + 1];
   __shared__ __attribute__((aligned(16))) float s_w[W_REGS ? 1 : CS_MAX * 9 * CL];
-  __shared__ float s_stat[4][2][CL];
+  __shared__ float s_stat[4][3][CL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int t = blockIdx.x;
   const int tx_id = t % a.tilesX; t /= a.tilesX;
@@ -71,13 +71,14 @@ __global__ __launch_bounds__(256) void smallconv_s2l_kernel(S2LArgs a) {
       s_w[i] = a.w[((size_t)s * 9 + (a.flip ? 8 - tap : tap)) * CL + l];
     }
   }
-  float b0[8], sc[8], sh[8], s1[8], s2[8];
+  float b0[8], sc[8], sh[8], s1[8], s2[8], K[8];
+  float cnt = 0.f;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     b0[k] = (a.bias ? a.bias[c0 + k] : 0.f) - (a.center ? a.center[c0 + k] : 0.f);
     sc[k] = a.scale_shift ? a.scale_shift[c0 + k] : 1.f;
     sh[k] = a.scale_shift ? a.scale_shift[CL + c0 + k] : 0.f;
-    s1[k] = 0.f; s2[k] = 0.f;
+    s1[k] = 0.f; s2[k] = 0.f; K[k] = 0.f;
   }
   __syncthreads();
   T* outb = reinterpret_cast<T*>(a.out) + (size_t)b * a.H * a.W * CL + c0;
@@ -124,25 +125,53 @@ __global__ __launch_bounds__(256) void smallconv_s2l_kernel(S2LArgs a) {
       constexpr int N = Vec16<T>::N;
 #pragma unroll
       for (int k = 0; k < 8; k += N) Vec16<T>::store(o + k, acc + k);
+      // statistics relative to this thread's first valid value (no cancellation when forming M2 below)
+      if (cnt == 0.f) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { s1[k] += acc[k]; s2[k] += acc[k] * acc[k]; }
+        for (int k = 0; k < 8; ++k) K[k] = acc[k];
+      }
+      cnt += 1.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float d = acc[k] - K[k]; s1[k] += d; s2[k] += d * d; }
     }
   }
   if (a.stats) {
+    // thread -> (count, mean, M2); merged over the lanes that share the channel group, then over the four waves
+    const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+    float mean[8], m2[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 8; ++k) { mean[k] = K[k] + s1[k] * inv; m2[k] = fmaxf(s2[k] - s1[k] * s1[k] * inv, 0.f); }
 #pragma unroll
-      for (int off = G; off < 64; off <<= 1) { s1[k] += __shfl_xor(s1[k], off, 64); s2[k] += __shfl_xor(s2[k], off, 64); }
+    for (int off = G; off < 64; off <<= 1) {
+      const float n2 = __shfl_xor(cnt, off, 64);
+      const float nn = cnt + n2;
+      const float ninv = nn > 0.f ? 1.f / nn : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float mo = __shfl_xor(mean[k], off, 64), qo = __shfl_xor(m2[k], off, 64);
+        const float d = mo - mean[k];
+        m2[k] = m2[k] + qo + d * d * (cnt * n2 * ninv);
+        mean[k] = (cnt * mean[k] + n2 * mo) * ninv;
+      }
+      cnt = nn;
     }
     if (lane < G) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { s_stat[wave][0][c0 + k] = s1[k]; s_stat[wave][1][c0 + k] = s2[k]; }
+      for (int k = 0; k < 8; ++k) { s_stat[wave][0][c0 + k] = mean[k]; s_stat[wave][1][c0 + k] = m2[k]; s_stat[wave][2][c0 + k] = cnt; }
     }
     __syncthreads();
-    if (tid < 2 * CL) {
-      const int which = tid / CL, c = tid % CL;
-      a.stats[(size_t)blockIdx.x * 2 * CL + which * CL + c] =
-          s_stat[0][which][c] + s_stat[1][which][c] + s_stat[2][which][c] + s_stat[3][which][c];
+    if (tid < CL) {
+      float n = s_stat[0][2][tid], m = s_stat[0][0][tid], q = s_stat[0][1][tid];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float n2 = s_stat[w][2][tid], mo = s_stat[w][0][tid], qo = s_stat[w][1][tid];
+        const float nn = n + n2, ninv = nn > 0.f ? 1.f / nn : 0.f, d = mo - m;
+        q = q + qo + d * d * (n * n2 * ninv);
+        m = (n * m + n2 * mo) * ninv;
+        n = nn;
+      }
+      float* st = a.stats + (size_t)blockIdx.x * 3 * CL;
+      st[tid] = m; st[CL + tid] = q; st[2 * CL + tid] = n;
     }
   }
 }

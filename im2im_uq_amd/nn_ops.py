@@ -144,7 +144,7 @@ def conv_fwd(x, wf, bias=None, scale_shift=None, relu=False, want_stats=False, i
     stats = None
     if want_stats:
         rows = lib.im2im_conv_stats_rows(b, h, w_, co)
-        stats = torch.empty((rows, 2, co), dtype=F32, device=x.device)
+        stats = torch.empty((rows, 3, co), dtype=F32, device=x.device)     # per-tile (mean, M2, count)
     sc = sh = None
     if scale_shift is not None:
         sc, sh = scale_shift[0], scale_shift[1]
@@ -185,7 +185,7 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, 
     dev = stats.device
     mean_invstd = torch.empty((2, c), dtype=F32, device=dev)
     scale_shift = torch.empty((2, c), dtype=F32, device=dev)
-    ws = _Scratch.get(lib.im2im_reduce_workspace_bytes(2 * c), dev)
+    ws = _Scratch.get(lib.im2im_reduce_workspace_bytes(3 * c), dev)
     check(lib.im2im_bn_finalize(dptr(stats), rows, c, count, dptr(gamma), dptr(beta), dptr(running_mean), dptr(running_var),
                                 float(momentum), float(eps), int(centered), dptr(mean_invstd), dptr(scale_shift), dptr(ws), stream_ptr(dev)),
           "im2im_bn_finalize")
@@ -250,7 +250,7 @@ def smallconv_s2l(x_nchw, w, bias, scale_shift, cl, dtype, relu=False, flip=Fals
     out = torch.empty((b, h, w_, cl), dtype=dtype, device=x_nchw.device)
     stats = None
     if want_stats:
-        stats = torch.empty((lib.im2im_smallconv_tiles(b, h, w_), 2, cl), dtype=F32, device=x_nchw.device)
+        stats = torch.empty((lib.im2im_smallconv_tiles(b, h, w_), 3, cl), dtype=F32, device=x_nchw.device)
     check(lib.im2im_smallconv_s2l_fwd(dptr(x_nchw), dptr(w), dptr(bias), dptr(center), dptr(scale_shift), dptr(out), dptr(stats), b, h, w_, cs, cl,
                                       int(relu), int(flip), _DT[dtype], stream_ptr(x_nchw.device)), "im2im_smallconv_s2l_fwd")
     return (out, stats) if want_stats else out

@@ -99,9 +99,10 @@ int im2im_pack_conv_weight(const float* w, int32_t Co, int32_t Ci, int32_t taps,
  *   x [B][H][W][Ci], y [B][H][W][Co] (dtype), Ci % 32 == 0, Co % 32 == 0, taps in {9,1}
  *   bias fp32 [Co] or NULL;  scale/shift fp32 [Co] or both NULL: v = v*scale + shift (folded eval-mode
  *   BatchNorm, unet_parts.py:17,20);  relu != 0: v = max(v,0) (unet_parts.py:18,21)
- *   stats (may be NULL): [rows][2][Co] fp32 per-tile partial sums and sums of squares of the STORED
- *   values over valid pixels, rows = im2im_conv_stats_rows(B,H,W,Co): train-mode BatchNorm statistics
- *   without re-reading y.  dgrad uses the same entry point with x = dz and wf = wd.
+ *   stats (may be NULL): [rows][3][Co] fp32 per-tile (mean, M2 = sum of squared deviations from that mean, count)
+ *   of the STORED values over valid pixels, rows = im2im_conv_stats_rows(B,H,W,Co): train-mode BatchNorm
+ *   statistics without re-reading y, in the cancellation-free form im2im_bn_finalize merges pairwise in fp64
+ *   (torch's CPU BatchNorm accumulates in double).  dgrad uses the same entry point with x = dz and wf = wd.
  *   center (may be NULL): fp32 [Co] subtracted from the stored output.  The bf16 train path passes the layer's
  *   running_mean so the pre-BatchNorm tensor is stored roughly zero-mean (BatchNorm is shift invariant; bf16 rounding
  *   is then relative to the spread of a channel instead of its offset); im2im_bn_finalize(centered = 1) adds it back
@@ -152,10 +153,10 @@ int64_t im2im_reduce_workspace_bytes(int64_t K);
  * BatchNorm2d + ReLU: nn.BatchNorm2d / nn.ReLU at core/models/trunks/unet_parts.py:17-18,20-21
  * (torch defaults eps = 1e-5, momentum = 0.1), tensors [M = B*H*W][C] in `dtype`.
  *
- * im2im_bn_finalize: per-tile partial sums from the conv epilogue (partial [R][2][C]) -> batch mean and
- *   biased variance; writes mean_invstd [2][C], scale_shift [2][C] (scale = gamma*invstd,
- *   shift = beta - mean*scale) and, if non-NULL, the running statistics (unbiased variance, as torch).
- *   ws: im2im_reduce_workspace_bytes(2*C) bytes.
+ * im2im_bn_finalize: per-tile partial moments from the conv epilogue (partial [R][3][C]: mean, M2, count) -> batch
+ *   mean and biased variance (pairwise merge in fp64, never E[z^2]-E[z]^2); writes mean_invstd [2][C],
+ *   scale_shift [2][C] (scale = gamma*invstd, shift = beta - mean*scale) and, if non-NULL, the running statistics
+ *   (unbiased variance, as torch).  ws: im2im_reduce_workspace_bytes(3*C) bytes.
  * im2im_bn_fold_eval: eval-mode fold into the conv epilogue: scale = gamma/sqrt(rv+eps),
  *   shift = beta + (conv_bias - rm)*scale.
  * im2im_bn_relu_apply: a = max(z*scale + shift, 0).
@@ -216,7 +217,7 @@ int im2im_upsample2x_concat_bwd(const void* dout, void* ddeep, void* dskip, int3
  * Small-channel direct 3x3 convolutions (pad 1), 16x16-pixel tiles, weights fp32.
  * s2l: in fp32 NCHW [B][CS][H][W] (CS <= 8) -> out NHWC [B][H][W][CL] (CL in {32,64}).
  *   w [CS][9][CL] (tap index reversed when flip != 0); bias [CL]|NULL; scale_shift [2][CL]|NULL; relu;
- *   stats [im2im_smallconv_tiles][2][CL]|NULL as for im2im_conv_fwd.  Uses: first UNet conv
+ *   stats [im2im_smallconv_tiles][3][CL]|NULL as for im2im_conv_fwd.  Uses: first UNet conv
  *   (unet_parts.py:16, Cin = n_in) and the data gradient of the quantile heads.
  * l2s: in NHWC [B][H][W][CL] -> out fp32 NCHW [B][CS][H][W]; w [CS][9][CL]; bias [CS]|NULL.  Use: the three
  *   quantile heads written directly as [B,3,C,H,W] (finallayers/quantile_layer.py:15-17,20).

@@ -29,6 +29,15 @@ def q(t, dt):
     return t.to(dt).to(F32)
 
 
+def merged_moments(stats):
+    """merge per-tile (mean, M2, count) rows [R,3,C] -> total (count, mean, M2) per channel in float64 (Chan et al.)."""
+    st = stats.double().cpu()
+    n = st[:, 2].sum(0)
+    mean = (st[:, 2] * st[:, 0]).sum(0) / n
+    m2 = st[:, 1].sum(0) + (st[:, 2] * (st[:, 0] - mean) ** 2).sum(0)
+    return n, mean, m2
+
+
 CONV_CASES = [
     # B, H, W, Ci, Co, taps
     (2, 20, 24, 64, 64, 9),       # 8x8 tiles, overhang in both dims
@@ -60,10 +69,11 @@ def test_conv_fwd_dgrad_wgrad(case, dt):
     got = y.float().cpu().permute(0, 3, 1, 2)
     assert rel_l2(got, ref.detach()) < tol(dt)
     # BatchNorm partial statistics of the STORED values
-    s = stats.double().sum(0).cpu()
+    n, mean, m2 = merged_moments(stats)
     yst = y.double().cpu().reshape(-1, co)
-    np.testing.assert_allclose(s[0].numpy(), yst.sum(0).numpy(), rtol=1e-4, atol=1e-2)
-    np.testing.assert_allclose(s[1].numpy(), (yst * yst).sum(0).numpy(), rtol=1e-4, atol=1e-2)
+    assert float((n - yst.shape[0]).abs().max()) == 0.0
+    np.testing.assert_allclose(mean.numpy(), yst.mean(0).numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(m2.numpy(), ((yst - yst.mean(0)) ** 2).sum(0).numpy(), rtol=2e-5)
     # folded affine + relu epilogue
     ss = torch.stack([rnd(co, seed=4).abs() + 0.5, rnd(co, seed=5)]).to(DEV)
     y2 = nn_ops.conv_fwd(x_d, wf, None, ss, relu=True).float().cpu().permute(0, 3, 1, 2)
@@ -159,8 +169,10 @@ def test_smallconv_family(shape, dt):
     got = z.float().cpu().permute(0, 3, 1, 2)
     assert rel_l2(got, ref.detach()) < (1e-5 if dt == F32 else 5e-3)
     zs = z.double().cpu().reshape(-1, cl)
-    np.testing.assert_allclose(stats.double().sum(0)[0].cpu().numpy(), zs.sum(0).numpy(), rtol=1e-4, atol=1e-2)
-    np.testing.assert_allclose(stats.double().sum(0)[1].cpu().numpy(), (zs * zs).sum(0).numpy(), rtol=1e-4, atol=1e-2)
+    n, mean, m2 = merged_moments(stats)
+    assert float((n - zs.shape[0]).abs().max()) == 0.0
+    np.testing.assert_allclose(mean.numpy(), zs.mean(0).numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(m2.numpy(), ((zs - zs.mean(0)) ** 2).sum(0).numpy(), rtol=2e-5)
     # its weight gradient (l_major)
     gz = rnd(b, cl, h, w, seed=4)
     ref.backward(q(gz, dt))
@@ -186,6 +198,26 @@ def test_smallconv_family(shape, dt):
     assert rel_l2(dbh.cpu(), bh_r.grad) < 1e-5
 
 
+def test_batchnorm_statistics_survive_a_large_channel_offset():
+    """|mean| >> sigma: E[z^2] - E[z]^2 in fp32 would lose mean^2/var ~ 1e6 of its digits; the epilogue's per-tile
+    (mean, M2, count) partials merged in fp64 keep the variance to fp32 accuracy (torch's CPU BatchNorm accumulates in
+    double, so the reference does too)."""
+    from im2im_uq_amd import nn_ops
+    b, h, w, ci, co = 2, 40, 48, 32, 64
+    x = rnd(b, h, w, ci, seed=1).to(DEV)
+    wt = rnd(co, ci, 3, 3, seed=2, scale=0.02).to(DEV)
+    bias = torch.full((co,), 300.0).to(DEV)                       # conv output ~ 300 +- 0.3
+    wf, _ = nn_ops.pack_weight(wt, F32, want_wd=False)
+    z, stats = nn_ops.conv_fwd(x, wf, bias, want_stats=True)
+    gamma, beta = torch.ones(co, device=DEV), torch.zeros(co, device=DEV)
+    mean_invstd, _ = nn_ops.bn_finalize(stats, b * h * w, gamma, beta, None, None, 0.1, 1e-5)
+    zz = z.double().reshape(-1, co)
+    ref_var = zz.var(0, unbiased=False)
+    got_var = 1.0 / mean_invstd[1].double() ** 2 - 1e-5
+    assert float(((got_var - ref_var).abs() / ref_var).max()) < 1e-5
+    assert float((mean_invstd[0].double() - zz.mean(0)).abs().max()) < 1e-4
+
+
 @pytest.mark.parametrize("dt", [F32, BF16])
 @pytest.mark.parametrize("shape", [(2, 20, 24, 64), (1, 33, 31, 128), (3, 8, 8, 512), (2, 16, 16, 32)])
 def test_batchnorm_relu_fwd_bwd(shape, dt):
@@ -200,7 +232,10 @@ def test_batchnorm_relu_fwd_bwd(shape, dt):
     ref = F.relu(F.batch_norm(zq, rm_r, rv_r, g_r, b_r, training=True, momentum=0.1, eps=1e-5))
     z_d = z.to(DEV).permute(0, 2, 3, 1).contiguous().to(dt)
     zf = z_d.float().reshape(-1, c)
-    stats = torch.stack([zf.sum(0), (zf * zf).sum(0)])[None].contiguous()          # one partial row
+    # three partial rows of unequal size in the epilogue's (mean, M2, count) form
+    parts = torch.split(zf, [zf.shape[0] // 2, zf.shape[0] // 3, zf.shape[0] - zf.shape[0] // 2 - zf.shape[0] // 3])
+    stats = torch.stack([torch.stack([pz.mean(0), ((pz - pz.mean(0)) ** 2).sum(0), torch.full((c,), float(pz.shape[0]), device=DEV)])
+                         for pz in parts]).contiguous()
     rm_d, rv_d = rm.to(DEV), rv.to(DEV)
     mean_invstd, scale_shift = nn_ops.bn_finalize(stats, b * h * w, gamma.to(DEV), beta.to(DEV), rm_d, rv_d, 0.1, 1e-5)
     a = nn_ops.bn_relu_apply(z_d, scale_shift)
