@@ -82,32 +82,45 @@ __global__ __launch_bounds__(256) void smallconv_s2l_kernel(S2LArgs a) {
   }
   __syncthreads();
   T* outb = reinterpret_cast<T*>(a.out) + (size_t)b * a.H * a.W * CL + c0;
-#pragma unroll 2
-  for (int pass = 0; pass < PASSES; ++pass) {
-    const int px = pass * PPP + tid / G;
-    const int ty = px / TS, tx = px % TS;
-    float acc[8];
+  // all of this thread's pixels advance together through (input channel, tap), so a weight vector fetched from LDS
+  // (or held in registers) serves PASSES pixels; per output the summation order stays bias, then (s, tap) ascending
+  const int q = tid / G;
+  const int qy = q / TS, qx = q % TS;                    // pixel of pass p: (qy + p * PPP / TS, qx)
+  float accv[PASSES][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = b0[k];
-    if constexpr (W_REGS) {
+  for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) accv[p][k] = b0[k];
+  if constexpr (W_REGS) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        const float xv = s_in[0][qy + p * (PPP / TS) + tap / 3][qx + tap % 3];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) accv[p][k] += xv * wreg[tap][k];
+      }
+  } else {
+    for (int s = 0; s < a.CS; ++s) {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const float xv = s_in[0][ty + tap / 3][tx + tap % 3];
+        const float4 w0 = *reinterpret_cast<const float4*>(&s_w[(s * 9 + tap) * CL + c0]);
+        const float4 w1 = *reinterpret_cast<const float4*>(&s_w[(s * 9 + tap) * CL + c0 + 4]);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] += xv * wreg[tap][k];
-      }
-    } else {
-      for (int s = 0; s < a.CS; ++s) {
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const float xv = s_in[s][ty + tap / 3][tx + tap % 3];
-          const float4 w0 = *reinterpret_cast<const float4*>(&s_w[(s * 9 + tap) * CL + c0]);
-          const float4 w1 = *reinterpret_cast<const float4*>(&s_w[(s * 9 + tap) * CL + c0 + 4]);
-          acc[0] += xv * w0.x; acc[1] += xv * w0.y; acc[2] += xv * w0.z; acc[3] += xv * w0.w;
-          acc[4] += xv * w1.x; acc[5] += xv * w1.y; acc[6] += xv * w1.z; acc[7] += xv * w1.w;
+        for (int p = 0; p < PASSES; ++p) {
+          const float xv = s_in[s][qy + p * (PPP / TS) + tap / 3][qx + tap % 3];
+          accv[p][0] += xv * w0.x; accv[p][1] += xv * w0.y; accv[p][2] += xv * w0.z; accv[p][3] += xv * w0.w;
+          accv[p][4] += xv * w1.x; accv[p][5] += xv * w1.y; accv[p][6] += xv * w1.z; accv[p][7] += xv * w1.w;
         }
       }
     }
+  }
+#pragma unroll
+  for (int pass = 0; pass < PASSES; ++pass) {
+    const int ty = qy + pass * (PPP / TS), tx = qx;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = accv[pass][k];
     if (a.scale_shift) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[k] = acc[k] * sc[k] + sh[k];
@@ -242,55 +255,75 @@ struct SWArgs {
   int B, H, W, CS, tilesY, tilesX;
 };
 
-template <typename T, int CL>
+// Persistent blocks: a block walks tiles t = blockIdx.x, += gridDim.x and keeps its sums in registers, so there is one
+// partial row per block (not per tile) and one LDS reduction at the end.  Thread = (wide-side channel l, row group g):
+// it walks its tile rows pixel by pixel with the 3x3 window of the small side sliding through registers (3 new LDS
+// broadcast reads per pixel and input channel instead of 9).
+// CSB = compile-time bound on the small side's channel count (1, 2, 4 or 8): the accumulators acc[CSB][9] must be
+// register-resident, and a bound of 8 for a 1-channel input would cost the occupancy.
+template <typename T, int CL, int CSB>
 __global__ __launch_bounds__(256) void smallconv_wgrad_kernel(SWArgs a) {
   constexpr int N = Vec16<T>::N;
   constexpr int G = 256 / CL;
+  constexpr int RPG = TS / G;                       // tile rows per group
   __shared__ __attribute__((aligned(16))) T s_L[TS * TS][CL];
   __shared__ float s_S[CS_MAX][HS][HS + 1];
   __shared__ float s_red[G][9][CL];
   __shared__ float s_b[G];
   const int tid = threadIdx.x;
-  int t = blockIdx.x;
-  const int tx_id = t % a.tilesX; t /= a.tilesX;
-  const int ty_id = t % a.tilesY;
-  const int b = t / a.tilesY;
-  const int y0 = ty_id * TS, x0 = tx_id * TS;
-  const float* Sb = a.S + (size_t)b * a.CS * a.H * a.W;
-  const T* Lb = reinterpret_cast<const T*>(a.L) + (size_t)b * a.H * a.W * CL;
-  for (int i = tid; i < a.CS * HS * HS; i += 256) {
-    const int s = i / (HS * HS), r = i % (HS * HS);
-    const int hy = r / HS, hx = r % HS;
-    const int yy = y0 + hy - 1, xx = x0 + hx - 1;
-    s_S[s][hy][hx] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? Sb[((size_t)s * a.H + yy) * a.W + xx] : 0.f;
-  }
-  constexpr int PPR = CL / N;
-  for (int i = tid; i < TS * TS * PPR; i += 256) {
-    const int px = i / PPR, part = i % PPR;
-    const int yy = y0 + px / TS, xx = x0 + px % TS;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (yy < a.H && xx < a.W) v = *reinterpret_cast<const uint4*>(Lb + ((size_t)yy * a.W + xx) * CL + part * N);
-    *reinterpret_cast<uint4*>(&s_L[px][part * N]) = v;
-  }
-  __syncthreads();
   const int l = tid % CL, g = tid / CL;
-  float acc[CS_MAX][9];
-  float bsum[CS_MAX];
+  float acc[CSB][9];
+  float bsum[CSB];
 #pragma unroll
-  for (int s = 0; s < CS_MAX; ++s) {
+  for (int s = 0; s < CSB; ++s) {
     bsum[s] = 0.f;
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) acc[s][tp] = 0.f;
   }
-  for (int px = g; px < TS * TS; px += G) {
-    const float lv = to_float(s_L[px][l]);
-    const int ty = px / TS, tx = px % TS;
+  const int ntiles = a.B * a.tilesY * a.tilesX;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int t = tile;
+    const int tx_id = t % a.tilesX; t /= a.tilesX;
+    const int ty_id = t % a.tilesY;
+    const int b = t / a.tilesY;
+    const int y0 = ty_id * TS, x0 = tx_id * TS;
+    const float* Sb = a.S + (size_t)b * a.CS * a.H * a.W;
+    const T* Lb = reinterpret_cast<const T*>(a.L) + (size_t)b * a.H * a.W * CL;
+    __syncthreads();                                // the previous tile's readers are done
+    for (int i = tid; i < a.CS * HS * HS; i += 256) {
+      const int s = i / (HS * HS), r = i % (HS * HS);
+      const int hy = r / HS, hx = r % HS;
+      const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+      s_S[s][hy][hx] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? Sb[((size_t)s * a.H + yy) * a.W + xx] : 0.f;
+    }
+    constexpr int PPR = CL / N;
+    for (int i = tid; i < TS * TS * PPR; i += 256) {
+      const int px = i / PPR, part = i % PPR;
+      const int yy = y0 + px / TS, xx = x0 + px % TS;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (yy < a.H && xx < a.W) v = *reinterpret_cast<const uint4*>(Lb + ((size_t)yy * a.W + xx) * CL + part * N);
+      *reinterpret_cast<uint4*>(&s_L[px][part * N]) = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int rr = 0; rr < RPG; ++rr) {
+      const int ty = g * RPG + rr;
 #pragma unroll
-    for (int s = 0; s < CS_MAX; ++s) {
-      if (s < a.CS) {
+      for (int s = 0; s < CSB; ++s) {
+        if (s < a.CS) {
+          float w[3][3];
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) acc[s][tp] += lv * s_S[s][ty + tp / 3][tx + tp % 3];
-        bsum[s] += s_S[s][ty + 1][tx + 1];
+          for (int dy = 0; dy < 3; ++dy) { w[dy][1] = s_S[s][ty + dy][0]; w[dy][2] = s_S[s][ty + dy][1]; }
+#pragma unroll
+          for (int tx = 0; tx < TS; ++tx) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) { w[dy][0] = w[dy][1]; w[dy][1] = w[dy][2]; w[dy][2] = s_S[s][ty + dy][tx + 2]; }
+            const float lv = to_float(s_L[ty * TS + tx][l]);
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) acc[s][tp] += lv * w[tp / 3][tp % 3];
+            bsum[s] += w[1][1];
+          }
+        }
       }
     }
   }
@@ -302,13 +335,13 @@ __global__ __launch_bounds__(256) void smallconv_wgrad_kernel(SWArgs a) {
     for (int tp = 0; tp < 9; ++tp) {
       float v = 0.f;
 #pragma unroll
-      for (int q = 0; q < CS_MAX; ++q) if (q == s) v = acc[q][tp];
+      for (int q = 0; q < CSB; ++q) if (q == s) v = acc[q][tp];
       s_red[g][tp][l] = v;
     }
     if (l == 0) {
       float v = 0.f;
 #pragma unroll
-      for (int q = 0; q < CS_MAX; ++q) if (q == s) v = bsum[q];
+      for (int q = 0; q < CSB; ++q) if (q == s) v = bsum[q];
       s_b[g] = v;
     }
     __syncthreads();
@@ -389,7 +422,7 @@ extern "C" int im2im_smallconv_l2s_fwd(const void* in, const float* w, const flo
 
 extern "C" int64_t im2im_smallconv_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t CS, int32_t CL) {
   const int64_t K = (int64_t)CS * 9 * CL + CS;
-  return im2im_smallconv_tiles(B, H, W) * K * (int64_t)sizeof(float) + im2im::reduce_tmp_bytes(K);
+  return std::min<int64_t>(im2im_smallconv_tiles(B, H, W), 2048) * K * (int64_t)sizeof(float) + im2im::reduce_tmp_bytes(K);
 }
 
 extern "C" int im2im_smallconv_wgrad(const float* S, const void* L, float* dw, float* dbias, int32_t B, int32_t H, int32_t W,
@@ -398,14 +431,18 @@ extern "C" int im2im_smallconv_wgrad(const float* S, const void* L, float* dw, f
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(S && L && dw && ws && B > 0 && H > 0 && W > 0 && CS >= 1 && CS <= CS_MAX);
   IM2IM_REQUIRE(ws_bytes >= im2im_smallconv_wgrad_workspace_bytes(B, H, W, CS, CL));
-  const int64_t nblk = im2im_smallconv_tiles(B, H, W);
+  const int64_t nblk = std::min<int64_t>(im2im_smallconv_tiles(B, H, W), 2048);   // persistent blocks, one partial row each
   const int64_t K = (int64_t)CS * 9 * CL + CS;
   float* partial = (float*)ws;
   double* tmp = (double*)((char*)ws + nblk * K * sizeof(float));
   SWArgs a{S, L, partial, B, H, W, CS, (int)cdiv(H, TS), (int)cdiv(W, TS)};
   return for_dtype_cl(dtype, CL, [&](auto* tag, auto cl) {
     using T = std::remove_pointer_t<decltype(tag)>;
-    hipLaunchKernelGGL((smallconv_wgrad_kernel<T, decltype(cl)::value>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
+    constexpr int CLv = decltype(cl)::value;
+    if (CS == 1) hipLaunchKernelGGL((smallconv_wgrad_kernel<T, CLv, 1>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
+    else if (CS == 2) hipLaunchKernelGGL((smallconv_wgrad_kernel<T, CLv, 2>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
+    else if (CS <= 4) hipLaunchKernelGGL((smallconv_wgrad_kernel<T, CLv, 4>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((smallconv_wgrad_kernel<T, CLv, 8>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
     if (int rc = check_launch("smallconv_wgrad_kernel")) return rc;
     int rc;
     const int Sp = launch_reduce_stage1(partial, nblk, K, tmp, stream, &rc);
