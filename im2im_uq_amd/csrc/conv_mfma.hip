@@ -20,6 +20,9 @@
 #ifndef IM2IM_SETPRIO
 #define IM2IM_SETPRIO 0
 #endif
+#ifndef IM2IM_WGRAD_XCD
+#define IM2IM_WGRAD_XCD 1
+#endif
 #include <type_traits>
 
 namespace {
@@ -114,12 +117,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5, l31 = lane & 31;
 
-  int mt_id = blockIdx.x;
+  const int tile_id = blockIdx.x, cob = blockIdx.y;
+  int mt_id = tile_id;
   const int tx_id = mt_id % a.tilesX; mt_id /= a.tilesX;
   const int ty_id = mt_id % a.tilesY;
   const int b0 = (mt_id / a.tilesY) * TB;             // first image of this tile (TB images share the weight tiles)
   const int y0 = ty_id * TH, x0 = tx_id * TW;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = cob * BN;
 
   const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int i = 1; i < WM; ++i)
         merge_moments_f32(n, m, q, ldsS[(i * BN + tid) * 3 + 0], ldsS[(i * BN + tid) * 3 + 1], ldsS[(i * BN + tid) * 3 + 2]);
-      float* st = a.stats + (size_t)blockIdx.x * 3 * a.Co;
+      float* st = a.stats + (size_t)tile_id * 3 * a.Co;
       st[n0 + tid] = m;
       st[a.Co + n0 + tid] = q;
       st[2 * a.Co + n0 + tid] = n;
@@ -600,7 +604,19 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
   const int wco = (wave >> 1) & 1, wci = wave & 1;
   const int half = lane >> 5, l31 = lane & 31;
   const int ci_tiles = a.Ci / CT;
-  const int co0 = (blockIdx.x / ci_tiles) * CT, ci0 = (blockIdx.x % ci_tiles) * CT;
+  // Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest).  All channel blocks of one pixel
+  // split read the same dz / x pixels, so they are renumbered to sit on ONE XCD and share them through its L2
+  // instead of each XCD fetching them from HBM.
+  int cb = blockIdx.x, split = blockIdx.y;
+#if IM2IM_WGRAD_XCD
+  if ((gridDim.y & 7) == 0) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, j = lin >> 3;
+    split = (j / (int)gridDim.x) * 8 + xcd;
+    cb = j % (int)gridDim.x;
+  }
+#endif
+  const int co0 = (cb / ci_tiles) * CT, ci0 = (cb % ci_tiles) * CT;
   const WgradSrc<T> xs(a, ci0);
   const T* __restrict__ xg = xs.x;
   const T* __restrict__ dzg = reinterpret_cast<const T*>(a.dz);
@@ -701,7 +717,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
     }
   };
 
-  const int t_begin = blockIdx.y * a.tiles_per_split;
+  const int t_begin = split * a.tiles_per_split;
   const int t_end = min(t_begin + a.tiles_per_split, a.ntiles);
   if (t_begin < t_end) {
     gload(t_begin);
@@ -717,7 +733,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
       cur ^= 1;
     }
   }
-  float* out = a.partial + (size_t)blockIdx.y * a.Co * 9 * a.Ci;
+  float* out = a.partial + (size_t)split * a.Co * 9 * a.Ci;
 #pragma unroll
   for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
