@@ -744,18 +744,30 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
     }
 }
 
-// sum partial[nsplit][Co][TAPS][Ci] over splits and write torch layout dw[Co][Ci][TAPS]
+// sum partial[nsplit][Co][TAPS][Ci] over splits and write torch layout dw[Co][Ci][TAPS].  Block = 64 outputs x 4 split
+// lanes (lane s adds splits s, s+4, ... in order, the four partial sums are combined in a fixed order): deterministic,
+// and the many-split / few-output case (the 1x1 OutConv) does not serialise on one thread per output.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int Co, int Ci,
                                                             int taps, float* __restrict__ dw) {
+  __shared__ float s_acc[4][64];
   const size_t total = (size_t)Co * taps * Ci;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+  const int ol = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
+    const size_t i = base + ol;
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * total + i];
-    const int ci = (int)(i % Ci);
-    const size_t r = i / Ci;
-    const int tp = (int)(r % taps);
-    const size_t co = r / taps;
-    dw[(co * Ci + ci) * taps + tp] = s;
+    if (i < total)
+      for (int k = sl; k < nsplit; k += 4) s += partial[(size_t)k * total + i];
+    s_acc[sl][ol] = s;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+      const float v = (s_acc[0][ol] + s_acc[1][ol]) + (s_acc[2][ol] + s_acc[3][ol]);
+      const int ci = (int)(i % Ci);
+      const size_t r = i / Ci;
+      const int tp = (int)(r % taps);
+      const size_t co = r / taps;
+      dw[(co * Ci + ci) * taps + tp] = v;
+    }
+    __syncthreads();
   }
 }
 
@@ -893,7 +905,7 @@ int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float
   const size_t wsz = (size_t)Co * TAPS * Ci * sizeof(float);
   int64_t max_split = partial_bytes / (int64_t)wsz;
   if (max_split < 1) return fail_invalid("wgrad: workspace smaller than one weight-sized slab");
-  int64_t nsplit = cdiv((IS_BF16 && TAPS == 9) ? 256 : 512, cblocks);   // pipelined kernel: one workgroup per CU
+  int64_t nsplit = cdiv((IS_BF16 && TAPS == 9) ? 256 : (TAPS == 1 ? 1536 : 512), cblocks);   // pipelined kernel: one workgroup per CU; 1x1: latency-bound, many small blocks
   if (nsplit > a.ntiles) nsplit = a.ntiles;
   if (nsplit > max_split) nsplit = max_split;
   if (nsplit < 1) nsplit = 1;
@@ -920,7 +932,7 @@ int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float
     if (int rc = check_launch("conv_wgrad_kernel")) return rc;
   }
   const size_t total = (size_t)Co * TAPS * Ci;
-  int blocks = (int)std::min<size_t>(cdiv(total, 256), 4096);
+  int blocks = (int)std::min<size_t>(cdiv(total, 64), 8192);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, (int)nsplit, Co, Ci, TAPS, dw);
   return check_launch("wgrad_reduce_kernel");
 }
@@ -930,7 +942,7 @@ extern "C" int64_t im2im_conv_wgrad_workspace_bytes(int32_t B, int32_t H, int32_
   if (Ci <= 0 || Co <= 0 || Ci % 64 || Co % 32) return -1;
   const int64_t ntiles = (int64_t)B * im2im::cdiv(H, 8) * im2im::cdiv(W, 16);
   const int64_t cblocks = im2im::cdiv(Co, 64) * (Ci / 64);
-  int64_t nsplit = im2im::cdiv(512, cblocks);
+  int64_t nsplit = im2im::cdiv(taps == 1 ? 1536 : 512, cblocks);
   if (nsplit > ntiles) nsplit = ntiles;
   if (nsplit < 1) nsplit = 1;
   return nsplit * (int64_t)Co * taps * Ci * (int64_t)sizeof(float);
