@@ -35,9 +35,9 @@ SIGNATURES = {
     "im2im_abi_version": (_i32, []),
     "im2im_last_error": (ctypes.c_char_p, []),
     "im2im_rcps_workspace_bytes": (_i64, [_i64, _i64, _i32]),
-    "im2im_rcps_loss_table": (_i32, [_ptr, _ptr, _i64, _i64, _ptr, _i32, _ptr, _ptr, _ptr, _ptr]),
-    "im2im_rcps_miscoverage": (_i32, [_ptr, _ptr, _i64, _i32, _i64, _f32, _ptr, _ptr]),
-    "im2im_nested_sets": (_i32, [_ptr, _i64, _i64, _f32, _ptr, _ptr, _i32, _ptr]),
+    "im2im_rcps_loss_table": (_i32, [_ptr, _ptr, _i64, _i64, _ptr, _i32, _i32, _ptr, _ptr, _ptr, _ptr]),
+    "im2im_rcps_miscoverage": (_i32, [_ptr, _ptr, _i64, _i32, _i64, _f32, _i32, _ptr, _ptr]),
+    "im2im_nested_sets": (_i32, [_ptr, _i64, _i64, _f32, _i32, _ptr, _ptr, _i32, _i32, _ptr]),
     "im2im_fraction_missed": (_i32, [_ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr]),
     "im2im_hb_mu_plus": (_f64, [_f64, _i64, _f64, _i32]),
     "im2im_pack_conv_weight": (_i32, [_ptr, _i32, _i32, _i32, _i32, _ptr, _ptr, _ptr]),
@@ -73,6 +73,10 @@ SIGNATURES = {
     "im2im_quantile_loss_workspace_bytes": (_i64, []),
     "im2im_quantile_loss_fwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _ptr, _ptr, _ptr]),
     "im2im_quantile_loss_bwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _i64, _ptr]),
+    # kind, a, b, c, target, N, P, img_stride, q_lo, q_hi, w0, w1, w2, loss, ws, stream
+    "im2im_uq_loss_fwd": (_i32, [_i32, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _ptr, _ptr, _ptr]),
+    # kind, a, b, c, target, N, P, img_stride, q_lo, q_hi, w0, w1, w2, grad_out, d_a, d_b, d_c, d_stride, stream
+    "im2im_uq_loss_bwd": (_i32, [_i32, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _i64, _ptr]),
     "im2im_adam_step": (_i32, [_i32, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _f32, _f32, _i64, _ptr]),
 }
 for _name, (_res, _args) in SIGNATURES.items():

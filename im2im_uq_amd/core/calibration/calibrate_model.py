@@ -24,6 +24,7 @@ from torch.utils.data import DataLoader, Subset, TensorDataset
 
 from .. import _pkg  # noqa: F401
 from ... import hip_ops
+from ..models.add_uncertainty import sets_form
 from .bounds import HB_mu_plus
 
 
@@ -85,9 +86,10 @@ def _as_device_pair(out_dataset, device):
 def get_rcps_losses_from_outputs(model, out_dataset, rcps_loss_fn, lam, device):
     """Losses [N] (cpu) of every image at ONE lambda (reference :21-29)."""
     outputs, labels = _as_device_pair(out_dataset, device)
-    if rcps_loss_fn is fraction_missed_loss:
+    form = sets_form(model)
+    if rcps_loss_fn is fraction_missed_loss and form is not None:
         lam_t = torch.as_tensor(lam, dtype=torch.float32).reshape(1)
-        return hip_ops.rcps_loss_table(outputs, labels, lam_t)[:, 0].cpu()
+        return hip_ops.rcps_loss_table(outputs, labels, lam_t, form=form)[:, 0].cpu()
     model = model.to(device)
     losses = []
     for s in range(0, outputs.shape[0], 64):          # user-supplied loss: same batching as the reference
@@ -114,14 +116,18 @@ def get_rcps_metrics_from_outputs(model, out_dataset, rcps_loss_fn, device):
         raise Exception("You have to specify lambda unless your model is already calibrated.")
     lhat = float(model.lhat)
     n = outputs.shape[0]
-    losses = hip_ops.rcps_loss_table(outputs, labels, torch.tensor([lhat], dtype=torch.float32))[:, 0]
+    form = sets_form(model)
+    if form is None:
+        raise NotImplementedError("get_rcps_metrics_from_outputs needs one of this package's nested-set functions")
+    k = outputs.shape[1]
+    losses = hip_ops.rcps_loss_table(outputs, labels, torch.tensor([lhat], dtype=torch.float32), form=form)[:, 0]
     # one random pixel per image: interval size and |residual| (reference :43-46)
     p = outputs[0, 0].numel()
     idx = np.concatenate([np.random.choice(p, size=min(64, n - s)) for s in range(0, n, 64)]) if n else np.zeros(0, int)
     idx_t = torch.from_numpy(idx).to(device)
     rows = torch.arange(n, device=device)
-    picked = outputs.flatten(start_dim=2)[rows, :, idx_t].reshape(n, 3, 1).contiguous()        # [N,3,1]
-    lo, mid, up = hip_ops.nested_sets(picked, lhat)
+    picked = outputs.flatten(start_dim=2)[rows, :, idx_t].reshape(n, k, 1).contiguous()        # [N,K,1]
+    lo, mid, up = hip_ops.nested_sets(picked, lhat, form=form)
     sizes = (up - lo).reshape(n).cpu()
     residuals = (labels.flatten(start_dim=1)[rows, idx_t] - mid.reshape(n)).abs()
     # the reference iterates one DataLoader here, whose iterator draws its base seed from torch's default
@@ -132,7 +138,7 @@ def get_rcps_metrics_from_outputs(model, out_dataset, rcps_loss_fn, device):
     spearman = spearmanr(residuals, sizes)[0]
     mse = (residuals * residuals).mean().item()
     c = outputs.shape[2]
-    counts = hip_ops.rcps_miscoverage(outputs, labels, lhat).reshape((c,) + tuple(outputs.shape[3:]))
+    counts = hip_ops.rcps_miscoverage(outputs, labels, lhat, form=form).reshape((c,) + tuple(outputs.shape[3:]))
     # reference: float32 mean over images, then float32 mean over the channel axis (:55)
     spatial_miscoverage = (counts.cpu().numpy().astype(np.float32) / np.float32(n)).mean(axis=0)
     size_bins = torch.tensor([0, torch.quantile(sizes, 0.25), torch.quantile(sizes, 0.5), torch.quantile(sizes, 0.75)])
@@ -243,8 +249,9 @@ def calibrate_model(model, dataset, config):
         outputs, labels = collect_outputs(model, dataset, config, device)
         dlambda = lambdas[1] - lambdas[0]
         model.set_lhat(lambdas[-1] + dlambda - 1e-9)
-        if rcps_loss_fn is fraction_missed_loss:
-            table = hip_ops.rcps_loss_table(outputs, labels, lambdas - dlambda)       # one pass, all lambdas
+        form = sets_form(model)
+        if rcps_loss_fn is fraction_missed_loss and form is not None:
+            table = hip_ops.rcps_loss_table(outputs, labels, lambdas - dlambda, form=form)   # one pass, all lambdas
         else:                                                 # plugin loss: per-lambda, still device-resident
             ds = TensorDataset(outputs, labels)
             table = torch.stack([get_rcps_losses_from_outputs(model, ds, rcps_loss_fn, lam - dlambda, device)

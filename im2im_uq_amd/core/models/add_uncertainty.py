@@ -5,8 +5,9 @@ final layer chosen by params["uncertainty_type"] and returns a ModelWithUncertai
 API as the reference (:15-49): forward, loss_fn, nested_sets_from_output, nested_sets, set_lhat,
 buffer `lhat`, attributes baseModel / last_layer / params.  state_dict keys are the reference's.
 
-Scope of this build: "quantiles" is implemented on HIP kernels; the other six
-heuristics are out of scope for now and raise NotImplementedError naming themselves.
+Scope of this build (SURVEY section 8 + 8f rank 1): "quantiles", "quantiles_l1", "gaussian", "residual_magnitude" and
+"residual_magnitude_l1" run on the HIP kernels (same trunk, heads and calibration kernels; only the head count, the
+fused loss and the nested-set formula differ); "softmax" and "inn" raise NotImplementedError naming themselves.
 """
 import torch
 import torch.nn as nn
@@ -15,6 +16,20 @@ from .. import _pkg  # noqa: F401
 from ... import hip_ops
 from .finallayers.quantile_layer import (QuantileRegressionLayer, quantile_regression_loss_fn,
                                          quantile_regression_nested_sets_from_output)
+from .finallayers.quantile_l1_layer import (QuantileRegressionL1Layer, quantile_regression_l1_loss_fn,
+                                            quantile_regression_l1_nested_sets_from_output)
+from .finallayers.gaussian_layer import (GaussianRegressionLayer, gaussian_regression_loss_fn,
+                                         gaussian_regression_nested_sets_from_output)
+from .finallayers.residual_magnitude_layer import (ResidualMagnitudeLayer, residual_magnitude_loss_fn,
+                                                   residual_magnitude_nested_sets_from_output)
+from .finallayers.residual_magnitude_l1_layer import (ResidualMagnitudeL1Layer, residual_magnitude_l1_loss_fn,
+                                                      residual_magnitude_l1_nested_sets_from_output)
+
+
+def sets_form(model):
+    """IM2IM_SETS_* form of the model's nested sets when they are one of this package's (then every calibration kernel
+    evaluates them directly from the raw output planes), else None (plugin function: generic per-lambda path)."""
+    return getattr(getattr(model, "in_nested_sets_from_output_fn", None), "im2im_sets_form", None)
 
 
 class ModelWithUncertainty(nn.Module):
@@ -36,9 +51,9 @@ class ModelWithUncertainty(nn.Module):
 
     def nested_sets_from_output(self, output, lam=None):
         """(lower_edge, prediction, upper_edge) with the +-1e-6 floor (reference :33-38)."""
-        if self.in_nested_sets_from_output_fn is quantile_regression_nested_sets_from_output and output.is_cuda:
-            # fused HIP path: clamp, scale and floor in one kernel (identical fp32 op order)
-            return quantile_regression_nested_sets_from_output(self, output, lam, _floor=True)
+        if sets_form(self) is not None and output.is_cuda:
+            # fused HIP path: (clamp,) scale and floor in one kernel (identical fp32 op order)
+            return self.in_nested_sets_from_output_fn(self, output, lam, _floor=True)
         lower_edge, prediction, upper_edge = self.in_nested_sets_from_output_fn(self, output, lam)
         upper_edge = torch.maximum(upper_edge, prediction + 1e-6)
         lower_edge = torch.minimum(lower_edge, prediction - 1e-6)
@@ -56,7 +71,7 @@ class ModelWithUncertainty(nn.Module):
         self.lhat = lhat
 
 
-_OUT_OF_SCOPE = ("quantiles_l1", "gaussian", "residual_magnitude", "residual_magnitude_l1", "softmax", "inn")
+_OUT_OF_SCOPE = ("softmax", "inn")
 
 
 def add_uncertainty(model, params):
@@ -64,10 +79,26 @@ def add_uncertainty(model, params):
         last_layer = QuantileRegressionLayer(model.n_channels_middle, model.n_channels_out, params)
         train_loss_fn = quantile_regression_loss_fn
         nested_sets_from_output_fn = quantile_regression_nested_sets_from_output
+    elif params["uncertainty_type"] == "quantiles_l1":
+        last_layer = QuantileRegressionL1Layer(model.n_channels_middle, model.n_channels_out, params)
+        train_loss_fn = quantile_regression_l1_loss_fn
+        nested_sets_from_output_fn = quantile_regression_l1_nested_sets_from_output
+    elif params["uncertainty_type"] == "gaussian":
+        last_layer = GaussianRegressionLayer(model.n_channels_middle, model.n_channels_out, params)
+        train_loss_fn = gaussian_regression_loss_fn
+        nested_sets_from_output_fn = gaussian_regression_nested_sets_from_output
+    elif params["uncertainty_type"] == "residual_magnitude":
+        last_layer = ResidualMagnitudeLayer(model.n_channels_middle, model.n_channels_out, params)
+        train_loss_fn = residual_magnitude_loss_fn
+        nested_sets_from_output_fn = residual_magnitude_nested_sets_from_output
+    elif params["uncertainty_type"] == "residual_magnitude_l1":
+        last_layer = ResidualMagnitudeL1Layer(model.n_channels_middle, model.n_channels_out, params)
+        train_loss_fn = residual_magnitude_l1_loss_fn
+        nested_sets_from_output_fn = residual_magnitude_l1_nested_sets_from_output
     elif params["uncertainty_type"] in _OUT_OF_SCOPE:
         raise NotImplementedError(
-            f"uncertainty_type={params['uncertainty_type']!r} is outside this build's hot-path scope "
-            "(SURVEY.md section 8f, rank 1); only 'quantiles' runs on the HIP kernels so far")
+            f"uncertainty_type={params['uncertainty_type']!r} is outside this build's scope (SURVEY.md section 8f): "
+            "the quantile, gaussian and residual-magnitude families run on the HIP kernels; softmax and inn do not yet")
     else:
         raise NotImplementedError
     return ModelWithUncertainty(model, last_layer, train_loss_fn, nested_sets_from_output_fn, params)

@@ -11,6 +11,7 @@ from .. import _pkg  # noqa: F401
 from ... import hip_ops
 from ..calibration.calibrate_model import (collect_outputs, fraction_missed_loss, gather_rows, get_rcps_loss_fn,
                                            get_rcps_losses_from_outputs, get_rcps_metrics_from_outputs, lambda_grid, _dist)
+from ..models.add_uncertainty import sets_form
 from ._wandb import wandb
 
 
@@ -83,8 +84,9 @@ def get_loss_table(model, dataset, config):
         rcps_loss_fn = get_rcps_loss_fn(config)
         model = model.to(device)
         outputs, labels = _outputs_for(model, dataset, config, device)
-        if rcps_loss_fn is fraction_missed_loss:
-            table = hip_ops.rcps_loss_table(outputs, labels, lambdas)
+        form = sets_form(model)
+        if rcps_loss_fn is fraction_missed_loss and form is not None:
+            table = hip_ops.rcps_loss_table(outputs, labels, lambdas, form=form)
         else:
             ds = TensorDataset(outputs, labels)
             table = torch.stack([get_rcps_losses_from_outputs(model, ds, rcps_loss_fn, lam, device) for lam in lambdas], dim=1).to(device)

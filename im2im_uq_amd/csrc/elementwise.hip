@@ -672,23 +672,53 @@ __global__ __launch_bounds__(256) void upcat_bwd_kernel(const T* __restrict__ do
 // so PinballLoss alone can reuse it.  sums[3] (fp64 via partials) then
 //   loss = w_lo * S_lo/P + w_hi * S_hi/P + w_mse * S_mse/P
 struct LossArgs {
-  const float* lo; const float* mid; const float* hi; const float* y;
+  const float* lo; const float* mid; const float* hi; const float* y;   // planes a, b, c (hi may be null) and the target
   int64_t N, P, img_stride;      // planes: ptr + n*img_stride + i ; y: n*P + i
   float q_lo, q_hi;
+  int kind;                      // IM2IM_LOSS_*
 };
+__device__ __forceinline__ float pinball_term(float e, float q) {         // losses/pinball.py:17-24
+  return (e < 0.f) ? q * fabsf(e) : (e > 0.f ? (1.f - q) * fabsf(e) : 0.f);
+}
+__device__ __forceinline__ float sign0(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+constexpr float GNLL_EPS = 1e-6f;                                          // torch.nn.GaussianNLLLoss default
+
+// per-element terms t[0..2] of the three mean-reduced sums (unused ones stay 0)
+__device__ __forceinline__ void loss_terms(const LossArgs& a, int64_t n, int64_t p, float y, float (&t)[3]) {
+  const float va = a.lo[n * a.img_stride + p];
+  const float vb = a.mid[n * a.img_stride + p];
+  t[0] = t[1] = t[2] = 0.f;
+  switch (a.kind) {
+    case IM2IM_LOSS_QUANTILE:
+    case IM2IM_LOSS_QUANTILE_L1: {
+      const float vc = a.hi[n * a.img_stride + p];
+      const float em = vb - y;
+      t[0] = pinball_term(va - y, a.q_lo);
+      t[1] = pinball_term(vc - y, a.q_hi);
+      t[2] = a.kind == IM2IM_LOSS_QUANTILE ? em * em : fabsf(em);
+      break;
+    }
+    case IM2IM_LOSS_GAUSSIAN: {
+      const float v = fmaxf(vb, GNLL_EPS), e = va - y;
+      t[0] = 0.5f * (logf(v) + e * e / v);
+      break;
+    }
+    default: {                                                              // RESIDUAL, RESIDUAL_L1
+      const float e = va - y, r = vb - fabsf(y - va);
+      t[0] = a.kind == IM2IM_LOSS_RESIDUAL ? e * e : fabsf(e);
+      t[1] = r * r;
+    }
+  }
+}
 __global__ __launch_bounds__(256) void qloss_partial_kernel(LossArgs a, float* __restrict__ partial) {
   __shared__ float s_red[3][4];
   const int64_t total = a.N * a.P;
   float s_lo = 0.f, s_hi = 0.f, s_m = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t n = i / a.P, p = i - n * a.P;
-    const float y = a.y[i];
-    const float el = a.lo[n * a.img_stride + p] - y;
-    const float eh = a.hi[n * a.img_stride + p] - y;
-    const float em = a.mid[n * a.img_stride + p] - y;
-    s_lo += (el < 0.f) ? a.q_lo * fabsf(el) : (el > 0.f ? (1.f - a.q_lo) * fabsf(el) : 0.f);
-    s_hi += (eh < 0.f) ? a.q_hi * fabsf(eh) : (eh > 0.f ? (1.f - a.q_hi) * fabsf(eh) : 0.f);
-    s_m += em * em;
+    float t[3];
+    loss_terms(a, n, p, a.y[i], t);
+    s_lo += t[0]; s_hi += t[1]; s_m += t[2];
   }
   for (int off = 32; off > 0; off >>= 1) {
     s_lo += __shfl_down(s_lo, off, 64); s_hi += __shfl_down(s_hi, off, 64); s_m += __shfl_down(s_m, off, 64);
@@ -707,7 +737,7 @@ __global__ void qloss_final_kernel(const double* __restrict__ tmp, int S, double
   const float l0 = (float)(s[0] / count), l1 = (float)(s[1] / count), l2 = (float)(s[2] / count);
   loss[0] = w_lo * l0 + w_hi * l1 + w_mse * l2;
 }
-// d(pred)[N][3][P] fp32 ; gscale points at the upstream scalar gradient on the device
+// d(pred) planes, fp32 ; gscale points at the upstream scalar gradient on the device
 __global__ __launch_bounds__(256) void qloss_bwd_kernel(LossArgs a, const float* __restrict__ gscale, float w_lo, float w_hi,
                                                          float w_mse, float* __restrict__ d_lo, float* __restrict__ d_mid,
                                                          float* __restrict__ d_hi, int64_t d_stride) {
@@ -716,12 +746,36 @@ __global__ __launch_bounds__(256) void qloss_bwd_kernel(LossArgs a, const float*
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t n = i / a.P, p = i - n * a.P;
     const float y = a.y[i];
-    const float el = a.lo[n * a.img_stride + p] - y;
-    const float eh = a.hi[n * a.img_stride + p] - y;
-    const float em = a.mid[n * a.img_stride + p] - y;
-    if (d_lo) d_lo[n * d_stride + p] = g * w_lo * (el < 0.f ? -a.q_lo : (el > 0.f ? 1.f - a.q_lo : 0.f));
-    if (d_hi) d_hi[n * d_stride + p] = g * w_hi * (eh < 0.f ? -a.q_hi : (eh > 0.f ? 1.f - a.q_hi : 0.f));
-    if (d_mid) d_mid[n * d_stride + p] = g * w_mse * 2.f * em;
+    const float va = a.lo[n * a.img_stride + p];
+    const float vb = a.mid[n * a.img_stride + p];
+    float ga = 0.f, gb = 0.f, gc = 0.f;
+    switch (a.kind) {
+      case IM2IM_LOSS_QUANTILE:
+      case IM2IM_LOSS_QUANTILE_L1: {
+        const float el = va - y, eh = a.hi[n * a.img_stride + p] - y, em = vb - y;
+        ga = w_lo * (el < 0.f ? -a.q_lo : (el > 0.f ? 1.f - a.q_lo : 0.f));
+        gc = w_hi * (eh < 0.f ? -a.q_hi : (eh > 0.f ? 1.f - a.q_hi : 0.f));
+        gb = w_mse * (a.kind == IM2IM_LOSS_QUANTILE ? 2.f * em : sign0(em));
+        break;
+      }
+      case IM2IM_LOSS_GAUSSIAN: {
+        // d/dmean = (mean - y)/v ; d/dvar = 0.5*(1/v - (mean-y)^2/v^2), v = clamped variance (the clamp itself is applied
+        // under no_grad in torch, so its gradient goes to var unchanged)
+        const float v = fmaxf(vb, GNLL_EPS), e = va - y;
+        ga = w_lo * (e / v);
+        gb = w_lo * (0.5f * (1.f / v - e * e / (v * v)));
+        break;
+      }
+      default: {
+        // loss = term0(a, y) + (b - |y - a|)^2 : the second term also depends on a through |y - a|
+        const float e = va - y, r = vb - fabsf(y - va);
+        ga = w_lo * (a.kind == IM2IM_LOSS_RESIDUAL ? 2.f * e : sign0(e)) + w_hi * (2.f * r * sign0(y - va));
+        gb = w_hi * (2.f * r);
+      }
+    }
+    if (d_lo) d_lo[n * d_stride + p] = g * ga;
+    if (d_mid) d_mid[n * d_stride + p] = g * gb;
+    if (d_hi) d_hi[n * d_stride + p] = g * gc;
   }
 }
 
@@ -987,12 +1041,14 @@ extern "C" int im2im_upsample2x_concat_bwd(const void* dout, void* ddeep, void* 
 
 extern "C" int64_t im2im_quantile_loss_workspace_bytes(void) { return 1024 * 3 * (int64_t)sizeof(float) + reduce_tmp_bytes(3); }
 
-extern "C" int im2im_quantile_loss_fwd(const float* lo, const float* mid, const float* hi, const float* target, int64_t N,
-                                       int64_t P, int64_t img_stride, float q_lo, float q_hi, float w_lo, float w_hi,
-                                       float w_mse, float* loss, void* ws, im2im_stream_t stream_) {
+extern "C" int im2im_uq_loss_fwd(int32_t kind, const float* pa, const float* pb, const float* pc, const float* target, int64_t N,
+                                 int64_t P, int64_t img_stride, float q_lo, float q_hi, float w0, float w1, float w2,
+                                 float* loss, void* ws, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  IM2IM_REQUIRE(lo && mid && hi && target && loss && ws && N > 0 && P > 0);
-  LossArgs a{lo, mid, hi, target, N, P, img_stride, q_lo, q_hi};
+  IM2IM_REQUIRE(kind >= IM2IM_LOSS_QUANTILE && kind <= IM2IM_LOSS_RESIDUAL_L1);
+  IM2IM_REQUIRE(pa && pb && target && loss && ws && N > 0 && P > 0);
+  IM2IM_REQUIRE(kind > IM2IM_LOSS_QUANTILE_L1 || pc != nullptr);
+  LossArgs a{pa, pb, pc, target, N, P, img_stride, q_lo, q_hi, kind};
   float* partial = (float*)ws;
   double* tmp = (double*)((char*)ws + 1024 * 3 * sizeof(float));
   int64_t nblk = cdiv(N * P, 256 * 8);
@@ -1002,19 +1058,35 @@ extern "C" int im2im_quantile_loss_fwd(const float* lo, const float* mid, const 
   int rc;
   const int S = launch_reduce_stage1(partial, nblk, 3, tmp, stream, &rc);
   if (rc) return rc;
-  hipLaunchKernelGGL(qloss_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)tmp, S, (double)(N * P), w_lo, w_hi, w_mse, loss);
+  hipLaunchKernelGGL(qloss_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)tmp, S, (double)(N * P), w0, w1, w2, loss);
   return check_launch("qloss_final_kernel");
+}
+
+extern "C" int im2im_uq_loss_bwd(int32_t kind, const float* pa, const float* pb, const float* pc, const float* target, int64_t N,
+                                 int64_t P, int64_t img_stride, float q_lo, float q_hi, float w0, float w1, float w2,
+                                 const float* grad_out, float* d_a, float* d_b, float* d_c, int64_t d_stride,
+                                 im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(kind >= IM2IM_LOSS_QUANTILE && kind <= IM2IM_LOSS_RESIDUAL_L1);
+  IM2IM_REQUIRE(pa && pb && target && grad_out && N > 0 && P > 0);
+  IM2IM_REQUIRE(kind > IM2IM_LOSS_QUANTILE_L1 || pc != nullptr);
+  LossArgs a{pa, pb, pc, target, N, P, img_stride, q_lo, q_hi, kind};
+  hipLaunchKernelGGL(qloss_bwd_kernel, dim3(ew_blocks(N * P)), dim3(256), 0, stream, a, grad_out, w0, w1, w2, d_a, d_b, d_c, d_stride);
+  return check_launch("qloss_bwd_kernel");
+}
+
+extern "C" int im2im_quantile_loss_fwd(const float* lo, const float* mid, const float* hi, const float* target, int64_t N,
+                                       int64_t P, int64_t img_stride, float q_lo, float q_hi, float w_lo, float w_hi,
+                                       float w_mse, float* loss, void* ws, im2im_stream_t stream_) {
+  return im2im_uq_loss_fwd(IM2IM_LOSS_QUANTILE, lo, mid, hi, target, N, P, img_stride, q_lo, q_hi, w_lo, w_hi, w_mse, loss, ws, stream_);
 }
 
 extern "C" int im2im_quantile_loss_bwd(const float* lo, const float* mid, const float* hi, const float* target, int64_t N,
                                        int64_t P, int64_t img_stride, float q_lo, float q_hi, float w_lo, float w_hi,
                                        float w_mse, const float* grad_out, float* d_lo, float* d_mid, float* d_hi,
                                        int64_t d_stride, im2im_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  IM2IM_REQUIRE(lo && mid && hi && target && grad_out && N > 0 && P > 0);
-  LossArgs a{lo, mid, hi, target, N, P, img_stride, q_lo, q_hi};
-  hipLaunchKernelGGL(qloss_bwd_kernel, dim3(ew_blocks(N * P)), dim3(256), 0, stream, a, grad_out, w_lo, w_hi, w_mse, d_lo, d_mid, d_hi, d_stride);
-  return check_launch("qloss_bwd_kernel");
+  return im2im_uq_loss_bwd(IM2IM_LOSS_QUANTILE, lo, mid, hi, target, N, P, img_stride, q_lo, q_hi, w_lo, w_hi, w_mse, grad_out, d_lo,
+                           d_mid, d_hi, d_stride, stream_);
 }
 
 extern "C" int im2im_adam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,

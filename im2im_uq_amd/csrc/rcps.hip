@@ -43,12 +43,27 @@ inline void rcps_partition(int64_t N, int64_t P, int L, int64_t* grid, int64_t* 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ bool miss_at(float lam, float l_d, float u_d, float p, float pm, float pp, float y) {
-  // quantile_layer.py:41-42 then add_uncertainty.py:35-36
-  float up = fmaxf(__fadd_rn(__fmul_rn(lam, u_d), p), pp);
-  float lo = fminf(__fsub_rn(p, __fmul_rn(lam, l_d)), pm);
-  return (lo > y) | (up < y);                                // calibrate_model.py:77-78
-}
+// How a final layer's output planes turn into the half-widths (d_lo, d_up) of the nested set
+//   lower_edge(lam) = min(p - lam*d_lo, p - 1e-6),  upper_edge(lam) = max(lam*d_up + p, p + 1e-6)   (add_uncertainty.py:33-38)
+// FORM 0  planes (l, p, u): d_lo = p - min(l, p-1e-6), d_up = max(u, p+1e-6) - p     quantile(_l1)_layer.py:39-42
+// FORM 1  planes (p, s):    d_lo = d_up = s                                          residual_magnitude(_l1)_layer.py:33-34
+// FORM 2  planes (p, v):    d_lo = d_up = sqrt(v)  (correctly rounded, as torch)      gaussian_layer.py:31-32
+template <int FORM> struct SetForm {
+  static constexpr int PLANES = FORM == 0 ? 3 : 2;
+  static constexpr int PRED = FORM == 0 ? 1 : 0;
+  // a = plane 0, b = plane 1, c = plane 2 (FORM 0 only)
+  static __device__ __forceinline__ void widths(float a, float b, float c, float& p, float& d_lo, float& d_up) {
+    if constexpr (FORM == 0) {
+      p = b;
+      d_lo = __fsub_rn(p, fminf(a, __fsub_rn(p, 1e-6f)));
+      d_up = __fsub_rn(fmaxf(c, __fadd_rn(p, 1e-6f)), p);
+    } else if constexpr (FORM == 1) {
+      p = a; d_lo = b; d_up = b;
+    } else {
+      p = a; d_lo = (float)sqrt((double)b); d_up = d_lo;      // fp64 sqrt rounded once more to fp32 == correctly rounded fp32 sqrt (53 >= 2*24+2)
+    }
+  }
+};
 
 // Number of grid points at which the pixel is missed.  Simplifications that keep the result bit-identical to
 // evaluating miss_at() at every grid point:
@@ -56,11 +71,16 @@ __device__ __forceinline__ bool miss_at(float lam, float l_d, float u_d, float p
 //   * max(v, pp) < y  <=>  v < y and pp < y (pp < y does not depend on lambda); likewise for the lower side;
 //   * p - lam*d > y  <=>  lam*d + (-p) < -y  (IEEE negation is exact), so both sides share one form
 //         miss(lam)  <=>  fl(fl(lam * d) + P) < Y .
-__device__ __forceinline__ int critical_index(float l, float p, float u, float y, const float* s_lam, int L,
+// (for the symmetric forms lam*d may be negative at the shifted first grid point; the argument is unchanged: the floor
+//  keeps lower_edge <= p and upper_edge >= p, and fp32 multiply/add stay monotone in lam for d >= 0)
+template <int FORM>
+__device__ __forceinline__ int critical_index(float a, float b, float c, float y, const float* s_lam, int L,
                                               float g0, float inv_dg) {
+  float p, d_lo, d_up;
+  SetForm<FORM>::widths(a, b, c, p, d_lo, d_up);
   const float pm = __fsub_rn(p, 1e-6f), pp = __fadd_rn(p, 1e-6f);
   const bool up_side = y > p;
-  const float d = up_side ? __fsub_rn(fmaxf(u, pp), p) : __fsub_rn(p, fminf(l, pm));   // quantile_layer.py:39-42
+  const float d = up_side ? d_up : d_lo;
   const float P = up_side ? p : -p;
   const float Y = up_side ? y : -y;
   const bool can_miss = up_side ? (pp < y) : (pm > y);                                  // add_uncertainty.py:35-36 floor
@@ -78,7 +98,7 @@ __device__ __forceinline__ int critical_index(float l, float p, float u, float y
 // (units of 4 pixels when P % 4 == 0), so every workgroup moves the same number of bytes and there is no
 // tail wave.  A range crosses at most `maxseg` images; at each image boundary the LDS histogram is flushed to the
 // (workgroup, segment) row of `partial` with plain stores; the suffix kernel adds the few rows that cover an image.
-template <bool VEC>
+template <bool VEC, int FORM>
 __global__ __launch_bounds__(HIST_THREADS, HIST_BLOCKS_PER_CU) void rcps_hist_kernel(
     const float* __restrict__ out3, const float* __restrict__ label, int64_t N, int64_t P,
     const float* __restrict__ lam, int L, int* __restrict__ partial, int maxseg) {
@@ -102,9 +122,10 @@ __global__ __launch_bounds__(HIST_THREADS, HIST_BLOCKS_PER_CU) void rcps_hist_ke
   while (u < u_end) {
     const int64_t n = u / units_per_img;
     const int64_t seg_end = min(u_end, (n + 1) * units_per_img);   // stay inside image n
-    const float* lo_p = out3 + (n * 3 + 0) * P;
-    const float* pr_p = out3 + (n * 3 + 1) * P;
-    const float* up_p = out3 + (n * 3 + 2) * P;
+    constexpr int K = SetForm<FORM>::PLANES;
+    const float* lo_p = out3 + (n * K + 0) * P;                 // planes 0, 1 and (FORM 0) 2 of image n
+    const float* pr_p = out3 + (n * K + 1) * P;
+    const float* up_p = out3 + (n * K + (K - 1)) * P;
     const float* y_p = label + n * P;
     const int64_t base = n * units_per_img;
     int n_full = 0;                                           // pixels missed at every grid point
@@ -114,18 +135,18 @@ __global__ __launch_bounds__(HIST_THREADS, HIST_BLOCKS_PER_CU) void rcps_hist_ke
         // every byte is read exactly once: non-temporal loads (measured +15 % over default-policy loads)
         const f32x4 l4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(lo_p + i));
         const f32x4 p4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(pr_p + i));
-        const f32x4 u4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(up_p + i));
+        const f32x4 u4 = (K == 3) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(up_p + i)) : p4;
         const f32x4 y4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y_p + i));
         const float lv[4] = {l4[0], l4[1], l4[2], l4[3]}, pv[4] = {p4[0], p4[1], p4[2], p4[3]};
         const float uv[4] = {u4[0], u4[1], u4[2], u4[3]}, yv[4] = {y4[0], y4[1], y4[2], y4[3]};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int j = critical_index(lv[k], pv[k], uv[k], yv[k], s_lam, L, g0, inv_dg);
+          const int j = critical_index<FORM>(lv[k], pv[k], uv[k], yv[k], s_lam, L, g0, inv_dg);
           if (j == L) ++n_full;
           else if (j > 0) atomicAdd(&s_hist[j], 1);
         }
       } else {
-        const int j = critical_index(lo_p[i], pr_p[i], up_p[i], y_p[i], s_lam, L, g0, inv_dg);
+        const int j = critical_index<FORM>(lo_p[i], pr_p[i], up_p[i], y_p[i], s_lam, L, g0, inv_dg);
         if (j == L) ++n_full;
         else if (j > 0) atomicAdd(&s_hist[j], 1);
       }
@@ -178,6 +199,7 @@ __global__ __launch_bounds__(256) void rcps_suffix_kernel(const int* __restrict_
 }
 
 // Spatial miscoverage counts at one lambda.  grid = (ceil(HW/ (256*4)), C, NSPLIT)
+template <int FORM>
 __global__ __launch_bounds__(256) void rcps_miscoverage_kernel(
     const float* __restrict__ out3, const float* __restrict__ label, int64_t N, int C, int64_t HW, float lam,
     int* __restrict__ map) {
@@ -190,9 +212,10 @@ __global__ __launch_bounds__(256) void rcps_miscoverage_kernel(
   int acc[4] = {0, 0, 0, 0};
   const bool vec_ok = ((HW & 3) == 0);
   for (int64_t n = n0; n < n1; ++n) {
-    const float* lo_p = out3 + (n * 3 + 0) * P + (int64_t)c * HW;
-    const float* pr_p = out3 + (n * 3 + 1) * P + (int64_t)c * HW;
-    const float* up_p = out3 + (n * 3 + 2) * P + (int64_t)c * HW;
+    constexpr int K = SetForm<FORM>::PLANES;
+    const float* lo_p = out3 + (n * K + 0) * P + (int64_t)c * HW;
+    const float* pr_p = out3 + (n * K + 1) * P + (int64_t)c * HW;
+    const float* up_p = out3 + (n * K + (K - 1)) * P + (int64_t)c * HW;
     const float* y_p = label + n * P + (int64_t)c * HW;
     float lv[4], pv[4], uv[4], yv[4];
     if (vec_ok) {
@@ -209,11 +232,11 @@ __global__ __launch_bounds__(256) void rcps_miscoverage_kernel(
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float p = pv[k];
+      float p, d_lo, d_up;
+      SetForm<FORM>::widths(lv[k], pv[k], uv[k], p, d_lo, d_up);
       const float pm = __fsub_rn(p, 1e-6f), pp = __fadd_rn(p, 1e-6f);
-      const float l = fminf(lv[k], pm), u = fmaxf(uv[k], pp);
-      const float up = fmaxf(__fadd_rn(__fmul_rn(lam, __fsub_rn(u, p)), p), pp);
-      const float lo = fminf(__fsub_rn(p, __fmul_rn(lam, __fsub_rn(p, l))), pm);
+      const float up = fmaxf(__fadd_rn(__fmul_rn(lam, d_up), p), pp);
+      const float lo = fminf(__fsub_rn(p, __fmul_rn(lam, d_lo)), pm);
       acc[k] += (int)(yv[k] > up) + (int)(yv[k] < lo);        // calibrate_model.py:47
     }
   }
@@ -221,20 +244,30 @@ __global__ __launch_bounds__(256) void rcps_miscoverage_kernel(
     if (i0 + k < HW && acc[k]) atomicAdd(&map[(int64_t)c * HW + i0 + k], acc[k]);
 }
 
+// lower/upper edges at one lambda.  floor != 0: with the +-1e-6 floor of ModelWithUncertainty.nested_sets_from_output
+// (add_uncertainty.py:35-36); floor == 0: the final layer's own *_nested_sets_from_output.  clamp_inplace (FORM 0):
+// write the clamped lower/upper planes back like the reference's in-place assignment (quantile_layer.py:39-40, Q5).
+template <int FORM>
 __global__ __launch_bounds__(256) void nested_sets_kernel(float* __restrict__ out3, int64_t N, int64_t P, float lam,
                                                            float* __restrict__ lower_edge, float* __restrict__ upper_edge,
-                                                           int clamp_inplace) {
+                                                           int clamp_inplace, int floor) {
+  constexpr int K = SetForm<FORM>::PLANES;
   const int64_t total = N * P;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t n = i / P, q = i - n * P;
-    float* lo_p = out3 + (n * 3 + 0) * P + q;
-    const float p = out3[(n * 3 + 1) * P + q];
-    float* up_p = out3 + (n * 3 + 2) * P + q;
+    float* a_p = out3 + (n * K + 0) * P + q;
+    float* b_p = out3 + (n * K + 1) * P + q;
+    float* c_p = out3 + (n * K + (K - 1)) * P + q;
+    float p, d_lo, d_up;
+    SetForm<FORM>::widths(*a_p, *b_p, *c_p, p, d_lo, d_up);
     const float pm = __fsub_rn(p, 1e-6f), pp = __fadd_rn(p, 1e-6f);
-    const float l = fminf(*lo_p, pm), u = fmaxf(*up_p, pp);
-    if (clamp_inplace) { *lo_p = l; *up_p = u; }
-    upper_edge[i] = fmaxf(__fadd_rn(__fmul_rn(lam, __fsub_rn(u, p)), p), pp);
-    lower_edge[i] = fminf(__fsub_rn(p, __fmul_rn(lam, __fsub_rn(p, l))), pm);
+    if (FORM == 0 && clamp_inplace) { *a_p = fminf(*a_p, pm); *c_p = fmaxf(*c_p, pp); }
+    float up = __fadd_rn(__fmul_rn(lam, d_up), p);
+    // FORM 0: p - lam*d_lo (quantile_layer.py:42); FORM 1/2: (-lam)*d + p (gaussian_layer.py:32) -- the same fp32 value
+    float lo = __fsub_rn(p, __fmul_rn(lam, d_lo));
+    if (floor) { up = fmaxf(up, pp); lo = fminf(lo, pm); }
+    upper_edge[i] = up;
+    lower_edge[i] = lo;
   }
 }
 
@@ -266,11 +299,21 @@ extern "C" int im2im_fraction_missed(const float* lower_edge, const float* upper
   return im2im::check_launch("fraction_missed_kernel");
 }
 
+namespace {
+template <int FORM>
+void launch_hist(bool vec, int64_t grid, size_t smem, hipStream_t stream, const float* out3, const float* label, int64_t N,
+                 int64_t P, const float* lam, int L, int* hist_ws, int maxseg) {
+  if (vec) hipLaunchKernelGGL((rcps_hist_kernel<true, FORM>), dim3((unsigned)grid), dim3(HIST_THREADS), smem, stream, out3, label, N, P, lam, L, hist_ws, maxseg);
+  else hipLaunchKernelGGL((rcps_hist_kernel<false, FORM>), dim3((unsigned)grid), dim3(HIST_THREADS), smem, stream, out3, label, N, P, lam, L, hist_ws, maxseg);
+}
+}  // namespace
+
 extern "C" int im2im_rcps_loss_table(const float* out3, const float* label, int64_t N, int64_t P,
-                                     const float* lam, int32_t L, int32_t* hist_ws, float* table,
+                                     const float* lam, int32_t L, int32_t form, int32_t* hist_ws, float* table,
                                      int32_t* counts, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(out3 && label && lam && hist_ws && table);
+  IM2IM_REQUIRE(form >= 0 && form <= 2);
   IM2IM_REQUIRE(N >= 0 && P > 0 && L >= 1 && L <= MAX_L);
   IM2IM_REQUIRE(P < (1 << 24));                               // fp32(count) exact, as in the reference's fp32 mean
   if (N == 0) return IM2IM_OK;
@@ -278,8 +321,9 @@ extern "C" int im2im_rcps_loss_table(const float* out3, const float* label, int6
   int64_t grid, per, maxseg, units_per_img;
   rcps_partition(N, P, L, &grid, &per, &maxseg, &units_per_img);
   const bool vec = (P & 3) == 0;
-  if (vec) hipLaunchKernelGGL(rcps_hist_kernel<true>, dim3((unsigned)grid), dim3(HIST_THREADS), smem, stream, out3, label, N, P, lam, (int)L, hist_ws, (int)maxseg);
-  else hipLaunchKernelGGL(rcps_hist_kernel<false>, dim3((unsigned)grid), dim3(HIST_THREADS), smem, stream, out3, label, N, P, lam, (int)L, hist_ws, (int)maxseg);
+  if (form == 0) launch_hist<0>(vec, grid, smem, stream, out3, label, N, P, lam, (int)L, hist_ws, (int)maxseg);
+  else if (form == 1) launch_hist<1>(vec, grid, smem, stream, out3, label, N, P, lam, (int)L, hist_ws, (int)maxseg);
+  else launch_hist<2>(vec, grid, smem, stream, out3, label, N, P, lam, (int)L, hist_ws, (int)maxseg);
   if (int rc = im2im::check_launch("rcps_hist_kernel")) return rc;
   hipLaunchKernelGGL(rcps_suffix_kernel, dim3((unsigned)N), dim3(256), sizeof(int) * (size_t)(L + 1 + 256), stream, hist_ws, (int)maxseg,
                      units_per_img, per, N * units_per_img, (int)L, (float)P, table, counts);
@@ -294,9 +338,10 @@ extern "C" int64_t im2im_rcps_workspace_bytes(int64_t N, int64_t P, int32_t L) {
 }
 
 extern "C" int im2im_rcps_miscoverage(const float* out3, const float* label, int64_t N, int32_t C, int64_t HW,
-                                      float lam, int32_t* map, im2im_stream_t stream_) {
+                                      float lam, int32_t form, int32_t* map, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(out3 && label && map);
+  IM2IM_REQUIRE(form >= 0 && form <= 2);
   IM2IM_REQUIRE(N >= 0 && C >= 1 && C <= 65535 && HW > 0);
   IM2IM_HIP(hipMemsetAsync(map, 0, sizeof(int32_t) * (size_t)C * HW, stream));
   if (N == 0) return IM2IM_OK;
@@ -305,19 +350,23 @@ extern "C" int im2im_rcps_miscoverage(const float* out3, const float* label, int
   if (nz > N) nz = N;
   if (nz > 1024) nz = 1024;
   if (nz < 1) nz = 1;
-  hipLaunchKernelGGL(rcps_miscoverage_kernel, dim3((unsigned)bx, (unsigned)C, (unsigned)nz), dim3(256), 0, stream,
-                     out3, label, N, (int)C, HW, lam, map);
+  const dim3 mgrid((unsigned)bx, (unsigned)C, (unsigned)nz);
+  if (form == 0) hipLaunchKernelGGL(rcps_miscoverage_kernel<0>, mgrid, dim3(256), 0, stream, out3, label, N, (int)C, HW, lam, map);
+  else if (form == 1) hipLaunchKernelGGL(rcps_miscoverage_kernel<1>, mgrid, dim3(256), 0, stream, out3, label, N, (int)C, HW, lam, map);
+  else hipLaunchKernelGGL(rcps_miscoverage_kernel<2>, mgrid, dim3(256), 0, stream, out3, label, N, (int)C, HW, lam, map);
   return im2im::check_launch("rcps_miscoverage_kernel");
 }
 
-extern "C" int im2im_nested_sets(float* out3, int64_t N, int64_t P, float lam, float* lower_edge,
-                                 float* upper_edge, int32_t clamp_inplace, im2im_stream_t stream_) {
+extern "C" int im2im_nested_sets(float* out3, int64_t N, int64_t P, float lam, int32_t form, float* lower_edge,
+                                 float* upper_edge, int32_t clamp_inplace, int32_t floor, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(out3 && lower_edge && upper_edge && N >= 0 && P > 0);
+  IM2IM_REQUIRE(form >= 0 && form <= 2);
   if (N == 0) return IM2IM_OK;
   int64_t blocks = im2im::cdiv(N * P, 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(nested_sets_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, out3, N, P, lam, lower_edge,
-                     upper_edge, (int)clamp_inplace);
+  if (form == 0) hipLaunchKernelGGL(nested_sets_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, out3, N, P, lam, lower_edge, upper_edge, (int)clamp_inplace, (int)floor);
+  else if (form == 1) hipLaunchKernelGGL(nested_sets_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, out3, N, P, lam, lower_edge, upper_edge, 0, (int)floor);
+  else hipLaunchKernelGGL(nested_sets_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, out3, N, P, lam, lower_edge, upper_edge, 0, (int)floor);
   return im2im::check_launch("nested_sets_kernel");
 }

@@ -12,15 +12,27 @@ from ._lib import check, dptr, lib, require_gpu, stream_ptr
 
 F32 = torch.float32
 
+# how a final layer's output planes become the nested set (include/im2im_uq.h IM2IM_SETS_*)
+SETS_QUANTILE, SETS_SCALE, SETS_SQRT = 0, 1, 2
+_FORM_PLANES = {SETS_QUANTILE: 3, SETS_SCALE: 2, SETS_SQRT: 2}
+
+
+def _check_form(outputs, form):
+    if form not in _FORM_PLANES:
+        raise _lib.Im2ImError(f"unknown nested-set form {form!r}")
+    if outputs.dim() < 3 or outputs.shape[1] != _FORM_PLANES[form]:
+        raise _lib.Im2ImError(f"outputs must be [N,{_FORM_PLANES[form]},...] for form {form}, got {tuple(outputs.shape)}")
+
 
 # ------------------------------------------------------------------ calibration (K11-K14)
-def rcps_loss_table(outputs: torch.Tensor, labels: torch.Tensor, lam: torch.Tensor, want_counts: bool = False):
-    """outputs [N,3,C,H,W] fp32, labels [N,C,H,W] fp32 (GPU); lam [L] fp32 ascending (any device).
+def rcps_loss_table(outputs: torch.Tensor, labels: torch.Tensor, lam: torch.Tensor, want_counts: bool = False,
+                    form: int = SETS_QUANTILE):
+    """outputs [N,K,C,H,W] fp32 (K = 3 quantile planes, or 2 for the scale / sqrt forms), labels [N,C,H,W] fp32 (GPU);
+    lam [L] fp32 ascending (any device).
     Returns table [N,L] fp32 on the GPU (and int32 counts if asked): one pass over HBM for all lambdas."""
     outputs = require_gpu(outputs, F32, "outputs")
     labels = require_gpu(labels, F32, "labels")
-    if outputs.dim() < 3 or outputs.shape[1] != 3:
-        raise _lib.Im2ImError(f"outputs must be [N,3,...], got {tuple(outputs.shape)}")
+    _check_form(outputs, form)
     n = outputs.shape[0]
     p = outputs[0, 0].numel() if n else int(torch.tensor(outputs.shape[2:]).prod())
     if labels.numel() != n * p:
@@ -36,7 +48,7 @@ def rcps_loss_table(outputs: torch.Tensor, labels: torch.Tensor, lam: torch.Tens
     hist = torch.empty((max(1, lib.im2im_rcps_workspace_bytes(n, p, L) // 4),), dtype=torch.int32, device=dev)
     table = torch.empty((n, L), dtype=F32, device=dev)
     counts = torch.empty((n, L), dtype=torch.int32, device=dev) if want_counts else None
-    rcps_loss_table_raw(outputs, labels, n, p, lam_dev, hist, table, counts)
+    rcps_loss_table_raw(outputs, labels, n, p, lam_dev, hist, table, counts, form)
     return (table, counts) if want_counts else table
 
 
@@ -54,40 +66,43 @@ def _grid_on_device(lam_cpu: torch.Tensor, dev) -> torch.Tensor:
     return t
 
 
-def rcps_loss_table_raw(outputs, labels, n, p, lam_dev, hist, table, counts=None):
-    """no allocation, no host traffic: memset + histogram kernel + suffix kernel on the current stream."""
+def rcps_loss_table_raw(outputs, labels, n, p, lam_dev, hist, table, counts=None, form=SETS_QUANTILE):
+    """no allocation, no host traffic: histogram kernel + suffix kernel on the current stream."""
     dev = outputs.device
     with torch.cuda.device(dev):
-        check(lib.im2im_rcps_loss_table(dptr(outputs), dptr(labels), n, p, dptr(lam_dev), lam_dev.numel(), dptr(hist), dptr(table),
-                                        dptr(counts), stream_ptr(dev)), "im2im_rcps_loss_table")
+        check(lib.im2im_rcps_loss_table(dptr(outputs), dptr(labels), n, p, dptr(lam_dev), lam_dev.numel(), int(form), dptr(hist),
+                                        dptr(table), dptr(counts), stream_ptr(dev)), "im2im_rcps_loss_table")
 
 
-def rcps_miscoverage(outputs: torch.Tensor, labels: torch.Tensor, lam: float) -> torch.Tensor:
+def rcps_miscoverage(outputs: torch.Tensor, labels: torch.Tensor, lam: float, form: int = SETS_QUANTILE) -> torch.Tensor:
     """int32 [C, H*W] counts of (label > upper) + (label < lower) over images at one lambda."""
     outputs = require_gpu(outputs, F32, "outputs")
     labels = require_gpu(labels, F32, "labels")
+    _check_form(outputs, form)
     n, three, c = outputs.shape[0], outputs.shape[1], outputs.shape[2]
     hw = outputs[0, 0, 0].numel()
     out = torch.empty((c, hw), dtype=torch.int32, device=outputs.device)
     with torch.cuda.device(outputs.device):
-        check(lib.im2im_rcps_miscoverage(dptr(outputs), dptr(labels), n, c, hw, float(lam), dptr(out),
+        check(lib.im2im_rcps_miscoverage(dptr(outputs), dptr(labels), n, c, hw, float(lam), int(form), dptr(out),
                                          stream_ptr(outputs.device)), "im2im_rcps_miscoverage")
     return out
 
 
-def nested_sets(output: torch.Tensor, lam: float, clamp_inplace: bool = True):
-    """output [N,3,...] fp32 GPU -> (lower_edge, prediction view, upper_edge), each [N,...]."""
+def nested_sets(output: torch.Tensor, lam: float, clamp_inplace: bool = True, form: int = SETS_QUANTILE, floor: bool = True):
+    """output [N,K,...] fp32 GPU -> (lower_edge, prediction view, upper_edge), each [N,...].  floor: with the +-1e-6 floor
+    of ModelWithUncertainty.nested_sets_from_output; without it, the final layer's own raw edges."""
     if not output.is_contiguous():
         raise _lib.Im2ImError("nested_sets: output must be contiguous (it is clamped in place like the reference)")
     require_gpu(output, F32, "output")
+    _check_form(output, form)
     n = output.shape[0]
     p = output[0, 0].numel()
     lower = torch.empty(output.shape[:1] + output.shape[2:], dtype=F32, device=output.device)
     upper = torch.empty_like(lower)
     with torch.cuda.device(output.device):
-        check(lib.im2im_nested_sets(dptr(output), n, p, float(lam), dptr(lower), dptr(upper), int(clamp_inplace),
-                                    stream_ptr(output.device)), "im2im_nested_sets")
-    return lower, output[:, 1], upper
+        check(lib.im2im_nested_sets(dptr(output), n, p, float(lam), int(form), dptr(lower), dptr(upper), int(clamp_inplace),
+                                    int(floor), stream_ptr(output.device)), "im2im_nested_sets")
+    return lower, output[:, 1 if form == SETS_QUANTILE else 0], upper
 
 
 def fraction_missed(lower: torch.Tensor, upper: torch.Tensor, label: torch.Tensor) -> torch.Tensor:

@@ -590,6 +590,91 @@ class QuantileHeads(torch.autograd.Function):
         return dfeat, dw[0], db[0], dw[1], db[1], dw[2], db[2], None
 
 
+class Heads(torch.autograd.Function):
+    """K 3x3 heads (K = 2 or 3) in one kernel, output [B,K,C,H,W] fp32, with an optional activation on head 1:
+    'relu' (GaussianRegressionLayer's variance, gaussian_layer.py:15-17) or 'abs' (ResidualMagnitude*Layer's magnitude,
+    residual_magnitude_layer.py:15-17).  The activation and its gradient mask act on one small fp32 plane."""
+
+    @staticmethod
+    def forward(ctx, feat, cdt, act, *wb):
+        x = nhwc(feat.detach(), cdt)
+        k = len(wb) // 2
+        ws, bs = wb[0::2], wb[1::2]
+        c_out = ws[0].shape[0]
+        w_all = torch.cat([w.detach() for w in ws], dim=0)
+        b_all = torch.cat([b.detach() for b in bs], dim=0).to(F32).contiguous()
+        wf, _ = pack_weight(w_all, F32, want_wd=False)              # [K*C][9][Cmid] fp32
+        b, h, w_, _ = x.shape
+        out = smallconv_l2s(x, wf, b_all, k * c_out).view(b, k, c_out, h, w_)
+        pre = torch.empty(0)
+        if act is not None:
+            pre = out[:, 1].clone()
+            if act == "relu":
+                out[:, 1].clamp_(min=0)
+            elif act == "abs":
+                out[:, 1].abs_()
+            else:
+                raise ValueError(f"unknown head activation {act!r}")
+        ctx.save_for_backward(x, wf, pre)
+        ctx.cfg = (c_out, k, act)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wf, pre = ctx.saved_tensors
+        c, k, act = ctx.cfg
+        b, h, w_, cmid = x.shape
+        dout = dout.to(F32).contiguous()
+        if act is not None:
+            dout = dout.clone()
+            dout[:, 1] *= (pre > 0).to(F32) if act == "relu" else torch.sign(pre)
+        dout = dout.view(b, k * c, h, w_)
+        dfeat = None
+        if ctx.needs_input_grad[0]:
+            dfeat = nchw(smallconv_s2l(dout, wf, None, None, cmid, x.dtype, flip=True))
+        dw, db = smallconv_wgrad(dout, x, l_major=False, want_bias=True)
+        dw = dw.view(k, c, cmid, 3, 3)
+        db = db.view(k, c)
+        grads = []
+        for i in range(k):
+            grads += [dw[i], db[i]]
+        return (dfeat, None, None) + tuple(grads)
+
+
+LOSS_QUANTILE, LOSS_QUANTILE_L1, LOSS_GAUSSIAN, LOSS_RESIDUAL, LOSS_RESIDUAL_L1 = 0, 1, 2, 3, 4
+
+
+class UQLossPacked(torch.autograd.Function):
+    """the training loss of a final layer on its packed [B,K,C,H,W] output (include/im2im_uq.h IM2IM_LOSS_*): one fused
+    reduction forward, one elementwise kernel backward writing d(pred) as one [B,K,C,H,W] tensor."""
+
+    @staticmethod
+    def forward(ctx, pred, target, kind, q_lo, q_hi, w0, w1, w2):
+        n, k = pred.shape[0], pred.shape[1]
+        p = pred[0, 0].numel()
+        dev = pred.device
+        loss = torch.empty((), dtype=F32, device=dev)
+        ws = _Scratch.get(lib.im2im_quantile_loss_workspace_bytes(), dev)
+        base = pred.data_ptr()
+        check(lib.im2im_uq_loss_fwd(kind, base, base + 4 * p, (base + 8 * p) if k == 3 else None, dptr(target), n, p, k * p,
+                                    q_lo, q_hi, w0, w1, w2, dptr(loss), dptr(ws), stream_ptr(dev)), "im2im_uq_loss_fwd")
+        ctx.save_for_backward(pred, target)
+        ctx.cfg = (n, k, p, kind, q_lo, q_hi, w0, w1, w2)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, target = ctx.saved_tensors
+        n, k, p, kind, q_lo, q_hi, w0, w1, w2 = ctx.cfg
+        gout = gout.to(F32).contiguous()
+        d = torch.empty_like(pred)
+        base, dbase = pred.data_ptr(), d.data_ptr()
+        check(lib.im2im_uq_loss_bwd(kind, base, base + 4 * p, (base + 8 * p) if k == 3 else None, dptr(target), n, p, k * p,
+                                    q_lo, q_hi, w0, w1, w2, dptr(gout), dbase, dbase + 4 * p, (dbase + 8 * p) if k == 3 else None,
+                                    k * p, stream_ptr(pred.device)), "im2im_uq_loss_bwd")
+        return d, None, None, None, None, None, None, None
+
+
 class QuantileLoss(torch.autograd.Function):
     """w_lo*pinball(q_lo) + w_hi*pinball(q_hi) + w_mse*MSE, each mean-reduced, in one fused reduction."""
 

@@ -44,7 +44,15 @@ const char* im2im_last_error(void);
  * as looped by get_rcps_losses_from_outputs (calibrate_model.py:21-29) inside the lambda scan
  * (calibrate_model.py:134-136) and by get_loss_table (core/scripts/eval.py:116-125).
  *
- *   out3    [N][3][P] fp32   model output (lower, prediction, upper planes), P = C*H*W
+ *   out3    [N][K][P] fp32   model output, P = C*H*W; its planes and how they become the nested set are given by `form`:
+ *                            IM2IM_SETS_QUANTILE (0)  K = 3 (lower, prediction, upper): quantile_layer.py:34-44 and
+ *                                                     quantile_l1_layer.py:34-44 (clamp to pred -+ 1e-6, then
+ *                                                     pred -+ lam * width)
+ *                            IM2IM_SETS_SCALE (1)     K = 2 (prediction, magnitude): pred -+ lam * magnitude,
+ *                                                     residual_magnitude(_l1)_layer.py:27-36
+ *                            IM2IM_SETS_SQRT (2)      K = 2 (mean, variance): mean -+ lam * sqrt(variance),
+ *                                                     gaussian_layer.py:25-34
+ *                            all followed by ModelWithUncertainty's +-1e-6 floor (add_uncertainty.py:35-36)
  *   label   [N][P]    fp32
  *   lam     [L]       fp32   device; ascending grid of the lambdas the edges are evaluated at
  *                            (the caller passes lambdas - dlambda for calibrate_model, Q1)
@@ -55,8 +63,11 @@ const char* im2im_last_error(void);
  * Edge arithmetic is fp32 with separate multiply and add (no FMA), as on the reference CPU path.
  */
 int64_t im2im_rcps_workspace_bytes(int64_t N, int64_t P, int32_t L);
+#define IM2IM_SETS_QUANTILE 0
+#define IM2IM_SETS_SCALE 1
+#define IM2IM_SETS_SQRT 2
 int im2im_rcps_loss_table(const float* out3, const float* label, int64_t N, int64_t P,
-                          const float* lam, int32_t L, int32_t* hist_ws, float* table,
+                          const float* lam, int32_t L, int32_t form, int32_t* hist_ws, float* table,
                           int32_t* counts, im2im_stream_t stream);
 
 /* Spatial miscoverage counts at one lambda; replaces the accumulation at
@@ -64,13 +75,15 @@ int im2im_rcps_loss_table(const float* out3, const float* label, int64_t N, int6
  *   map [C][HW] int32, zeroed by the call: map[c][i] = #images n with label > upper or label < lower
  */
 int im2im_rcps_miscoverage(const float* out3, const float* label, int64_t N, int32_t C, int64_t HW,
-                           float lam, int32_t* map, im2im_stream_t stream);
+                           float lam, int32_t form, int32_t* map, im2im_stream_t stream);
 
 /* Elementwise nested sets at one lambda (a10): same two call sites as above, materialising
- * (lower_edge, upper_edge) [N][P].  If clamp_inplace != 0, out3's lower/upper planes are
- * overwritten with the clamped values like the reference does (quantile_layer.py:39-40, Q5). */
-int im2im_nested_sets(float* out3, int64_t N, int64_t P, float lam, float* lower_edge,
-                      float* upper_edge, int32_t clamp_inplace, im2im_stream_t stream);
+ * (lower_edge, upper_edge) [N][P] for the given `form`.  floor != 0: with ModelWithUncertainty's +-1e-6 floor
+ * (add_uncertainty.py:35-36); floor == 0: the final layer's own *_nested_sets_from_output.  If clamp_inplace != 0
+ * (quantile form), out3's lower/upper planes are overwritten with the clamped values like the reference does
+ * (quantile_layer.py:39-40, Q5). */
+int im2im_nested_sets(float* out3, int64_t N, int64_t P, float lam, int32_t form, float* lower_edge,
+                      float* upper_edge, int32_t clamp_inplace, int32_t floor, im2im_stream_t stream);
 
 /* Per-image miss fraction for already-materialised edges; replaces fraction_missed_loss
  * core/calibration/calibrate_model.py:76-80.  lower/upper/label [N][P] fp32 -> loss [N] fp32
@@ -252,6 +265,28 @@ int im2im_quantile_loss_bwd(const float* lo, const float* mid, const float* hi, 
                             int64_t N, int64_t P, int64_t img_stride, float q_lo, float q_hi, float w_lo,
                             float w_hi, float w_mse, const float* grad_out, float* d_lo, float* d_mid,
                             float* d_hi, int64_t d_stride, im2im_stream_t stream);
+
+/* The training losses of the other final layers on the same fused reduction, all mean-reduced;
+ * a, b, c are the output planes addressed like lo/mid/hi above (c NULL for two-plane layers), `kind`:
+ *   IM2IM_LOSS_QUANTILE (0)     w0*pinball_{q_lo}(a) + w1*pinball_{q_hi}(c) + w2*MSE(b)      quantile_layer.py:23-32
+ *   IM2IM_LOSS_QUANTILE_L1 (1)  ... + w2*L1(b)                                            quantile_l1_layer.py:23-32
+ *   IM2IM_LOSS_GAUSSIAN (2)     nn.GaussianNLLLoss(a = mean, y, b = var), eps 1e-6: mean(0.5*(log v + (a-y)^2/v)),
+ *                               v = max(var, eps) with the gradient passed straight to var     gaussian_layer.py:19-23
+ *   IM2IM_LOSS_RESIDUAL (3)     MSE(a, y) + MSE(b, |y - a|)                                residual_magnitude_layer.py:19-25
+ *   IM2IM_LOSS_RESIDUAL_L1 (4)  L1(a, y) + MSE(b, |y - a|)                              residual_magnitude_l1_layer.py:19-25
+ * Workspace: im2im_quantile_loss_workspace_bytes(). */
+#define IM2IM_LOSS_QUANTILE 0
+#define IM2IM_LOSS_QUANTILE_L1 1
+#define IM2IM_LOSS_GAUSSIAN 2
+#define IM2IM_LOSS_RESIDUAL 3
+#define IM2IM_LOSS_RESIDUAL_L1 4
+int im2im_uq_loss_fwd(int32_t kind, const float* a, const float* b, const float* c, const float* target, int64_t N,
+                      int64_t P, int64_t img_stride, float q_lo, float q_hi, float w0, float w1, float w2,
+                      float* loss, void* ws, im2im_stream_t stream);
+int im2im_uq_loss_bwd(int32_t kind, const float* a, const float* b, const float* c, const float* target, int64_t N,
+                      int64_t P, int64_t img_stride, float q_lo, float q_hi, float w0, float w1, float w2,
+                      const float* grad_out, float* d_a, float* d_b, float* d_c, int64_t d_stride,
+                      im2im_stream_t stream);
 
 /* Multi-tensor Adam: optim.Adam(net.parameters(), lr) at core/scripts/train.py:120 with torch
  * defaults (betas, eps, no weight decay, no amsgrad).  Host arrays of n_tensors device pointers / sizes;

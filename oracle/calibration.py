@@ -47,17 +47,29 @@ def lambda_grid(cfg):
     return torch.linspace(cfg["minimum_lambda"], cfg["maximum_lambda"], cfg["num_lambdas"])
 
 
-def nested_sets(output, lam):
-    """quantile_regression_nested_sets_from_output (quantile_layer.py:39-44) followed by the
-    floor in ModelWithUncertainty.nested_sets_from_output (add_uncertainty.py:33-38).
-    ``output`` [b,3,C,H,W] is NOT mutated here (the reference clamps in place; the clamp is
-    idempotent so the values it leaves behind equal ``lo``/``hi`` below).  ``lam`` is a 0-dim
-    fp32 tensor or a python float, as at the reference's call sites."""
-    lo, mid, hi = output[:, 0], output[:, 1], output[:, 2]
-    lo = torch.minimum(lo, mid - 1e-6)
-    hi = torch.maximum(hi, mid + 1e-6)
-    upper = lam * (hi - mid) + mid
-    lower = mid - lam * (mid - lo)
+def raw_nested_sets(output, lam, utype="quantiles"):
+    """the final layer's own *_nested_sets_from_output (no floor):
+    quantiles / quantiles_l1: quantile_layer.py:39-44 == quantile_l1_layer.py:39-44 (clamp, then pred -+ lam*width);
+    gaussian: gaussian_layer.py:31-32 (mean -+ lam*sqrt(var));  residual_magnitude(_l1):
+    residual_magnitude_layer.py:33-34 (pred -+ lam*magnitude).  ``output`` is NOT mutated here (the reference's
+    quantile layers clamp in place; the clamp is idempotent)."""
+    if utype in ("quantiles", "quantiles_l1"):
+        lo, mid, hi = output[:, 0], output[:, 1], output[:, 2]
+        lo = torch.minimum(lo, mid - 1e-6)
+        hi = torch.maximum(hi, mid + 1e-6)
+        return mid - lam * (mid - lo), mid, lam * (hi - mid) + mid
+    mid = output[:, 0]
+    scale = output[:, 1].sqrt() if utype == "gaussian" else output[:, 1]
+    if utype not in ("gaussian", "residual_magnitude", "residual_magnitude_l1"):
+        raise NotImplementedError(utype)
+    return -lam * scale + mid, mid, lam * scale + mid
+
+
+def nested_sets(output, lam, utype="quantiles"):
+    """raw_nested_sets followed by the floor in ModelWithUncertainty.nested_sets_from_output
+    (add_uncertainty.py:33-38).  ``lam`` is a 0-dim fp32 tensor or a python float, as at the reference's
+    call sites."""
+    lower, mid, upper = raw_nested_sets(output, lam, utype)
     upper = torch.maximum(upper, mid + 1e-6)
     lower = torch.minimum(lower, mid - 1e-6)
     return lower, mid, upper
@@ -72,16 +84,16 @@ def fraction_missed(lower, upper, label):
     return miss.flatten(start_dim=1).mean(dim=1)
 
 
-def losses_at(outputs, labels, lam, batch=64):
+def losses_at(outputs, labels, lam, batch=64, utype="quantiles"):
     """get_rcps_losses_from_outputs, calibrate_model.py:21-29 (batches of 64, concatenated)."""
     parts = []
     for s in range(0, outputs.shape[0], batch):
-        lo, _, hi = nested_sets(outputs[s:s + batch], lam)
+        lo, _, hi = nested_sets(outputs[s:s + batch], lam, utype)
         parts.append(fraction_missed(lo, hi, labels[s:s + batch]))
     return torch.cat(parts, dim=0)
 
 
-def calibrate_from_outputs(outputs, labels, cfg):
+def calibrate_from_outputs(outputs, labels, cfg, utype="quantiles"):
     """Phase B of calibrate_model, calibrate_model.py:129-145: descending grid scan with the
     ``lam - dlambda`` shift (Q1), zero columns left of the break (Q2), stop rule
     ``Rhat >= alpha or RhatPlus > alpha`` (Q4), default lhat = last + dlambda - 1e-9.
@@ -95,7 +107,7 @@ def calibrate_from_outputs(outputs, labels, cfg):
     trace = []
     for j in range(lambdas.shape[0] - 1, -1, -1):
         lam = lambdas[j]
-        losses = losses_at(outputs, labels, lam - dlambda)
+        losses = losses_at(outputs, labels, lam - dlambda, utype=utype)
         table[:, j] = losses
         rhat = losses.mean()
         rhat_plus = hb_mu_plus(rhat.item(), n, delta)
@@ -119,15 +131,28 @@ def loss_table_from_outputs(outputs, labels, cfg):
     return table
 
 
-def risk_and_miscoverage(outputs, labels, lhat):
+def risk_and_miscoverage(outputs, labels, lhat, utype="quantiles"):
     """RNG-free part of get_rcps_metrics_from_outputs, calibrate_model.py:31-60: per-image
     risk at lhat (:42) and the spatial miscoverage map = mean over images and channel of
     (label > upper) + (label < lower)  (:47,55)."""
-    lo, _, hi = nested_sets(outputs, lhat)
+    lo, _, hi = nested_sets(outputs, lhat, utype)
     losses = fraction_missed(lo, hi, labels)
     mis = (labels > hi).float() + (labels < lo).float()          # [N,C,H,W]
     spatial = mis.numpy().mean(axis=0).mean(axis=0)              # [H,W]
     return losses, spatial
+
+
+def synth_outputs_two_plane(n, c, h, w, seed=0, width=0.05, utype="gaussian"):
+    """calibration inputs for the two-plane layers: (pred, variance) for gaussian, (pred, magnitude) otherwise; a few
+    exact zeros in the second plane (ReLU / abs outputs do hit 0) and labels equal to the prediction."""
+    g = torch.Generator().manual_seed(seed)
+    pred = torch.rand((n, c, h, w), generator=g)
+    mag = width * torch.rand((n, c, h, w), generator=g)
+    y = pred + width * torch.randn((n, c, h, w), generator=g)
+    mag.view(-1)[::97] = 0.0
+    y.view(-1)[::89] = pred.view(-1)[::89]
+    second = mag * mag if utype == "gaussian" else mag
+    return torch.stack([pred, second], dim=1).contiguous(), y.contiguous()
 
 
 def synth_outputs(n, c, h, w, seed=0, width=0.05):

@@ -36,7 +36,17 @@ def unet_blocks(n_in: int) -> List[Tuple[str, int, int, int]]:
     ]
 
 
-def state_spec(n_in: int = 1, n_out: int = 1, n_mid: int = 32) -> List[Tuple[str, Tuple[int, ...]]]:
+# head names per uncertainty type, in the reference's registration (= state_dict) order
+HEADS = {
+    "quantiles": ("lower", "prediction", "upper"),                    # quantile_layer.py:15-17
+    "quantiles_l1": ("lower", "prediction", "upper"),                 # quantile_l1_layer.py:15-17
+    "gaussian": ("mean", "variance"),                                 # gaussian_layer.py:12-13
+    "residual_magnitude": ("prediction", "residual_magnitude"),       # residual_magnitude_layer.py:12-13
+    "residual_magnitude_l1": ("prediction", "residual_magnitude"),    # residual_magnitude_l1_layer.py:12-13
+}
+
+
+def state_spec(n_in: int = 1, n_out: int = 1, n_mid: int = 32, utype: str = "quantiles") -> List[Tuple[str, Tuple[int, ...]]]:
     """(key, shape) list in the reference's state_dict order
     (unet.py:20-31, unet_parts.py:15-22,90, quantile_layer.py:15-17)."""
     spec: List[Tuple[str, Tuple[int, ...]]] = []
@@ -52,7 +62,7 @@ def state_spec(n_in: int = 1, n_out: int = 1, n_mid: int = 32) -> List[Tuple[str
             spec.append((f"{p}.{idx + 1}.num_batches_tracked", ()))
     spec.append(("baseModel.out.conv.weight", (n_mid, 64, 1, 1)))
     spec.append(("baseModel.out.conv.bias", (n_mid,)))
-    for head in ("lower", "prediction", "upper"):
+    for head in HEADS[utype]:
         spec.append((f"last_layer.{head}.weight", (n_out, n_mid, 3, 3)))
         spec.append((f"last_layer.{head}.bias", (n_out,)))
     return spec
@@ -139,9 +149,20 @@ def quantile_heads(feat, state):
     return torch.stack(outs, dim=1)
 
 
-def model_forward(x, state, training: bool = False, emulate_bf16: bool = False):
+def final_layer(feat, state, utype="quantiles"):
+    """the final layers' forward: 3x3 heads stacked on a new dim 1; ReLU on the gaussian variance
+    (gaussian_layer.py:15-17), abs on the residual magnitude (residual_magnitude_layer.py:15-17)."""
+    outs = [F.conv2d(feat, state[f"last_layer.{h}.weight"], state[f"last_layer.{h}.bias"], padding=1) for h in HEADS[utype]]
+    if utype == "gaussian":
+        outs[1] = torch.relu(outs[1])
+    elif utype in ("residual_magnitude", "residual_magnitude_l1"):
+        outs[1] = outs[1].abs()
+    return torch.stack(outs, dim=1)
+
+
+def model_forward(x, state, training: bool = False, emulate_bf16: bool = False, utype: str = "quantiles"):
     """ModelWithUncertainty.forward, core/models/add_uncertainty.py:25-27."""
-    return quantile_heads(unet_forward(x, state, training, emulate_bf16), state)
+    return final_layer(unet_forward(x, state, training, emulate_bf16), state, utype)
 
 
 def pinball(output, target, q: float):
@@ -159,6 +180,31 @@ def quantile_loss(pred, target, params):
     return (params["q_lo_weight"] * pinball(pred[:, 0].squeeze(), t, params["q_lo"])
             + params["q_hi_weight"] * pinball(pred[:, 2].squeeze(), t, params["q_hi"])
             + params["mse_weight"] * F.mse_loss(pred[:, 1].squeeze(), t))
+
+
+def uq_loss(pred, target, params, utype="quantiles"):
+    """the train loss of each final layer (all mean-reduced):
+    quantiles quantile_layer.py:23-32; quantiles_l1 quantile_l1_layer.py:23-32 (L1 point loss); gaussian
+    gaussian_layer.py:19-23 (nn.GaussianNLLLoss, eps 1e-6, clamp under no_grad); residual_magnitude(_l1)
+    residual_magnitude(_l1)_layer.py:19-25 (MSE|L1 point loss + MSE of the magnitude against |y - pred|)."""
+    t = target.squeeze()
+    if utype == "quantiles":
+        return quantile_loss(pred, target, params)
+    if utype == "quantiles_l1":
+        return (params["q_lo_weight"] * pinball(pred[:, 0].squeeze(), t, params["q_lo"])
+                + params["q_hi_weight"] * pinball(pred[:, 2].squeeze(), t, params["q_hi"])
+                + params["mse_weight"] * F.l1_loss(pred[:, 1].squeeze(), t))
+    if utype == "gaussian":
+        mean, var = pred[:, 0].squeeze(), pred[:, 1].squeeze()
+        v = var.clone()
+        with torch.no_grad():
+            v.clamp_(min=1e-6)
+        return (0.5 * (torch.log(v) + (mean - t) ** 2 / v)).mean()
+    if utype in ("residual_magnitude", "residual_magnitude_l1"):
+        p0, m = pred[:, 0].squeeze(), pred[:, 1].squeeze()
+        first = F.mse_loss(p0, t) if utype == "residual_magnitude" else F.l1_loss(p0, t)
+        return first + F.mse_loss(m, (t - p0).abs())
+    raise NotImplementedError(utype)
 
 
 # ----------------------------------------------------------------------------
@@ -189,8 +235,8 @@ def det_fill(key: str, shape: Tuple[int, ...]) -> torch.Tensor:
     return v.to(torch.float32).reshape(shape)
 
 
-def det_state(n_in: int = 1, n_out: int = 1) -> Dict[str, torch.Tensor]:
-    return {k: det_fill(k, shp) for k, shp in state_spec(n_in, n_out)}
+def det_state(n_in: int = 1, n_out: int = 1, utype: str = "quantiles") -> Dict[str, torch.Tensor]:
+    return {k: det_fill(k, shp) for k, shp in state_spec(n_in, n_out, utype=utype)}
 
 
 def det_images(n: int, c: int, h: int, w: int, salt: int = 0):

@@ -7,7 +7,8 @@ fixture holds inputs and the reference's outputs for one reference call site.
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 
-Fixture ids follow SURVEY.md section 8(c): G1..G11.
+Fixture ids follow SURVEY.md section 8(c): G1..G11; G12 covers the final layers of section 8(f) rank 1.
+(`make_golden.py g12` regenerates only the named groups.)
 """
 import os
 import sys
@@ -346,6 +347,69 @@ def g11():
          lower=lo, pred=mid, upper=hi, split=np.array([n_train, n_cal, n_val]))
 
 
+# ---------------------------------------------------------------- G12 the other final layers
+def g12():
+    """per uncertainty type: (a) final layer forward + train loss + gradients on a fixed feature map with the
+    closed-form weights, (b) ModelWithUncertainty.nested_sets_from_output at several lambdas (with the floor) and the
+    layer's own raw edges, (c) calibrate_model + get_rcps_metrics_from_outputs on synthetic outputs."""
+    from core.models.add_uncertainty import add_uncertainty as ref_add
+
+    class Trunk(nn.Module):                       # the factory only needs the two channel counts (add_uncertainty.py:57)
+        n_channels_middle, n_channels_out = 32, 1
+
+        def forward(self, x):
+            return x
+
+    for utype in ("quantiles_l1", "gaussian", "residual_magnitude", "residual_magnitude_l1"):
+        params = dict(PARAMS, uncertainty_type=utype)
+        model = ref_add(Trunk(), params)
+        st = om.det_state(1, 1, utype=utype)
+        model.last_layer.load_state_dict({k[len("last_layer."):]: v for k, v in st.items() if k.startswith("last_layer.")})
+        idx = torch.arange(2 * 32 * 16 * 16, dtype=torch.float64).reshape(2, 32, 16, 16)
+        feat = (0.8 * torch.sin(0.37 * idx) * torch.cos(0.011 * idx + 0.3)).to(torch.float32).requires_grad_(True)
+        y = (0.5 + 0.4 * torch.sin(0.05 * torch.arange(2 * 16 * 16, dtype=torch.float64))).to(torch.float32).reshape(2, 1, 16, 16)
+        pred = model(feat)
+        loss = model.loss_fn(pred, y)
+        loss.backward()
+        grads = {"g_" + n.replace(".", "_"): p.grad for n, p in model.last_layer.named_parameters()}
+        # (b) nested sets
+        lams = torch.tensor([-0.1224, 0.0, 1e-3, 0.5, 1.0, 2.5, 6.0])
+        if utype == "quantiles_l1":
+            out, lab = oc.synth_outputs(3, 1, 16, 16, seed=3)
+        else:
+            out, lab = oc.synth_outputs_two_plane(3, 1, 16, 16, seed=3, utype=utype)
+        lows, ups, raw_lows, raw_ups = [], [], [], []
+        for lam in lams:
+            lo, mid, hi = model.nested_sets_from_output(out.clone(), lam)
+            lows.append(lo); ups.append(hi)
+            rlo, _, rhi = model.in_nested_sets_from_output_fn(model, out.clone(), lam)
+            raw_lows.append(rlo); raw_ups.append(rhi)
+        # (c) calibration on synthetic outputs through the Identity trick (G7)
+        cfg = dict(params, batch_size=32, num_lambdas=80, maximum_lambda=8)
+        if utype == "quantiles_l1":
+            cout, cy = oc.synth_outputs(96, 1, 16, 16, seed=7)
+        else:
+            cout, cy = oc.synth_outputs_two_plane(96, 1, 16, 16, seed=7, utype=utype)
+        ident = ModelWithUncertainty(nn.Identity(), nn.Identity(), model.in_train_loss_fn, model.in_nested_sets_from_output_fn, cfg)
+        with quiet():
+            ident, table = calibrate_model(ident, TensorDataset(cout.clone(), cy.clone()), cfg)
+        fix_randomness(0)
+        with quiet():
+            losses, sizes, spearman, strat, mse, spatial = get_rcps_metrics_from_outputs(
+                ident, TensorDataset(cout.clone(), cy.clone()), fraction_missed_loss, "cpu")
+        save("g12_" + utype, feat=feat, target=y, pred=pred, loss=loss, g_feat=feat.grad, **grads,
+             sets_output=out, lams=lams, lower=torch.stack(lows), upper=torch.stack(ups),
+             raw_lower=torch.stack(raw_lows), raw_upper=torch.stack(raw_ups),
+             cal_output=cout, cal_label=cy, lhat=ident.lhat, table=table, risk=losses, spatial=spatial,
+             sizes=sizes, spearman=np.float64(spearman), mse=np.float64(mse), strat=strat,
+             cfg=np.array([cfg["alpha"], cfg["delta"], cfg["num_lambdas"], cfg["minimum_lambda"], cfg["maximum_lambda"],
+                           cfg["batch_size"]], dtype=np.float64))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    g1_g2(); g3(); g4(); g5(); g6(); g7(); g8(); g9_g10(); g11()
+    only = sys.argv[1:]
+    for name, fn in (("g1_g2", g1_g2), ("g3", g3), ("g4", g4), ("g5", g5), ("g6", g6), ("g7", g7), ("g8", g8),
+                     ("g9_g10", g9_g10), ("g11", g11), ("g12", g12)):
+        if not only or name in only:
+            fn()

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_argument_validation_needs_no_gpu():
     """entry points reject bad arguments before touching the device (error convention: rc<0 + message)."""
     from im2im_uq_amd import _lib
-    rc = _lib.lib.im2im_rcps_loss_table(None, None, 4, 16, None, 8, None, None, None, None)
+    rc = _lib.lib.im2im_rcps_loss_table(None, None, 4, 16, None, 8, 0, None, None, None, None)
     assert rc == -1
     assert b"invalid argument" in _lib.lib.im2im_last_error()
 

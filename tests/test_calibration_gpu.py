@@ -122,3 +122,56 @@ def test_fraction_missed_and_large_image_properties():
         assert torch.equal(ref, table[:1, j].cpu())
     mis = hip_ops.rcps_miscoverage(o, l, float(lambdas[300]))
     assert int(mis.sum()) == int(counts[:, 300].sum())
+
+
+UTYPES = ["quantiles_l1", "gaussian", "residual_magnitude", "residual_magnitude_l1"]
+
+
+def _family(utype):
+    import importlib
+    from im2im_uq_amd.core.models.add_uncertainty import ModelWithUncertainty
+    mod, prefix = {"quantiles_l1": ("quantile_l1_layer", "quantile_regression_l1"), "gaussian": ("gaussian_layer", "gaussian_regression"),
+                   "residual_magnitude": ("residual_magnitude_layer", "residual_magnitude"),
+                   "residual_magnitude_l1": ("residual_magnitude_l1_layer", "residual_magnitude_l1")}[utype]
+    m = importlib.import_module("im2im_uq_amd.core.models.finallayers." + mod)
+    return ModelWithUncertainty(nn.Identity(), nn.Identity(), getattr(m, prefix + "_loss_fn"),
+                                getattr(m, prefix + "_nested_sets_from_output"), dict(BASE, uncertainty_type=utype))
+
+
+@pytest.mark.parametrize("utype", UTYPES)
+def test_g12_other_final_layers_nested_sets_and_calibration_bit_exact(utype):
+    """nested sets (with ModelWithUncertainty's floor and the layer's own raw edges), calibrate_model (one-pass table for
+    every lambda, lhat) and the metrics at lhat for the gaussian / residual-magnitude / quantile-L1 layers: identical
+    bits to the reference (fixtures from tests/golden/make_golden.py g12)."""
+    import random
+    from im2im_uq_amd.core.calibration.calibrate_model import calibrate_model, get_rcps_metrics_from_outputs, fraction_missed_loss
+    g = load_golden("g12_" + utype)
+    model = _family(utype)
+    for i, lam in enumerate(T(g["lams"])):
+        lo, _, hi = model.nested_sets_from_output(T(g["sets_output"]).to(DEV).clone(), lam)
+        assert np.array_equal(lo.cpu().numpy(), g["lower"][i]) and np.array_equal(hi.cpu().numpy(), g["upper"][i]), float(lam)
+        rlo, _, rhi = model.in_nested_sets_from_output_fn(model, T(g["sets_output"]).to(DEV).clone(), lam)
+        assert np.array_equal(rlo.cpu().numpy(), g["raw_lower"][i]) and np.array_equal(rhi.cpu().numpy(), g["raw_upper"][i]), float(lam)
+    ds = TensorDataset(T(g["cal_output"]).clone(), T(g["cal_label"]).clone())
+    model, table = calibrate_model(model, ds, _cfg(g["cfg"]))
+    assert np.array_equal(table.numpy(), g["table"])
+    assert float(model.lhat) == float(g["lhat"])
+    np.random.seed(0); torch.manual_seed(0); random.seed(0)
+    losses, sizes, spearman, strat, mse, spatial = get_rcps_metrics_from_outputs(model, ds, fraction_missed_loss, DEV)
+    assert np.array_equal(losses.numpy(), g["risk"]) and np.array_equal(spatial, g["spatial"])
+    np.testing.assert_allclose(sizes.numpy(), g["sizes"], rtol=0, atol=1e-7)
+    assert spearman == pytest.approx(float(g["spearman"]), abs=1e-6) and mse == pytest.approx(float(g["mse"]), rel=1e-6)
+
+
+@pytest.mark.parametrize("utype", ["gaussian", "residual_magnitude"])
+def test_two_plane_loss_table_vs_oracle_incl_negative_lambda_and_zero_width(utype):
+    from im2im_uq_amd import hip_ops
+    from oracle import calibration as oc
+    form = hip_ops.SETS_SQRT if utype == "gaussian" else hip_ops.SETS_SCALE
+    for (n, c, h, w, L, lmax, seed) in [(5, 1, 7, 9, 17, 3.0, 0), (33, 2, 12, 20, 64, 8.0, 1), (3, 1, 64, 64, 1000, 6.0, 2)]:
+        out, y = oc.synth_outputs_two_plane(n, c, h, w, seed=seed, utype=utype)
+        lambdas = oc.lambda_grid(dict(num_lambdas=L, minimum_lambda=0.0, maximum_lambda=lmax))
+        for grid in (lambdas, lambdas - (lambdas[1] - lambdas[0])):
+            table = hip_ops.rcps_loss_table(out.to(DEV), y.to(DEV), grid, form=form).cpu()
+            ref = torch.stack([oc.fraction_missed(*oc.nested_sets(out, lam, utype)[::2], y) for lam in grid], dim=1)
+            assert np.array_equal(table.numpy(), ref.numpy()), (n, c, h, w, L)

@@ -409,3 +409,65 @@ def test_bf16_centering_reduces_train_mode_rounding_error():
     e_on, e_off = rel_l2(outs["on"], outs["fp32"]), rel_l2(outs["off"], outs["fp32"])
     print("bf16 train-forward error vs fp32: centred", e_on, "un-centred", e_off)
     assert e_on < e_off < 8e-2
+
+
+@pytest.mark.parametrize("utype", ["quantiles_l1", "gaussian", "residual_magnitude", "residual_magnitude_l1"])
+def test_g12_other_final_layers_forward_loss_gradients(utype):
+    """heads kernel + activation, fused loss forward and backward of the gaussian / residual-magnitude / quantile-L1 final
+    layers vs the reference (fixtures g12): output 1e-5, loss 1e-5, gradients 1e-4 rel-L2 (5e-4 for the gaussian NLL), fp32 feature map."""
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from oracle import model as om
+    g = load_golden("g12_" + utype)
+
+    class Trunk(torch.nn.Module):
+        n_channels_middle, n_channels_out = 32, 1
+
+        def forward(self, x):
+            return x
+
+    model = add_uncertainty(Trunk(), dict(PARAMS, uncertainty_type=utype)).to(DEV)
+    st = om.det_state(1, 1, utype=utype)
+    model.last_layer.load_state_dict({k[len("last_layer."):]: v for k, v in st.items() if k.startswith("last_layer.")})
+    model.last_layer.compute_dtype = torch.float32
+    feat = torch.from_numpy(g["feat"]).to(DEV).requires_grad_(True)
+    pred = model(feat)
+    assert pred.shape == g["pred"].shape
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g["pred"], rtol=1e-5, atol=1e-6)
+    loss = model.loss_fn(pred, torch.from_numpy(g["target"]).to(DEV))
+    loss.backward()
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-5)
+    # gaussian: where ReLU zeroes the variance the NLL gradient has terms of size (mean-y)^2/eps^2 ~ 1e10 that cancel in
+    # the sums over pixels, so fp32 summation order shows at the 1e-4 level
+    tol = 5e-4 if utype == "gaussian" else 1e-4
+    assert rel_l2(feat.grad.cpu(), torch.from_numpy(g["g_feat"])) < tol
+    for n, p in model.last_layer.named_parameters():
+        assert rel_l2(p.grad.cpu(), torch.from_numpy(g["g_" + n.replace(".", "_")])) < tol, n
+
+
+@pytest.mark.parametrize("utype", ["gaussian", "residual_magnitude_l1"])
+def test_other_final_layers_train_and_calibrate_end_to_end_bf16(utype):
+    """one bf16 train step + calibration of the full UNet with a two-plane final layer: finite, loss close to the oracle
+    at bf16 storage precision, lhat inside the grid."""
+    from im2im_uq_amd.core.calibration.calibrate_model import calibrate_model
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from im2im_uq_amd.core.models.trunks.unet import UNet
+    from im2im_uq_amd import nn_ops
+    from oracle import model as om
+    from torch.utils.data import TensorDataset
+    params = dict(PARAMS, uncertainty_type=utype)
+    model = add_uncertainty(UNet(1, 1), params).to(DEV)
+    st = om.det_state(1, 1, utype=utype)
+    model.load_state_dict(st, strict=False)
+    model.train()
+    x, y = om.det_images(4, 1, 48, 48, salt=2)
+    opt = nn_ops.FusedAdam(model.parameters(), lr=1e-3)
+    loss = model.loss_fn(model(x.to(DEV)), y.to(DEV))
+    ref = om.uq_loss(om.model_forward(x, dict(st), training=True, emulate_bf16=True, utype=utype), y, params, utype)
+    assert loss.item() == pytest.approx(ref.item(), rel=5e-2)
+    loss.backward()
+    opt.step()
+    assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+    cfg = dict(params, alpha=0.2, delta=0.2, num_lambdas=40, minimum_lambda=0, maximum_lambda=20, rcps_loss="fraction_missed",
+               device=DEV, dataset="synthetic", batch_size=4)
+    model, table = calibrate_model(model, TensorDataset(x, y), cfg)
+    assert table.shape == (4, 40) and bool(torch.isfinite(table).all()) and 0.0 <= float(model.lhat) <= 21.0

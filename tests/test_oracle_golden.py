@@ -153,3 +153,42 @@ def test_g10_metrics():
     losses, spatial = oc.risk_and_miscoverage(T(g["output"]), T(g["label"]), T(g["lhat"]))
     assert np.array_equal(losses.numpy(), g["losses"])
     np.testing.assert_allclose(spatial, g["spatial"], rtol=1e-6, atol=1e-7)
+
+
+UTYPES = ["quantiles_l1", "gaussian", "residual_magnitude", "residual_magnitude_l1"]
+
+
+@pytest.mark.parametrize("utype", UTYPES)
+def test_g12_final_layer_loss_and_gradients(utype):
+    """the other final layers: heads + activation, train loss and its gradients vs the reference."""
+    g = load_golden("g12_" + utype)
+    st = om.det_state(1, 1, utype=utype)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in st.items() if k.startswith("last_layer.")}
+    feat = T(g["feat"]).clone().requires_grad_(True)
+    pred = om.final_layer(feat, leaves, utype)
+    np.testing.assert_allclose(pred.detach().numpy(), g["pred"], rtol=1e-5, atol=1e-6)
+    loss = om.uq_loss(pred, T(g["target"]), PARAMS, utype)
+    loss.backward()
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-5)
+    np.testing.assert_allclose(feat.grad.numpy(), g["g_feat"], rtol=1e-4, atol=1e-7 * float(np.abs(g["g_feat"]).max()) + 1e-12)
+    for k, v in leaves.items():
+        ref = g["g_" + k[len("last_layer."):].replace(".", "_")]
+        assert float(np.linalg.norm(v.grad.numpy() - ref) / (np.linalg.norm(ref) + 1e-30)) < 1e-4, k
+
+
+@pytest.mark.parametrize("utype", UTYPES)
+def test_g12_nested_sets_and_calibration(utype):
+    g = load_golden("g12_" + utype)
+    out = T(g["sets_output"])
+    for i, lam in enumerate(T(g["lams"])):
+        lo, _, hi = oc.nested_sets(out, lam, utype)
+        assert np.array_equal(lo.numpy(), g["lower"][i]) and np.array_equal(hi.numpy(), g["upper"][i])
+        rlo, _, rhi = oc.raw_nested_sets(out, lam, utype)
+        assert np.array_equal(rlo.numpy(), g["raw_lower"][i]) and np.array_equal(rhi.numpy(), g["raw_upper"][i])
+    v = g["cfg"]
+    cfg = dict(alpha=float(v[0]), delta=float(v[1]), num_lambdas=int(v[2]), minimum_lambda=float(v[3]), maximum_lambda=float(v[4]))
+    lhat, table, _ = oc.calibrate_from_outputs(T(g["cal_output"]), T(g["cal_label"]), cfg, utype)
+    assert np.array_equal(table.numpy(), g["table"]) and float(lhat) == float(g["lhat"])
+    losses, spatial = oc.risk_and_miscoverage(T(g["cal_output"]), T(g["cal_label"]), T(g["lhat"]), utype)
+    assert np.array_equal(losses.numpy(), g["risk"])
+    np.testing.assert_allclose(spatial, g["spatial"], rtol=1e-6, atol=1e-7)
