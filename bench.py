@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--legs", default="train,calib", help="which legs to run (profiling: --legs train / --legs calib)")
+    ap.add_argument("--uncertainty-type", default="quantiles",
+                    choices=["quantiles", "quantiles_l1", "gaussian", "residual_magnitude", "residual_magnitude_l1"],
+                    help="final layer (the headline metric is 'quantiles'; the others are the SURVEY 8f rank-1 rows)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,7 +109,11 @@ def main():
 
     nn_ops.set_compute_dtype(args.dtype)
     torch.manual_seed(0)                                                  # same init on every rank
-    cfg = dict(PARAMS, device=str(dev), batch_size=args.batch)
+    cfg = dict(PARAMS, device=str(dev), batch_size=args.batch, uncertainty_type=args.uncertainty_type)
+    two_plane = args.uncertainty_type in ("gaussian", "residual_magnitude", "residual_magnitude_l1")
+    form = {"gaussian": hip_ops.SETS_SQRT, "residual_magnitude": hip_ops.SETS_SCALE,
+            "residual_magnitude_l1": hip_ops.SETS_SCALE}.get(args.uncertainty_type, hip_ops.SETS_QUANTILE)
+    calib_bytes_per_img = (12 if two_plane else 16) * 320 * 320       # 2 or 3 fp32 output planes + the label, read once
     model = add_uncertainty(UNet(1, 1), cfg).to(dev)
     opt = nn_ops.FusedAdam(model.parameters(), lr=cfg["lr"])
     params = [p for p in model.parameters() if p.requires_grad]
@@ -199,7 +206,11 @@ def main():
     calib_ips = M * world * cal_steps / dt_cal
     # scoring kernel alone on outputs shaped like SURVEY 8(d): lhat lands mid-grid
     pred = torch.rand(M, 1, hw, hw, device=dev, generator=g)
-    out3 = torch.stack([pred - 0.05 * torch.rand_like(pred), pred, pred + 0.05 * torch.rand_like(pred)], dim=1).contiguous()
+    if two_plane:
+        mag = 0.05 * torch.rand_like(pred)
+        out3 = torch.stack([pred, mag * mag if args.uncertainty_type == "gaussian" else mag], dim=1).contiguous()
+    else:
+        out3 = torch.stack([pred - 0.05 * torch.rand_like(pred), pred, pred + 0.05 * torch.rand_like(pred)], dim=1).contiguous()
     lab = pred + 0.05 * torch.randn(pred.shape, device=dev, generator=g)
     lambdas = torch.linspace(0, 6, 1000)
     lam_eff = lambdas - (lambdas[1] - lambdas[0])
@@ -209,20 +220,20 @@ def main():
     hist = torch.empty((_abi.im2im_rcps_workspace_bytes(M, hw * hw, 1000) // 4,), dtype=torch.int32, device=dev)
     table = torch.empty((M, 1000), dtype=torch.float32, device=dev)
     for _ in range(3):
-        hip_ops.rcps_loss_table_raw(out3, lab, M, hw * hw, lam_dev, hist, table)
+        hip_ops.rcps_loss_table_raw(out3, lab, M, hw * hw, lam_dev, hist, table, None, form)
     reps = 20
     e0.record()
     for _ in range(reps):
-        hip_ops.rcps_loss_table_raw(out3, lab, M, hw * hw, lam_dev, hist, table)
+        hip_ops.rcps_loss_table_raw(out3, lab, M, hw * hw, lam_dev, hist, table, None, form)
     e1.record()
     torch.cuda.synchronize()
     ms_score = e0.elapsed_time(e1) / reps
-    score_gbs = M * CALIB_BYTES_PER_IMG * (hw * hw) / (320 * 320) / ms_score / 1e6
+    score_gbs = M * calib_bytes_per_img * (hw * hw) / (320 * 320) / ms_score / 1e6
     traffic = None                      # HBM bytes per launch from the committed PMC passes (same M and size only)
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             rec = json.load(f)["rcps_hist_kernel"]
-        if rec["images"] == M and rec["hw"] == hw:
+        if rec["images"] == M and rec["hw"] == hw and not two_plane:
             traffic = rec["traffic_bytes_per_launch"]
     except Exception:  # noqa: BLE001
         pass
@@ -233,7 +244,7 @@ def main():
                          "roofline": {"bound": "hbm", "achieved": score_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                       "frac": score_gbs / PEAK_HBM_GBS, "traffic": traffic,
                                       "kernel": "rcps_hist_kernel (+ memset + suffix)",
-                                      "algorithmic_bytes_per_launch": M * CALIB_BYTES_PER_IMG}},
+                                      "algorithmic_bytes_per_launch": M * calib_bytes_per_img}},
     }
 
     cpu = None
@@ -242,11 +253,12 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "train imgs/sec (+ calib imgs/sec in `calib`), fastMRI 320x320 UNet quantile regression",
+            "metric": "train imgs/sec (+ calib imgs/sec in `calib`), fastMRI 320x320 UNet "
+                      + ("quantile regression" if args.uncertainty_type == "quantiles" else args.uncertainty_type),
             "value": train_ips, "unit": "imgs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_train / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (fastMRI-shaped, random-init weights)",
-            "config": {"workload": f"fastMRI knee singlecoil {hw}x{hw} UNet quantile regression (BASELINE configs[1])",
+            "config": {"workload": f"fastMRI knee singlecoil {hw}x{hw} UNet {args.uncertainty_type} (BASELINE configs[1])",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "train_tflops": train_ips * TRAIN_FLOP_PER_IMG * (hw * hw) / (320 * 320) / 1e12},
             "roofline": roof, "roofline_wgrad": roof_w, "calib": calib, "cpu_baseline": cpu, "per_kernel": per_kernel,

@@ -60,7 +60,7 @@ template <int FORM> struct SetForm {
     } else if constexpr (FORM == 1) {
       p = a; d_lo = b; d_up = b;
     } else {
-      p = a; d_lo = (float)sqrt((double)b); d_up = d_lo;      // fp64 sqrt rounded once more to fp32 == correctly rounded fp32 sqrt (53 >= 2*24+2)
+      p = a; d_lo = sqrtf(b); d_up = d_lo;                    // correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt; NOT __fsqrt_rn, which maps to the 1-ulp native instruction)
     }
   }
 };
