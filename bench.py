@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--legs", default="train,calib", help="which legs to run (profiling: --legs train / --legs calib)")
     ap.add_argument("--uncertainty-type", default="quantiles",
-                    choices=["quantiles", "quantiles_l1", "gaussian", "residual_magnitude", "residual_magnitude_l1"],
+                    choices=["quantiles", "quantiles_l1", "gaussian", "residual_magnitude", "residual_magnitude_l1", "softmax"],
                     help="final layer (the headline metric is 'quantiles'; the others are the SURVEY 8f rank-1 rows)")
     args = ap.parse_args()
 
@@ -109,10 +109,11 @@ def main():
 
     nn_ops.set_compute_dtype(args.dtype)
     torch.manual_seed(0)                                                  # same init on every rank
-    cfg = dict(PARAMS, device=str(dev), batch_size=args.batch, uncertainty_type=args.uncertainty_type)
+    cfg = dict(PARAMS, device=str(dev), batch_size=args.batch, uncertainty_type=args.uncertainty_type,
+               num_softmax=50, minimum_lambda_softmax=0, maximum_lambda_softmax=1.2)      # fastmri_test/config.yml
     two_plane = args.uncertainty_type in ("gaussian", "residual_magnitude", "residual_magnitude_l1")
     form = {"gaussian": hip_ops.SETS_SQRT, "residual_magnitude": hip_ops.SETS_SCALE,
-            "residual_magnitude_l1": hip_ops.SETS_SCALE}.get(args.uncertainty_type, hip_ops.SETS_QUANTILE)
+            "residual_magnitude_l1": hip_ops.SETS_SCALE, "softmax": hip_ops.SETS_SOFTMAX}.get(args.uncertainty_type, hip_ops.SETS_QUANTILE)
     calib_bytes_per_img = (12 if two_plane else 16) * 320 * 320       # 2 or 3 fp32 output planes + the label, read once
     model = add_uncertainty(UNet(1, 1), cfg).to(dev)
     opt = nn_ops.FusedAdam(model.parameters(), lr=cfg["lr"])
@@ -209,6 +210,9 @@ def main():
     if two_plane:
         mag = 0.05 * torch.rand_like(pred)
         out3 = torch.stack([pred, mag * mag if args.uncertainty_type == "gaussian" else mag], dim=1).contiguous()
+    elif args.uncertainty_type == "softmax":                    # (lower quantile, prediction, upper quantile) bins of 1/50
+        q = torch.round(pred * 50) / 50
+        out3 = torch.stack([(q - 0.04).clamp(0, 1), q, (q + 0.04).clamp(0, 1)], dim=1).contiguous()
     else:
         out3 = torch.stack([pred - 0.05 * torch.rand_like(pred), pred, pred + 0.05 * torch.rand_like(pred)], dim=1).contiguous()
     lab = pred + 0.05 * torch.randn(pred.shape, device=dev, generator=g)

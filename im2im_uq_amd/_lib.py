@@ -73,6 +73,9 @@ SIGNATURES = {
     "im2im_quantile_loss_workspace_bytes": (_i64, []),
     "im2im_quantile_loss_fwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _ptr, _ptr, _ptr]),
     "im2im_quantile_loss_bwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _i64, _ptr]),
+    "im2im_softmax_ce_fwd": (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _i32, _i32, _ptr, _ptr, _ptr]),
+    "im2im_softmax_ce_bwd": (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _i32, _i32, _ptr, _ptr, _ptr]),
+    "im2im_softmax_sets_summary": (_i32, [_ptr, _i64, _i64, _i32, _i32, _i32, _ptr, _ptr]),
     # kind, a, b, c, target, N, P, img_stride, q_lo, q_hi, w0, w1, w2, loss, ws, stream
     "im2im_uq_loss_fwd": (_i32, [_i32, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _ptr, _ptr, _ptr]),
     # kind, a, b, c, target, N, P, img_stride, q_lo, q_hi, w0, w1, w2, grad_out, d_a, d_b, d_c, d_stride, stream

@@ -24,7 +24,7 @@ from torch.utils.data import DataLoader, Subset, TensorDataset
 
 from .. import _pkg  # noqa: F401
 from ... import hip_ops
-from ..models.add_uncertainty import sets_form
+from ..models.add_uncertainty import calibration_repr, sets_form
 from .bounds import HB_mu_plus
 
 
@@ -77,15 +77,17 @@ def get_rcps_loss_fn(config):
         raise NotImplementedError
 
 
-def _as_device_pair(out_dataset, device):
+def _as_device_pair(out_dataset, device, model=None):
     outputs, labels = out_dataset.tensors
-    return (outputs.to(device=device, dtype=torch.float32).contiguous(),
-            labels.to(device=device, dtype=torch.float32).contiguous())
+    outputs = outputs.to(device=device, dtype=torch.float32).contiguous()
+    if model is not None:
+        outputs = calibration_repr(model, outputs)            # softmax layer: class logits -> quantile summary planes
+    return outputs, labels.to(device=device, dtype=torch.float32).contiguous()
 
 
 def get_rcps_losses_from_outputs(model, out_dataset, rcps_loss_fn, lam, device):
     """Losses [N] (cpu) of every image at ONE lambda (reference :21-29)."""
-    outputs, labels = _as_device_pair(out_dataset, device)
+    outputs, labels = _as_device_pair(out_dataset, device, model)
     form = sets_form(model)
     if rcps_loss_fn is fraction_missed_loss and form is not None:
         lam_t = torch.as_tensor(lam, dtype=torch.float32).reshape(1)
@@ -110,7 +112,7 @@ def get_rcps_metrics_from_outputs(model, out_dataset, rcps_loss_fn, device):
     (losses[N], sizes[N], spearman, stratified_risks[4], mse, spatial_miscoverage[H,W]).
     numpy/torch RNG is consumed in the reference's order (one np.random.choice per batch of 64, then one
     torch.rand), so with the same seed the sampled-pixel statistics are the reference's."""
-    outputs, labels = _as_device_pair(out_dataset, device)
+    outputs, labels = _as_device_pair(out_dataset, device, model)
     model = model.to(device)
     if model.lhat is None:
         raise Exception("You have to specify lambda unless your model is already calibrated.")
@@ -175,7 +177,7 @@ def collect_outputs(model, dataset, config, device, shard=True):
             lo, hi = shard_bounds(len(samples), dist.get_rank(), dist.get_world_size())
             samples = samples[lo:hi]
         labels = torch.cat([s[1].unsqueeze(0) for s in samples], dim=0).to(device, torch.float32)
-        outputs = torch.cat([model(s[0].unsqueeze(0).to(device, torch.float32)) for s in samples], dim=0)
+        outputs = torch.cat([calibration_repr(model, model(s[0].unsqueeze(0).to(device, torch.float32))) for s in samples], dim=0)
         return outputs.contiguous(), labels.contiguous()
     n_total = len(dataset)
     if dist is not None and not getattr(dataset, "im2im_local_shard", False):
@@ -191,7 +193,7 @@ def collect_outputs(model, dataset, config, device, shard=True):
     else:
         loader = DataLoader(dataset, num_workers=0, batch_size=config['batch_size'], pin_memory=True)
     for batch in loader:
-        out = model(batch[0].to(device=device, dtype=torch.float32))
+        out = calibration_repr(model, model(batch[0].to(device=device, dtype=torch.float32)))
         if outputs is None:
             outputs = torch.empty((n,) + tuple(out.shape[1:]), dtype=torch.float32, device=device)
             labels = torch.empty((n,) + tuple(batch[1].shape[1:]), dtype=torch.float32, device=device)

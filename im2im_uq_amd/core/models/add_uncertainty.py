@@ -7,7 +7,8 @@ buffer `lhat`, attributes baseModel / last_layer / params.  state_dict keys are 
 
 Scope of this build (SURVEY section 8 + 8f rank 1): "quantiles", "quantiles_l1", "gaussian", "residual_magnitude" and
 "residual_magnitude_l1" run on the HIP kernels (same trunk, heads and calibration kernels; only the head count, the
-fused loss and the nested-set formula differ); "softmax" and "inn" raise NotImplementedError naming themselves.
+fused loss and the nested-set formula differ), "softmax" too (MFMA conv to the class logits, fused cross entropy, a
+softmax-quantile summary kernel feeding the same calibration kernels); "inn" raises NotImplementedError naming itself.
 """
 import torch
 import torch.nn as nn
@@ -24,12 +25,20 @@ from .finallayers.residual_magnitude_layer import (ResidualMagnitudeLayer, resid
                                                    residual_magnitude_nested_sets_from_output)
 from .finallayers.residual_magnitude_l1_layer import (ResidualMagnitudeL1Layer, residual_magnitude_l1_loss_fn,
                                                       residual_magnitude_l1_nested_sets_from_output)
+from .finallayers.softmax_layer import SoftmaxLayer, softmax_loss_fn, softmax_nested_sets_from_output
 
 
 def sets_form(model):
     """IM2IM_SETS_* form of the model's nested sets when they are one of this package's (then every calibration kernel
     evaluates them directly from the raw output planes), else None (plugin function: generic per-lambda path)."""
     return getattr(getattr(model, "in_nested_sets_from_output_fn", None), "im2im_sets_form", None)
+
+
+def calibration_repr(model, output):
+    """what calibration keeps of a model output: the output itself, or (softmax layer) its lambda-independent
+    [b,3,C,H,W] quantile summary."""
+    summarize = getattr(getattr(model, "in_nested_sets_from_output_fn", None), "im2im_summarize", None)
+    return output if summarize is None else summarize(output)
 
 
 class ModelWithUncertainty(nn.Module):
@@ -71,7 +80,7 @@ class ModelWithUncertainty(nn.Module):
         self.lhat = lhat
 
 
-_OUT_OF_SCOPE = ("softmax", "inn")
+_OUT_OF_SCOPE = ("inn",)
 
 
 def add_uncertainty(model, params):
@@ -95,10 +104,14 @@ def add_uncertainty(model, params):
         last_layer = ResidualMagnitudeL1Layer(model.n_channels_middle, model.n_channels_out, params)
         train_loss_fn = residual_magnitude_l1_loss_fn
         nested_sets_from_output_fn = residual_magnitude_l1_nested_sets_from_output
+    elif params["uncertainty_type"] == "softmax":
+        last_layer = SoftmaxLayer(model.n_channels_middle, model.n_channels_out, params)
+        train_loss_fn = softmax_loss_fn
+        nested_sets_from_output_fn = softmax_nested_sets_from_output
     elif params["uncertainty_type"] in _OUT_OF_SCOPE:
         raise NotImplementedError(
             f"uncertainty_type={params['uncertainty_type']!r} is outside this build's scope (SURVEY.md section 8f): "
-            "the quantile, gaussian and residual-magnitude families run on the HIP kernels; softmax and inn do not yet")
+            "the quantile, gaussian, residual-magnitude and softmax layers run on the HIP kernels; inn does not yet")
     else:
         raise NotImplementedError
     return ModelWithUncertainty(model, last_layer, train_loss_fn, nested_sets_from_output_fn, params)

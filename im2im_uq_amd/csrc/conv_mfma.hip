@@ -479,8 +479,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wco = wave >> 1, wci = wave & 1;        // 2 x 2 waves, 32 co x 32 ci each
   const int half = lane >> 5, l31 = lane & 31;
-  const int ci_tiles = a.Ci / CT;
-  const int co0 = (blockIdx.x / ci_tiles) * CT, ci0 = (blockIdx.x % ci_tiles) * CT;   // Co may be 32 mod 64: masked
+  const int ci_tiles = (a.Ci + CT - 1) / CT;
+  const int co0 = (blockIdx.x / ci_tiles) * CT, ci0 = (blockIdx.x % ci_tiles) * CT;   // Co / Ci may be 32 mod 64: masked
   const WgradSrc<T> xs(a, ci0);
   const T* __restrict__ xg = xs.x;
   const T* __restrict__ dzg = reinterpret_cast<const T*>(a.dz);
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       const int px = p / PPR, part = p % PPR;
       const int yy = y0 + px / HWD - PAD, xx = x0 + px % HWD - PAD;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (px < HPX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+      if (px < HPX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && ci0 + part * EPP < a.Ci) {
         v = *reinterpret_cast<const uint4*>(xb + ((size_t)yy * a.W + xx) * xs.stride + part * EPP);
         if (xs.sc) {
           float f[EPP];
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       const int ci = ci0 + wci * 32 + l31;
-      if (co < a.Co) out[((size_t)co * TAPS + tp) * a.Ci + ci] = acc[tp][r];
+      if (co < a.Co && ci < a.Ci) out[((size_t)co * TAPS + tp) * a.Ci + ci] = acc[tp][r];
     }
 }
 
@@ -901,7 +901,7 @@ int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float
   constexpr size_t smem = (size_t)(TH * TW + (TH + 2 * PAD) * (TW + 2 * PAD)) * PB;
   WgradArgs a{x, dz, partial, B, H, W, Ci, Co, (int)cdiv(H, TH), (int)cdiv(W, TW), 0, 0, x_ss, x_hi, x_ss_hi, Ci_lo};
   a.ntiles = B * a.tilesY * a.tilesX;
-  const int cblocks = (int)cdiv(Co, 64) * (Ci / 64);
+  const int cblocks = (int)cdiv(Co, 64) * (int)cdiv(Ci, 64);
   const size_t wsz = (size_t)Co * TAPS * Ci * sizeof(float);
   int64_t max_split = partial_bytes / (int64_t)wsz;
   if (max_split < 1) return fail_invalid("wgrad: workspace smaller than one weight-sized slab");
@@ -911,7 +911,9 @@ int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float
   if (nsplit < 1) nsplit = 1;
   a.tiles_per_split = (int)cdiv(a.ntiles, nsplit);
   nsplit = cdiv(a.ntiles, a.tiles_per_split);
-  if constexpr (IS_BF16 && TAPS == 9) {
+  const bool pipe = IS_BF16 && TAPS == 9 && Ci % 64 == 0;   // the pipelined kernel has no channel masking
+  if (pipe) {
+   if constexpr (IS_BF16 && TAPS == 9) {
     constexpr size_t smem2 = 2 * smem;                        // double-buffered tiles, one 12-wave workgroup per CU
     auto kern = conv_wgrad_pipe_kernel<TH, TW>;
     static bool attr_set = false;
@@ -921,6 +923,7 @@ int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)cblocks, (unsigned)nsplit), dim3(768), smem2, stream, a);
     if (int rc = check_launch("conv_wgrad_pipe_kernel")) return rc;
+   }
   } else {
     auto kern = conv_wgrad_kernel<T, TH, TW, TAPS>;
     static bool attr_set = false;
@@ -939,9 +942,9 @@ int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float
 }  // namespace
 
 extern "C" int64_t im2im_conv_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t taps) {
-  if (Ci <= 0 || Co <= 0 || Ci % 64 || Co % 32) return -1;
+  if (Ci <= 0 || Co <= 0 || Ci % 32 || Co % 32) return -1;
   const int64_t ntiles = (int64_t)B * im2im::cdiv(H, 8) * im2im::cdiv(W, 16);
-  const int64_t cblocks = im2im::cdiv(Co, 64) * (Ci / 64);
+  const int64_t cblocks = im2im::cdiv(Co, 64) * im2im::cdiv(Ci, 64);
   int64_t nsplit = im2im::cdiv(taps == 1 ? 1536 : 512, cblocks);
   if (nsplit > ntiles) nsplit = ntiles;
   if (nsplit < 1) nsplit = 1;
@@ -969,7 +972,7 @@ extern "C" int im2im_conv_wgrad_split(const void* x, const float* x_scale_shift,
     Ci_lo = Ci;
   }
   IM2IM_REQUIRE(B > 0 && H > 0 && W > 0);
-  IM2IM_REQUIRE(Ci > 0 && Ci % 64 == 0);
+  IM2IM_REQUIRE(Ci > 0 && Ci % 32 == 0);
   IM2IM_REQUIRE(Co > 0 && Co % 32 == 0);
   IM2IM_REQUIRE(taps == 9 || taps == 1);
   IM2IM_REQUIRE(dtype == IM2IM_F32 || dtype == IM2IM_BF16);

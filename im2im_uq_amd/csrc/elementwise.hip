@@ -780,6 +780,129 @@ __global__ __launch_bounds__(256) void qloss_bwd_kernel(LossArgs a, const float*
 }
 
 // ------------------------------------------------------------------------------------------------
+// Softmax final layer (finallayers/softmax_layer.py): logits [M][stride] T (NHWC pixels x padded class channels, the
+// first K valid), one thread per pixel, all arithmetic fp32 in the reference's order (max, exp, sequential sum, divide).
+constexpr int SOFTMAX_MAX_K = 64;
+template <typename T>
+__device__ __forceinline__ void load_logits(const T* __restrict__ row, int K, float (&z)[SOFTMAX_MAX_K]) {
+  constexpr int N = Vec16<T>::N;
+#pragma unroll
+  for (int k = 0; k < SOFTMAX_MAX_K; k += N) {
+    float v[N];
+    if (k < K) Vec16<T>::load(row + k, v);
+#pragma unroll
+    for (int j = 0; j < N; ++j) z[k + j] = (k + j < K) ? v[j] : -INFINITY;
+  }
+}
+// torch.bucketize(v, bounds, right=False): first index i with bounds[i] >= v; indices >= K fold to K-1 (:21-22)
+__device__ __forceinline__ int bucket_of(float v, const float* __restrict__ bounds, int K) {
+  int idx = 0;
+  for (int k = 0; k < K; ++k) idx += (bounds[k] < v) ? 1 : 0;
+  return idx >= K ? K - 1 : idx;
+}
+// nn.CrossEntropyLoss (mean over pixels): partial[blk] = sum over the block's pixels of -(z_t - max - log sum exp)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_ce_partial_kernel(const T* __restrict__ logits, const float* __restrict__ target,
+                                                                  const float* __restrict__ bounds, int64_t M, int K, int stride,
+                                                                  float* __restrict__ partial) {
+  __shared__ float s_red[4];
+  float acc = 0.f;
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+    float z[SOFTMAX_MAX_K];
+    load_logits(logits + m * stride, K, z);
+    float mx = z[0];
+#pragma unroll
+    for (int k = 1; k < SOFTMAX_MAX_K; ++k) mx = fmaxf(mx, z[k]);
+    float sum = 0.f, zt = 0.f;
+    const int t = bucket_of(target[m], bounds, K);
+#pragma unroll
+    for (int k = 0; k < SOFTMAX_MAX_K; ++k) {
+      if (k < K) { sum += expf(z[k] - mx); if (k == t) zt = z[k]; }
+    }
+    acc += logf(sum) - (zt - mx);
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+__global__ void softmax_ce_final_kernel(const double* __restrict__ tmp, int S, double count, float* __restrict__ loss) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0.0;
+  for (int i = 0; i < S; ++i) s += tmp[i];
+  loss[0] = (float)(s / count);
+}
+// d(logits) = g/M * (softmax - onehot); padded class channels get 0
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_ce_bwd_kernel(const T* __restrict__ logits, const float* __restrict__ target,
+                                                              const float* __restrict__ bounds, int64_t M, int K, int stride,
+                                                              const float* __restrict__ gscale, T* __restrict__ dlogits) {
+  constexpr int N = Vec16<T>::N;
+  const float g = gscale[0] / (float)M;
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+    float z[SOFTMAX_MAX_K];
+    load_logits(logits + m * stride, K, z);
+    float mx = z[0];
+#pragma unroll
+    for (int k = 1; k < SOFTMAX_MAX_K; ++k) mx = fmaxf(mx, z[k]);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < SOFTMAX_MAX_K; ++k) { z[k] = (k < K) ? expf(z[k] - mx) : 0.f; sum += z[k]; }
+    const int t = bucket_of(target[m], bounds, K);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int k = 0; k < SOFTMAX_MAX_K; k += N) {
+      if (k < stride) {
+        float v[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = (k + j < K) ? g * (z[k + j] * inv - ((k + j == t) ? 1.f : 0.f)) : 0.f;
+        Vec16<T>::store(dlogits + m * stride + k, v);
+      }
+    }
+  }
+}
+// softmax_nested_sets_from_output, the lambda-independent part (:33-47): softmax over the classes, running sum,
+//   lq = #(cumsum <= 0.05)/K, uq = #(cumsum <= 0.95)/K, pred = argmax/K, the collapse guards and the [0,1] clamp.
+// out3 [N][3][P] fp32 planes (lq, pred, uq) of pixel m = n*P + i.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_summary_kernel(const T* __restrict__ logits, int64_t M, int64_t P, int K, int stride,
+                                                               float* __restrict__ out3) {
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+    float z[SOFTMAX_MAX_K];
+    load_logits(logits + m * stride, K, z);
+    float mx = z[0];
+#pragma unroll
+    for (int k = 1; k < SOFTMAX_MAX_K; ++k) mx = fmaxf(mx, z[k]);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < SOFTMAX_MAX_K; ++k) { if (k < K) { z[k] = expf(z[k] - mx); sum += z[k]; } }
+    float cum = 0.f, best = -1.f;
+    int n_lo = 0, n_hi = 0, arg = 0;
+#pragma unroll
+    for (int k = 0; k < SOFTMAX_MAX_K; ++k) {
+      if (k < K) {
+        const float pk = z[k] / sum;
+        if (pk > best) { best = pk; arg = k; }               // first maximum, as torch.argmax
+        cum += pk;
+        n_lo += (cum <= 0.05f) ? 1 : 0;
+        n_hi += (cum <= 0.95f) ? 1 : 0;
+      }
+    }
+    const float Kf = (float)K, step = (float)(1.0 / (double)K);
+    const float pred = (float)arg / Kf;
+    float lq = (float)n_lo / Kf, uq = (float)n_hi / Kf;
+    if (pred == lq) lq -= step;
+    if (pred == uq) uq += step;
+    lq = fminf(fmaxf(lq, 0.f), 1.f);
+    uq = fminf(fmaxf(uq, 0.f), 1.f);
+    const int64_t n = m / P, i = m - n * P;
+    out3[(n * 3 + 0) * P + i] = lq;
+    out3[(n * 3 + 1) * P + i] = pred;
+    out3[(n * 3 + 2) * P + i] = uq;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // multi-tensor Adam (torch.optim.Adam defaults as used at core/scripts/train.py:120; no weight decay / amsgrad)
 constexpr int ADAM_MAX_TENSORS = 24;
 struct AdamArgs {
@@ -1087,6 +1210,55 @@ extern "C" int im2im_quantile_loss_bwd(const float* lo, const float* mid, const 
                                        int64_t d_stride, im2im_stream_t stream_) {
   return im2im_uq_loss_bwd(IM2IM_LOSS_QUANTILE, lo, mid, hi, target, N, P, img_stride, q_lo, q_hi, w_lo, w_hi, w_mse, grad_out, d_lo,
                            d_mid, d_hi, d_stride, stream_);
+}
+
+extern "C" int im2im_softmax_ce_fwd(const void* logits, const float* target, const float* bounds, int64_t M, int32_t K,
+                                   int32_t stride, int32_t dtype, float* loss, void* ws, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(logits && target && bounds && loss && ws && M > 0);
+  IM2IM_REQUIRE(K >= 2 && K <= SOFTMAX_MAX_K && stride >= K && stride % 8 == 0 && stride <= SOFTMAX_MAX_K);
+  float* partial = (float*)ws;
+  double* tmp = (double*)((char*)ws + 1024 * 3 * sizeof(float));
+  int64_t nblk = cdiv(M, 256 * 2);
+  if (nblk > 1024) nblk = 1024;
+  return for_dtype(dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    hipLaunchKernelGGL(softmax_ce_partial_kernel<T>, dim3((unsigned)nblk), dim3(256), 0, stream, (const T*)logits, target, bounds, M,
+                       (int)K, (int)stride, partial);
+    if (int rc = check_launch("softmax_ce_partial_kernel")) return rc;
+    int rc;
+    const int S = launch_reduce_stage1(partial, nblk, 1, tmp, stream, &rc);
+    if (rc) return rc;
+    hipLaunchKernelGGL(softmax_ce_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)tmp, S, (double)M, loss);
+    return check_launch("softmax_ce_final_kernel");
+  });
+}
+
+extern "C" int im2im_softmax_ce_bwd(const void* logits, const float* target, const float* bounds, int64_t M, int32_t K,
+                                   int32_t stride, int32_t dtype, const float* grad_out, void* dlogits, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(logits && target && bounds && grad_out && dlogits && M > 0);
+  IM2IM_REQUIRE(K >= 2 && K <= SOFTMAX_MAX_K && stride >= K && stride % 8 == 0 && stride <= SOFTMAX_MAX_K);
+  return for_dtype(dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    hipLaunchKernelGGL(softmax_ce_bwd_kernel<T>, dim3(ew_blocks(M)), dim3(256), 0, stream, (const T*)logits, target, bounds, M, (int)K,
+                       (int)stride, grad_out, (T*)dlogits);
+    return check_launch("softmax_ce_bwd_kernel");
+  });
+}
+
+extern "C" int im2im_softmax_sets_summary(const void* logits, int64_t N, int64_t P, int32_t K, int32_t stride, int32_t dtype,
+                                         float* out3, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(logits && out3 && N >= 0 && P > 0);
+  IM2IM_REQUIRE(K >= 2 && K <= SOFTMAX_MAX_K && stride >= K && stride % 8 == 0 && stride <= SOFTMAX_MAX_K);
+  if (N == 0) return IM2IM_OK;
+  return for_dtype(dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    hipLaunchKernelGGL(softmax_summary_kernel<T>, dim3(ew_blocks(N * P)), dim3(256), 0, stream, (const T*)logits, N * P, P, (int)K,
+                       (int)stride, out3);
+    return check_launch("softmax_summary_kernel");
+  });
 }
 
 extern "C" int im2im_adam_step(int32_t n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,

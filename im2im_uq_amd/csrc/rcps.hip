@@ -48,9 +48,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // FORM 0  planes (l, p, u): d_lo = p - min(l, p-1e-6), d_up = max(u, p+1e-6) - p     quantile(_l1)_layer.py:39-42
 // FORM 1  planes (p, s):    d_lo = d_up = s                                          residual_magnitude(_l1)_layer.py:33-34
 // FORM 2  planes (p, v):    d_lo = d_up = sqrt(v)  (correctly rounded, as torch)      gaussian_layer.py:31-32
+// FORM 3  planes (lq, p, uq): d_lo = relu(p - lq), d_up = relu(uq - p)               softmax_layer.py:50-51 (lq, p, uq are
+//         the lambda-independent quantile summary of the softmax output, im2im_softmax_sets_summary)
 template <int FORM> struct SetForm {
-  static constexpr int PLANES = FORM == 0 ? 3 : 2;
-  static constexpr int PRED = FORM == 0 ? 1 : 0;
+  static constexpr int PLANES = (FORM == 0 || FORM == 3) ? 3 : 2;
+  static constexpr int PRED = (FORM == 0 || FORM == 3) ? 1 : 0;
   // a = plane 0, b = plane 1, c = plane 2 (FORM 0 only)
   static __device__ __forceinline__ void widths(float a, float b, float c, float& p, float& d_lo, float& d_up) {
     if constexpr (FORM == 0) {
@@ -59,6 +61,10 @@ template <int FORM> struct SetForm {
       d_up = __fsub_rn(fmaxf(c, __fadd_rn(p, 1e-6f)), p);
     } else if constexpr (FORM == 1) {
       p = a; d_lo = b; d_up = b;
+    } else if constexpr (FORM == 3) {
+      p = b;
+      d_lo = fmaxf(__fsub_rn(p, a), 0.f);
+      d_up = fmaxf(__fsub_rn(c, p), 0.f);
     } else {
       p = a; d_lo = sqrtf(b); d_up = d_lo;                    // correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt; NOT __fsqrt_rn, which maps to the 1-ulp native instruction)
     }
@@ -313,7 +319,7 @@ extern "C" int im2im_rcps_loss_table(const float* out3, const float* label, int6
                                      int32_t* counts, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(out3 && label && lam && hist_ws && table);
-  IM2IM_REQUIRE(form >= 0 && form <= 2);
+  IM2IM_REQUIRE(form >= 0 && form <= 3);
   IM2IM_REQUIRE(N >= 0 && P > 0 && L >= 1 && L <= MAX_L);
   IM2IM_REQUIRE(P < (1 << 24));                               // fp32(count) exact, as in the reference's fp32 mean
   if (N == 0) return IM2IM_OK;
@@ -323,7 +329,8 @@ extern "C" int im2im_rcps_loss_table(const float* out3, const float* label, int6
   const bool vec = (P & 3) == 0;
   if (form == 0) launch_hist<0>(vec, grid, smem, stream, out3, label, N, P, lam, (int)L, hist_ws, (int)maxseg);
   else if (form == 1) launch_hist<1>(vec, grid, smem, stream, out3, label, N, P, lam, (int)L, hist_ws, (int)maxseg);
-  else launch_hist<2>(vec, grid, smem, stream, out3, label, N, P, lam, (int)L, hist_ws, (int)maxseg);
+  else if (form == 2) launch_hist<2>(vec, grid, smem, stream, out3, label, N, P, lam, (int)L, hist_ws, (int)maxseg);
+  else launch_hist<3>(vec, grid, smem, stream, out3, label, N, P, lam, (int)L, hist_ws, (int)maxseg);
   if (int rc = im2im::check_launch("rcps_hist_kernel")) return rc;
   hipLaunchKernelGGL(rcps_suffix_kernel, dim3((unsigned)N), dim3(256), sizeof(int) * (size_t)(L + 1 + 256), stream, hist_ws, (int)maxseg,
                      units_per_img, per, N * units_per_img, (int)L, (float)P, table, counts);
@@ -341,7 +348,7 @@ extern "C" int im2im_rcps_miscoverage(const float* out3, const float* label, int
                                       float lam, int32_t form, int32_t* map, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(out3 && label && map);
-  IM2IM_REQUIRE(form >= 0 && form <= 2);
+  IM2IM_REQUIRE(form >= 0 && form <= 3);
   IM2IM_REQUIRE(N >= 0 && C >= 1 && C <= 65535 && HW > 0);
   IM2IM_HIP(hipMemsetAsync(map, 0, sizeof(int32_t) * (size_t)C * HW, stream));
   if (N == 0) return IM2IM_OK;
@@ -353,7 +360,8 @@ extern "C" int im2im_rcps_miscoverage(const float* out3, const float* label, int
   const dim3 mgrid((unsigned)bx, (unsigned)C, (unsigned)nz);
   if (form == 0) hipLaunchKernelGGL(rcps_miscoverage_kernel<0>, mgrid, dim3(256), 0, stream, out3, label, N, (int)C, HW, lam, map);
   else if (form == 1) hipLaunchKernelGGL(rcps_miscoverage_kernel<1>, mgrid, dim3(256), 0, stream, out3, label, N, (int)C, HW, lam, map);
-  else hipLaunchKernelGGL(rcps_miscoverage_kernel<2>, mgrid, dim3(256), 0, stream, out3, label, N, (int)C, HW, lam, map);
+  else if (form == 2) hipLaunchKernelGGL(rcps_miscoverage_kernel<2>, mgrid, dim3(256), 0, stream, out3, label, N, (int)C, HW, lam, map);
+  else hipLaunchKernelGGL(rcps_miscoverage_kernel<3>, mgrid, dim3(256), 0, stream, out3, label, N, (int)C, HW, lam, map);
   return im2im::check_launch("rcps_miscoverage_kernel");
 }
 
@@ -361,12 +369,13 @@ extern "C" int im2im_nested_sets(float* out3, int64_t N, int64_t P, float lam, i
                                  float* upper_edge, int32_t clamp_inplace, int32_t floor, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(out3 && lower_edge && upper_edge && N >= 0 && P > 0);
-  IM2IM_REQUIRE(form >= 0 && form <= 2);
+  IM2IM_REQUIRE(form >= 0 && form <= 3);
   if (N == 0) return IM2IM_OK;
   int64_t blocks = im2im::cdiv(N * P, 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (form == 0) hipLaunchKernelGGL(nested_sets_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, out3, N, P, lam, lower_edge, upper_edge, (int)clamp_inplace, (int)floor);
   else if (form == 1) hipLaunchKernelGGL(nested_sets_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, out3, N, P, lam, lower_edge, upper_edge, 0, (int)floor);
-  else hipLaunchKernelGGL(nested_sets_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, out3, N, P, lam, lower_edge, upper_edge, 0, (int)floor);
+  else if (form == 2) hipLaunchKernelGGL(nested_sets_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, out3, N, P, lam, lower_edge, upper_edge, 0, (int)floor);
+  else hipLaunchKernelGGL(nested_sets_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, stream, out3, N, P, lam, lower_edge, upper_edge, 0, (int)floor);
   return im2im::check_launch("nested_sets_kernel");
 }

@@ -13,8 +13,8 @@ from ._lib import check, dptr, lib, require_gpu, stream_ptr
 F32 = torch.float32
 
 # how a final layer's output planes become the nested set (include/im2im_uq.h IM2IM_SETS_*)
-SETS_QUANTILE, SETS_SCALE, SETS_SQRT = 0, 1, 2
-_FORM_PLANES = {SETS_QUANTILE: 3, SETS_SCALE: 2, SETS_SQRT: 2}
+SETS_QUANTILE, SETS_SCALE, SETS_SQRT, SETS_SOFTMAX = 0, 1, 2, 3
+_FORM_PLANES = {SETS_QUANTILE: 3, SETS_SCALE: 2, SETS_SQRT: 2, SETS_SOFTMAX: 3}
 
 
 def _check_form(outputs, form):
@@ -102,7 +102,7 @@ def nested_sets(output: torch.Tensor, lam: float, clamp_inplace: bool = True, fo
     with torch.cuda.device(output.device):
         check(lib.im2im_nested_sets(dptr(output), n, p, float(lam), int(form), dptr(lower), dptr(upper), int(clamp_inplace),
                                     int(floor), stream_ptr(output.device)), "im2im_nested_sets")
-    return lower, output[:, 1 if form == SETS_QUANTILE else 0], upper
+    return lower, output[:, 1 if form in (SETS_QUANTILE, SETS_SOFTMAX) else 0], upper
 
 
 def fraction_missed(lower: torch.Tensor, upper: torch.Tensor, label: torch.Tensor) -> torch.Tensor:

@@ -641,6 +641,92 @@ class Heads(torch.autograd.Function):
         return (dfeat, None, None) + tuple(grads)
 
 
+class SoftmaxHead(torch.autograd.Function):
+    """SoftmaxLayer's 3x3 conv to num_softmax class logits (softmax_layer.py:11-14) on the MFMA conv kernel: the class
+    axis is zero-padded to a multiple of 32 channels and the result stays NHWC [B,H,W,S] in the compute dtype (the
+    [B,K,1,H,W] tensor the reference returns is a strided view of it, made by the caller)."""
+
+    @staticmethod
+    def forward(ctx, feat, cdt, weight, bias):
+        x = nhwc(feat.detach(), cdt)
+        k, cmid = weight.shape[0], weight.shape[1]
+        s_ch = (k + 31) // 32 * 32
+        wpad = torch.zeros((s_ch, cmid, 3, 3), dtype=F32, device=x.device)
+        wpad[:k] = weight.detach()
+        bpad = torch.zeros((s_ch,), dtype=F32, device=x.device)
+        bpad[:k] = bias.detach()
+        wf, wd = pack_weight(wpad, cdt)
+        y = conv_fwd(x, wf, bpad)
+        ctx.save_for_backward(x, wd)
+        ctx.k = k
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wd = ctx.saved_tensors
+        k = ctx.k
+        dy = dy.contiguous()
+        dfeat = nchw(conv_fwd(dy, wd)) if ctx.needs_input_grad[0] else None
+        dw = conv_wgrad(x, dy, 9).view(dy.shape[3], x.shape[3], 3, 3)[:k]
+        db = colsum(dy)[:k]
+        return dfeat, None, dw, db
+
+
+def logits_nhwc(pred):
+    """(NHWC class-padded logits [B,H,W,S], K) of a softmax-layer output [B,K,1,H,W]: zero-copy when `pred` is this
+    package's own SoftmaxLayer output, else one padded copy (plumbing for user-supplied tensors)."""
+    base = getattr(pred, "_im2im_nhwc", None)
+    k = pred.shape[1]
+    if base is not None:
+        return base, k
+    if pred.dim() != 5 or pred.shape[2] != 1:
+        raise ValueError(f"softmax layer output must be [B,K,1,H,W], got {tuple(pred.shape)}")
+    b, _, _, h, w_ = pred.shape
+    s_ch = (k + 7) // 8 * 8
+    dt = pred.dtype if pred.dtype in (F32, BF16) else F32
+    buf = torch.zeros((b, h, w_, s_ch), dtype=dt, device=pred.device)
+    buf[..., :k] = pred[:, :, 0].permute(0, 2, 3, 1)
+    return buf, k
+
+
+class SoftmaxCE(torch.autograd.Function):
+    """softmax_loss_fn (softmax_layer.py:15-25): cross entropy of the class logits against the bucketised target, mean
+    over pixels; one reduction kernel forward, one elementwise kernel backward (gradient in the logits' NHWC layout)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, k, bounds):
+        dev = logits.device
+        m = logits.numel() // logits.shape[-1]
+        loss = torch.empty((), dtype=F32, device=dev)
+        ws = _Scratch.get(lib.im2im_quantile_loss_workspace_bytes(), dev)
+        check(lib.im2im_softmax_ce_fwd(dptr(logits), dptr(target), dptr(bounds), m, k, logits.shape[-1], _DT[logits.dtype],
+                                       dptr(loss), dptr(ws), stream_ptr(dev)), "im2im_softmax_ce_fwd")
+        ctx.save_for_backward(logits, target, bounds)
+        ctx.k = k
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, target, bounds = ctx.saved_tensors
+        m = logits.numel() // logits.shape[-1]
+        gout = gout.to(F32).contiguous()
+        d = torch.empty_like(logits)
+        check(lib.im2im_softmax_ce_bwd(dptr(logits), dptr(target), dptr(bounds), m, ctx.k, logits.shape[-1], _DT[logits.dtype],
+                                       dptr(gout), dptr(d), stream_ptr(logits.device)), "im2im_softmax_ce_bwd")
+        return d, None, None, None
+
+
+def softmax_sets_summary(pred):
+    """[B,K,1,H,W] class logits -> [B,3,1,H,W] fp32 planes (lower quantile, prediction, upper quantile): the
+    lambda-independent part of softmax_nested_sets_from_output (softmax_layer.py:33-47)."""
+    logits, k = logits_nhwc(pred.detach())
+    b, h, w_, s_ch = logits.shape
+    out = torch.empty((b, 3, 1, h, w_), dtype=F32, device=logits.device)
+    check(lib.im2im_softmax_sets_summary(dptr(logits), b, h * w_, k, s_ch, _DT[logits.dtype], dptr(out), stream_ptr(logits.device)),
+          "im2im_softmax_sets_summary")
+    return out
+
+
 LOSS_QUANTILE, LOSS_QUANTILE_L1, LOSS_GAUSSIAN, LOSS_RESIDUAL, LOSS_RESIDUAL_L1 = 0, 1, 2, 3, 4
 
 

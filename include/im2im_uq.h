@@ -52,6 +52,9 @@ const char* im2im_last_error(void);
  *                                                     residual_magnitude(_l1)_layer.py:27-36
  *                            IM2IM_SETS_SQRT (2)      K = 2 (mean, variance): mean -+ lam * sqrt(variance),
  *                                                     gaussian_layer.py:25-34
+ *                            IM2IM_SETS_SOFTMAX (3)   K = 3 (lower quantile, prediction, upper quantile) as written by
+ *                                                     im2im_softmax_sets_summary: pred - lam*relu(pred - lq),
+ *                                                     pred + lam*relu(uq - pred), softmax_layer.py:50-51
  *                            all followed by ModelWithUncertainty's +-1e-6 floor (add_uncertainty.py:35-36)
  *   label   [N][P]    fp32
  *   lam     [L]       fp32   device; ascending grid of the lambdas the edges are evaluated at
@@ -66,6 +69,7 @@ int64_t im2im_rcps_workspace_bytes(int64_t N, int64_t P, int32_t L);
 #define IM2IM_SETS_QUANTILE 0
 #define IM2IM_SETS_SCALE 1
 #define IM2IM_SETS_SQRT 2
+#define IM2IM_SETS_SOFTMAX 3
 int im2im_rcps_loss_table(const float* out3, const float* label, int64_t N, int64_t P,
                           const float* lam, int32_t L, int32_t form, int32_t* hist_ws, float* table,
                           int32_t* counts, im2im_stream_t stream);
@@ -145,7 +149,7 @@ int im2im_conv_fwd_split(const void* x, const float* in_scale_shift, const void*
                          int32_t taps, int32_t relu, int32_t dtype, im2im_stream_t stream);
 
 /* dw[co][ci][tap] (fp32, torch layout) = sum_{b,h,w} dz[b,h,w,co] * x[b,h+kh-1,w+kw-1,ci]
- *   Ci % 64 == 0, Co % 32 == 0.  workspace: im2im_conv_wgrad_workspace_bytes(...) bytes (split-K slabs,
+ *   Ci % 32 == 0, Co % 32 == 0.  workspace: im2im_conv_wgrad_workspace_bytes(...) bytes (split-K slabs,
  *   reduced deterministically). */
 int64_t im2im_conv_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t taps);
 int im2im_conv_wgrad(const void* x, const float* x_scale_shift, const void* dz, float* dw, void* workspace,
@@ -287,6 +291,22 @@ int im2im_uq_loss_bwd(int32_t kind, const float* a, const float* b, const float*
                       int64_t P, int64_t img_stride, float q_lo, float q_hi, float w0, float w1, float w2,
                       const float* grad_out, float* d_a, float* d_b, float* d_c, int64_t d_stride,
                       im2im_stream_t stream);
+
+/* Softmax final layer (finallayers/softmax_layer.py, n_channels_out = 1): logits [M = B*H*W][stride] in `dtype`, NHWC
+ * pixels x class channels padded to `stride` (a multiple of 8, <= 64), the first K (= num_softmax <= 64) valid.
+ *   im2im_softmax_ce_fwd/bwd: softmax_loss_fn (:15-25) = nn.CrossEntropyLoss (mean over pixels) against
+ *     torch.bucketize(target, bounds, right=False) folded to K-1; bounds [K] fp32 on the device (the caller passes
+ *     torch.linspace(0, 1, K) so class edges are torch's).  bwd writes d(logits) [M][stride] in `dtype` (padding = 0),
+ *     scaled by the device scalar *grad_out.  ws: im2im_quantile_loss_workspace_bytes().
+ *   im2im_softmax_sets_summary: the lambda-independent part of softmax_nested_sets_from_output (:33-47): softmax,
+ *     cumulative sum, lower/upper quantile bins at 0.05/0.95, argmax prediction, collapse guards, [0,1] clamp ->
+ *     out3 [N][3][P] fp32 planes (lq, pred, uq), the input of the calibration kernels with form IM2IM_SETS_SOFTMAX. */
+int im2im_softmax_ce_fwd(const void* logits, const float* target, const float* bounds, int64_t M, int32_t K,
+                         int32_t stride, int32_t dtype, float* loss, void* ws, im2im_stream_t stream);
+int im2im_softmax_ce_bwd(const void* logits, const float* target, const float* bounds, int64_t M, int32_t K,
+                         int32_t stride, int32_t dtype, const float* grad_out, void* dlogits, im2im_stream_t stream);
+int im2im_softmax_sets_summary(const void* logits, int64_t N, int64_t P, int32_t K, int32_t stride, int32_t dtype,
+                               float* out3, im2im_stream_t stream);
 
 /* Multi-tensor Adam: optim.Adam(net.parameters(), lr) at core/scripts/train.py:120 with torch
  * defaults (betas, eps, no weight decay, no amsgrad).  Host arrays of n_tensors device pointers / sizes;

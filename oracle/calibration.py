@@ -42,9 +42,25 @@ def hb_mu_plus(muhat, n, delta, maxiters=1000):
 
 
 # ------------------------------------------------------- nested sets / loss
-def lambda_grid(cfg):
-    """calibrate_model.py:100 / eval.py:95 (non-softmax branch): fp32 linspace."""
+def lambda_grid(cfg, utype="quantiles"):
+    """calibrate_model.py:97-100 / eval.py:92-95: fp32 linspace (softmax has its own lambda range keys)."""
+    if utype == "softmax":
+        return torch.linspace(cfg["minimum_lambda_softmax"], cfg["maximum_lambda_softmax"], cfg["num_lambdas"])
     return torch.linspace(cfg["minimum_lambda"], cfg["maximum_lambda"], cfg["num_lambdas"])
+
+
+def softmax_summary(output):
+    """lambda-independent part of softmax_nested_sets_from_output (softmax_layer.py:33-47): [b,K,C,H,W] class logits ->
+    (lower quantile, prediction, upper quantile), each [b,C,H,W]."""
+    prob = output.softmax(dim=1)
+    k = prob.shape[1]
+    cum = torch.cumsum(prob, dim=1)
+    lq = (cum <= 0.05).float().sum(dim=1) / k
+    uq = (cum <= 0.95).float().sum(dim=1) / k
+    pred = torch.argmax(prob, dim=1) / k
+    lq = torch.where(pred == lq, lq - 1 / k, lq)
+    uq = torch.where(pred == uq, uq + 1 / k, uq)
+    return lq.clamp(min=0, max=1), pred, uq.clamp(min=0, max=1)
 
 
 def raw_nested_sets(output, lam, utype="quantiles"):
@@ -53,6 +69,9 @@ def raw_nested_sets(output, lam, utype="quantiles"):
     gaussian: gaussian_layer.py:31-32 (mean -+ lam*sqrt(var));  residual_magnitude(_l1):
     residual_magnitude_layer.py:33-34 (pred -+ lam*magnitude).  ``output`` is NOT mutated here (the reference's
     quantile layers clamp in place; the clamp is idempotent)."""
+    if utype == "softmax":                                             # softmax_layer.py:50-51
+        lq, pred, uq = softmax_summary(output)
+        return pred - (pred - lq).relu() * lam, pred, pred + (uq - pred).relu() * lam
     if utype in ("quantiles", "quantiles_l1"):
         lo, mid, hi = output[:, 0], output[:, 1], output[:, 2]
         lo = torch.minimum(lo, mid - 1e-6)
@@ -99,7 +118,7 @@ def calibrate_from_outputs(outputs, labels, cfg, utype="quantiles"):
     ``Rhat >= alpha or RhatPlus > alpha`` (Q4), default lhat = last + dlambda - 1e-9.
     Returns (lhat 0-dim fp32 tensor, table [N,L] fp32, trace list of (j, Rhat, RhatPlus))."""
     alpha, delta = cfg["alpha"], cfg["delta"]
-    lambdas = lambda_grid(cfg)
+    lambdas = lambda_grid(cfg, utype)
     dlambda = lambdas[1] - lambdas[0]
     lhat = lambdas[-1] + dlambda - 1e-9
     n = outputs.shape[0]
@@ -140,6 +159,16 @@ def risk_and_miscoverage(outputs, labels, lhat, utype="quantiles"):
     mis = (labels > hi).float() + (labels < lo).float()          # [N,C,H,W]
     spatial = mis.numpy().mean(axis=0).mean(axis=0)              # [H,W]
     return losses, spatial
+
+
+def synth_logits(n, k, h, w, seed=0, sharp=0.5):
+    """class logits [n,k,1,h,w] peaked around a smooth ground truth in [0,1] plus noise, and labels near that truth."""
+    g = torch.Generator().manual_seed(seed)
+    truth = torch.rand((n, 1, 1, h, w), generator=g)
+    centres = torch.linspace(0, 1, k).view(1, k, 1, 1, 1)
+    logits = -sharp * k * (centres - truth).abs() + 0.7 * torch.randn((n, k, 1, h, w), generator=g)
+    y = (truth[:, 0] + 0.06 * torch.randn((n, 1, h, w), generator=g)).clamp(0, 1)
+    return logits.contiguous(), y.contiguous()
 
 
 def synth_outputs_two_plane(n, c, h, w, seed=0, width=0.05, utype="gaussian"):

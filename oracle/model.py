@@ -36,6 +36,8 @@ def unet_blocks(n_in: int) -> List[Tuple[str, int, int, int]]:
     ]
 
 
+NUM_SOFTMAX = 50     # experiments/fastmri_test/config.yml num_softmax
+
 # head names per uncertainty type, in the reference's registration (= state_dict) order
 HEADS = {
     "quantiles": ("lower", "prediction", "upper"),                    # quantile_layer.py:15-17
@@ -62,6 +64,10 @@ def state_spec(n_in: int = 1, n_out: int = 1, n_mid: int = 32, utype: str = "qua
             spec.append((f"{p}.{idx + 1}.num_batches_tracked", ()))
     spec.append(("baseModel.out.conv.weight", (n_mid, 64, 1, 1)))
     spec.append(("baseModel.out.conv.bias", (n_mid,)))
+    if utype == "softmax":                                             # softmax_layer.py:11 (one conv to num_softmax classes)
+        spec.append(("last_layer.output_layers.0.weight", (NUM_SOFTMAX, n_mid, 3, 3)))
+        spec.append(("last_layer.output_layers.0.bias", (NUM_SOFTMAX,)))
+        return spec
     for head in HEADS[utype]:
         spec.append((f"last_layer.{head}.weight", (n_out, n_mid, 3, 3)))
         spec.append((f"last_layer.{head}.bias", (n_out,)))
@@ -152,6 +158,9 @@ def quantile_heads(feat, state):
 def final_layer(feat, state, utype="quantiles"):
     """the final layers' forward: 3x3 heads stacked on a new dim 1; ReLU on the gaussian variance
     (gaussian_layer.py:15-17), abs on the residual magnitude (residual_magnitude_layer.py:15-17)."""
+    if utype == "softmax":                                             # softmax_layer.py:13-14, n_channels_out = 1
+        return F.conv2d(feat, state["last_layer.output_layers.0.weight"], state["last_layer.output_layers.0.bias"],
+                        padding=1).unsqueeze(2)
     outs = [F.conv2d(feat, state[f"last_layer.{h}.weight"], state[f"last_layer.{h}.bias"], padding=1) for h in HEADS[utype]]
     if utype == "gaussian":
         outs[1] = torch.relu(outs[1])
@@ -204,6 +213,12 @@ def uq_loss(pred, target, params, utype="quantiles"):
         p0, m = pred[:, 0].squeeze(), pred[:, 1].squeeze()
         first = F.mse_loss(p0, t) if utype == "residual_magnitude" else F.l1_loss(p0, t)
         return first + F.mse_loss(m, (t - p0).abs())
+    if utype == "softmax":                                             # softmax_layer.py:15-25
+        k = pred.shape[1]
+        classes = torch.linspace(0, 1, k)
+        idx = torch.bucketize(target, classes, right=False)
+        idx[idx >= k] = k - 1
+        return F.cross_entropy(pred, idx)
     raise NotImplementedError(utype)
 
 

@@ -406,10 +406,61 @@ def g12():
                            cfg["batch_size"]], dtype=np.float64))
 
 
+# ---------------------------------------------------------------- G13 softmax final layer
+def g13():
+    """softmax layer (num_softmax = 50): forward + cross-entropy loss + gradients on a fixed feature map; nested sets of
+    synthetic class logits at several lambdas; calibrate_model + metrics through the Identity trick."""
+    from core.models.add_uncertainty import add_uncertainty as ref_add
+    from core.models.finallayers.softmax_layer import softmax_loss_fn, softmax_nested_sets_from_output
+
+    class Trunk(nn.Module):
+        n_channels_middle, n_channels_out = 32, 1
+
+        def forward(self, x):
+            return x
+
+    params = dict(PARAMS, uncertainty_type="softmax", num_softmax=50, minimum_lambda_softmax=0, maximum_lambda_softmax=2.0)
+    model = ref_add(Trunk(), params)
+    st = om.det_state(1, 1, utype="softmax")
+    model.last_layer.load_state_dict({k[len("last_layer."):]: v for k, v in st.items() if k.startswith("last_layer.")})
+    idx = torch.arange(2 * 32 * 16 * 16, dtype=torch.float64).reshape(2, 32, 16, 16)
+    feat = (0.8 * torch.sin(0.37 * idx) * torch.cos(0.011 * idx + 0.3)).to(torch.float32).requires_grad_(True)
+    y = (0.5 + 0.45 * torch.sin(0.05 * torch.arange(2 * 16 * 16, dtype=torch.float64))).to(torch.float32).reshape(2, 1, 16, 16)
+    y.view(-1)[:3] = torch.tensor([0.0, 1.0, 1.0 / 49])            # exact class edges (bucketize right=False)
+    pred = model(feat)
+    loss = model.loss_fn(pred, y)
+    loss.backward()
+    grads = {"g_" + n.replace(".", "_"): p.grad for n, p in model.last_layer.named_parameters()}
+    lams = torch.tensor([-0.0253, 0.0, 0.25, 0.5, 0.99, 2.0])
+    out, lab = oc.synth_logits(3, 50, 16, 16, seed=3)
+    lows, ups, raw_lows, raw_ups, preds = [], [], [], [], []
+    for lam in lams:
+        lo, mid, hi = model.nested_sets_from_output(out.clone(), lam)
+        lows.append(lo); ups.append(hi); preds.append(mid)
+        rlo, _, rhi = softmax_nested_sets_from_output(model, out.clone(), lam)
+        raw_lows.append(rlo); raw_ups.append(rhi)
+    cfg = dict(params, batch_size=32, num_lambdas=80)
+    cout, cy = oc.synth_logits(96, 50, 16, 16, seed=7)
+    cout = cout.to(torch.float16).to(torch.float32)                # fp16-representable logits: the fixture stores them in 2 bytes
+    ident = ModelWithUncertainty(nn.Identity(), nn.Identity(), softmax_loss_fn, softmax_nested_sets_from_output, cfg)
+    with quiet():
+        ident, table = calibrate_model(ident, TensorDataset(cout.clone(), cy.clone()), cfg)
+    fix_randomness(0)
+    with quiet():
+        losses, sizes, spearman, strat, mse, spatial = get_rcps_metrics_from_outputs(
+            ident, TensorDataset(cout.clone(), cy.clone()), fraction_missed_loss, "cpu")
+    save("g13_softmax", feat=feat, target=y, pred=pred, loss=loss, g_feat=feat.grad, **grads,
+         sets_output=out, lams=lams, lower=torch.stack(lows), upper=torch.stack(ups), prediction=torch.stack(preds),
+         raw_lower=torch.stack(raw_lows), raw_upper=torch.stack(raw_ups),
+         cal_output=cout.to(torch.float16), cal_label=cy, lhat=ident.lhat, table=table, risk=losses, spatial=spatial,
+         cfg=np.array([cfg["alpha"], cfg["delta"], cfg["num_lambdas"], cfg["minimum_lambda_softmax"],
+                       cfg["maximum_lambda_softmax"], cfg["batch_size"]], dtype=np.float64))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
     for name, fn in (("g1_g2", g1_g2), ("g3", g3), ("g4", g4), ("g5", g5), ("g6", g6), ("g7", g7), ("g8", g8),
-                     ("g9_g10", g9_g10), ("g11", g11), ("g12", g12)):
+                     ("g9_g10", g9_g10), ("g11", g11), ("g12", g12), ("g13", g13)):
         if not only or name in only:
             fn()

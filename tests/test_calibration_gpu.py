@@ -175,3 +175,34 @@ def test_two_plane_loss_table_vs_oracle_incl_negative_lambda_and_zero_width(utyp
             table = hip_ops.rcps_loss_table(out.to(DEV), y.to(DEV), grid, form=form).cpu()
             ref = torch.stack([oc.fraction_missed(*oc.nested_sets(out, lam, utype)[::2], y) for lam in grid], dim=1)
             assert np.array_equal(table.numpy(), ref.numpy()), (n, c, h, w, L)
+
+
+def test_g13_softmax_nested_sets_and_calibration():
+    """softmax nested sets (softmax -> running sum -> 5 %/95 % bins -> argmax prediction) and calibration vs the reference.
+    The bin counts are threshold decisions on fp32 running sums of exponentials, which differ in the last bit between any
+    two exp implementations (the reference's own CPU and GPU paths included), so a pixel may land one bin away: at most
+    0.5 % of the pixels may differ, every other value is identical, the loss table moves by at most 2 pixels per image
+    and lhat by at most one grid step."""
+    from im2im_uq_amd.core.calibration.calibrate_model import calibrate_model
+    from im2im_uq_amd.core.models.add_uncertainty import ModelWithUncertainty
+    from im2im_uq_amd.core.models.finallayers.softmax_layer import softmax_loss_fn, softmax_nested_sets_from_output
+    g = load_golden("g13_softmax")
+    v = g["cfg"]
+    cfg = dict(BASE, uncertainty_type="softmax", num_softmax=50, alpha=float(v[0]), delta=float(v[1]), num_lambdas=int(v[2]),
+               minimum_lambda_softmax=float(v[3]), maximum_lambda_softmax=float(v[4]), batch_size=int(v[5]))
+    model = ModelWithUncertainty(nn.Identity(), nn.Identity(), softmax_loss_fn, softmax_nested_sets_from_output, cfg)
+    worst = 0.0
+    for i, lam in enumerate(T(g["lams"])):
+        lo, mid, hi = model.nested_sets_from_output(T(g["sets_output"]).to(DEV), lam)
+        rlo, _, rhi = softmax_nested_sets_from_output(model, T(g["sets_output"]).to(DEV), lam)
+        for got, key in ((lo, "lower"), (hi, "upper"), (mid, "prediction"), (rlo, "raw_lower"), (rhi, "raw_upper")):
+            worst = max(worst, float((got.cpu().numpy() != g[key][i]).mean()))
+    assert worst <= 0.005, worst
+    ds = TensorDataset(T(g["cal_output"].astype(np.float32)), T(g["cal_label"]).clone())
+    model, table = calibrate_model(model, ds, cfg)
+    p = g["cal_label"][0].size
+    assert float(np.abs(table.numpy() - g["table"]).max()) <= 2.0 / p + 1e-7
+    step = (float(v[4]) - float(v[3])) / (int(v[2]) - 1)
+    assert abs(float(model.lhat) - float(g["lhat"])) <= step + 1e-6
+    print("softmax: worst differing-pixel fraction", worst, "table max diff", float(np.abs(table.numpy() - g["table"]).max()),
+          "lhat", float(model.lhat), float(g["lhat"]))

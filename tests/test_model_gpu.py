@@ -471,3 +471,64 @@ def test_other_final_layers_train_and_calibrate_end_to_end_bf16(utype):
                device=DEV, dataset="synthetic", batch_size=4)
     model, table = calibrate_model(model, TensorDataset(x, y), cfg)
     assert table.shape == (4, 40) and bool(torch.isfinite(table).all()) and 0.0 <= float(model.lhat) <= 21.0
+
+
+def test_g13_softmax_layer_forward_loss_gradients():
+    """SoftmaxLayer on the MFMA conv (class axis padded to 64), fused cross entropy forward/backward, fp32 mode, vs the
+    reference (fixture g13): logits 2e-5, loss 1e-5, gradients 2e-4 rel-L2."""
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from oracle import model as om
+    g = load_golden("g13_softmax")
+
+    class Trunk(torch.nn.Module):
+        n_channels_middle, n_channels_out = 32, 1
+
+        def forward(self, x):
+            return x
+
+    model = add_uncertainty(Trunk(), dict(PARAMS, uncertainty_type="softmax", num_softmax=50)).to(DEV)
+    st = om.det_state(1, 1, utype="softmax")
+    model.last_layer.load_state_dict({k[len("last_layer."):]: v for k, v in st.items() if k.startswith("last_layer.")})
+    model.last_layer.compute_dtype = torch.float32
+    feat = torch.from_numpy(g["feat"]).to(DEV).requires_grad_(True)
+    pred = model(feat)
+    assert tuple(pred.shape) == g["pred"].shape
+    np.testing.assert_allclose(pred.detach().float().cpu().numpy(), g["pred"], rtol=2e-5, atol=2e-6)
+    loss = model.loss_fn(pred, torch.from_numpy(g["target"]).to(DEV))
+    loss.backward()
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-5)
+    assert rel_l2(feat.grad.cpu(), torch.from_numpy(g["g_feat"])) < 2e-4
+    conv = model.last_layer.output_layers[0]
+    assert rel_l2(conv.weight.grad.cpu(), torch.from_numpy(g["g_output_layers_0_weight"])) < 2e-4
+    assert rel_l2(conv.bias.grad.cpu(), torch.from_numpy(g["g_output_layers_0_bias"])) < 2e-4
+    # a user tensor with the same values (no NHWC buffer attached) takes the padded-copy path to the same loss
+    loss2 = model.loss_fn(pred.detach().clone(), torch.from_numpy(g["target"]).to(DEV))
+    assert loss2.item() == pytest.approx(loss.item(), rel=1e-6)
+
+
+def test_softmax_train_and_calibrate_end_to_end_bf16():
+    from im2im_uq_amd.core.calibration.calibrate_model import calibrate_model
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from im2im_uq_amd.core.models.trunks.unet import UNet
+    from im2im_uq_amd import nn_ops
+    from oracle import model as om
+    from torch.utils.data import TensorDataset
+    params = dict(PARAMS, uncertainty_type="softmax", num_softmax=50, device=DEV)
+    model = add_uncertainty(UNet(1, 1), params).to(DEV)
+    st = om.det_state(1, 1, utype="softmax")
+    model.load_state_dict(st, strict=False)
+    model.train()
+    x, y = om.det_images(4, 1, 48, 48, salt=2)
+    opt = nn_ops.FusedAdam(model.parameters(), lr=1e-3)
+    loss = model.loss_fn(model(x.to(DEV)), y.to(DEV))
+    ref = om.uq_loss(om.model_forward(x, dict(st), training=True, emulate_bf16=True, utype="softmax"), y, params, "softmax")
+    assert loss.item() == pytest.approx(ref.item(), rel=3e-2)
+    loss.backward()
+    opt.step()
+    assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+    cfg = dict(params, alpha=0.3, delta=0.3, num_lambdas=40, minimum_lambda_softmax=0, maximum_lambda_softmax=30, rcps_loss="fraction_missed",
+               dataset="synthetic", batch_size=4)
+    model, table = calibrate_model(model, TensorDataset(x, y), cfg)
+    assert table.shape == (4, 40) and bool(torch.isfinite(table).all())
+    lo, mid, hi = model.nested_sets((x[:2].to(DEV),))
+    assert lo.shape == (2, 1, 48, 48) and bool((lo <= mid).all()) and bool((mid <= hi).all())

@@ -192,3 +192,34 @@ def test_g12_nested_sets_and_calibration(utype):
     losses, spatial = oc.risk_and_miscoverage(T(g["cal_output"]), T(g["cal_label"]), T(g["lhat"]), utype)
     assert np.array_equal(losses.numpy(), g["risk"])
     np.testing.assert_allclose(spatial, g["spatial"], rtol=1e-6, atol=1e-7)
+
+
+def test_g13_softmax_layer_loss_nested_sets_calibration():
+    """softmax final layer (softmax_layer.py): class logits, cross entropy against the bucketised target, softmax-quantile
+    nested sets and calibration, all vs the reference (same torch-CPU substrate -> exact where integers decide)."""
+    g = load_golden("g13_softmax")
+    st = om.det_state(1, 1, utype="softmax")
+    leaves = {k: v.clone().requires_grad_(True) for k, v in st.items() if k.startswith("last_layer.")}
+    feat = T(g["feat"]).clone().requires_grad_(True)
+    pred = om.final_layer(feat, leaves, "softmax")
+    np.testing.assert_allclose(pred.detach().numpy(), g["pred"], rtol=1e-5, atol=1e-6)
+    loss = om.uq_loss(pred, T(g["target"]), PARAMS, "softmax")
+    loss.backward()
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-6)
+    np.testing.assert_allclose(feat.grad.numpy(), g["g_feat"], rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(leaves["last_layer.output_layers.0.weight"].grad.numpy(), g["g_output_layers_0_weight"], rtol=1e-4, atol=1e-8)
+    out = T(g["sets_output"])
+    for i, lam in enumerate(T(g["lams"])):
+        lo, mid, hi = oc.nested_sets(out, lam, "softmax")
+        assert np.array_equal(lo.numpy(), g["lower"][i]) and np.array_equal(hi.numpy(), g["upper"][i])
+        assert np.array_equal(mid.numpy(), g["prediction"][i])
+        rlo, _, rhi = oc.raw_nested_sets(out, lam, "softmax")
+        assert np.array_equal(rlo.numpy(), g["raw_lower"][i]) and np.array_equal(rhi.numpy(), g["raw_upper"][i])
+    v = g["cfg"]
+    cfg = dict(alpha=float(v[0]), delta=float(v[1]), num_lambdas=int(v[2]), minimum_lambda_softmax=float(v[3]),
+               maximum_lambda_softmax=float(v[4]))
+    cout = T(g["cal_output"].astype(np.float32))
+    lhat, table, _ = oc.calibrate_from_outputs(cout, T(g["cal_label"]), cfg, "softmax")
+    assert np.array_equal(table.numpy(), g["table"]) and float(lhat) == float(g["lhat"])
+    losses, spatial = oc.risk_and_miscoverage(cout, T(g["cal_label"]), T(g["lhat"]), "softmax")
+    assert np.array_equal(losses.numpy(), g["risk"])
