@@ -8,7 +8,8 @@ buffer `lhat`, attributes baseModel / last_layer / params.  state_dict keys are 
 Scope of this build (SURVEY section 8 + 8f rank 1): "quantiles", "quantiles_l1", "gaussian", "residual_magnitude" and
 "residual_magnitude_l1" run on the HIP kernels (same trunk, heads and calibration kernels; only the head count, the
 fused loss and the nested-set formula differ), "softmax" too (MFMA conv to the class logits, fused cross entropy, a
-softmax-quantile summary kernel feeding the same calibration kernels); "inn" raises NotImplementedError naming itself.
+softmax-quantile summary kernel feeding the same calibration kernels) and "inn" (quantile heads, interval loss): all
+seven types of the reference's factory (:51-87).
 """
 import torch
 import torch.nn as nn
@@ -26,6 +27,7 @@ from .finallayers.residual_magnitude_layer import (ResidualMagnitudeLayer, resid
 from .finallayers.residual_magnitude_l1_layer import (ResidualMagnitudeL1Layer, residual_magnitude_l1_loss_fn,
                                                       residual_magnitude_l1_nested_sets_from_output)
 from .finallayers.softmax_layer import SoftmaxLayer, softmax_loss_fn, softmax_nested_sets_from_output
+from .finallayers.inn_layer import INNLayer, inn_loss_fn, inn_nested_sets_from_output
 
 
 def sets_form(model):
@@ -80,7 +82,7 @@ class ModelWithUncertainty(nn.Module):
         self.lhat = lhat
 
 
-_OUT_OF_SCOPE = ("inn",)
+_OUT_OF_SCOPE = ()
 
 
 def add_uncertainty(model, params):
@@ -108,6 +110,10 @@ def add_uncertainty(model, params):
         last_layer = SoftmaxLayer(model.n_channels_middle, model.n_channels_out, params)
         train_loss_fn = softmax_loss_fn
         nested_sets_from_output_fn = softmax_nested_sets_from_output
+    elif params["uncertainty_type"] == "inn":
+        last_layer = INNLayer(model.n_channels_middle, model.n_channels_out, params)
+        train_loss_fn = inn_loss_fn
+        nested_sets_from_output_fn = inn_nested_sets_from_output
     elif params["uncertainty_type"] in _OUT_OF_SCOPE:
         raise NotImplementedError(
             f"uncertainty_type={params['uncertainty_type']!r} is outside this build's scope (SURVEY.md section 8f): "

@@ -703,6 +703,13 @@ __device__ __forceinline__ void loss_terms(const LossArgs& a, int64_t n, int64_t
       t[0] = 0.5f * (logf(v) + e * e / v);
       break;
     }
+    case IM2IM_LOSS_INN: {                                                  // a = lower, b = prediction, c = upper; beta = q_lo
+      const float vc = a.hi[n * a.img_stride + p];
+      const float em = vb - y, over = fmaxf(y - vc, 0.f), under = fmaxf(va - y, 0.f);
+      t[0] = em * em;
+      t[1] = over * over + under * under + a.q_lo * fabsf(vc - va);
+      break;
+    }
     default: {                                                              // RESIDUAL, RESIDUAL_L1
       const float e = va - y, r = vb - fabsf(y - va);
       t[0] = a.kind == IM2IM_LOSS_RESIDUAL ? e * e : fabsf(e);
@@ -756,6 +763,14 @@ __global__ __launch_bounds__(256) void qloss_bwd_kernel(LossArgs a, const float*
         ga = w_lo * (el < 0.f ? -a.q_lo : (el > 0.f ? 1.f - a.q_lo : 0.f));
         gc = w_hi * (eh < 0.f ? -a.q_hi : (eh > 0.f ? 1.f - a.q_hi : 0.f));
         gb = w_mse * (a.kind == IM2IM_LOSS_QUANTILE ? 2.f * em : sign0(em));
+        break;
+      }
+      case IM2IM_LOSS_INN: {
+        const float vc = a.hi[n * a.img_stride + p];
+        const float s = sign0(vc - va);
+        ga = w_hi * (2.f * fmaxf(va - y, 0.f) - a.q_lo * s);
+        gc = w_hi * (-2.f * fmaxf(y - vc, 0.f) + a.q_lo * s);
+        gb = w_lo * (2.f * (vb - y));
         break;
       }
       case IM2IM_LOSS_GAUSSIAN: {
@@ -1168,9 +1183,9 @@ extern "C" int im2im_uq_loss_fwd(int32_t kind, const float* pa, const float* pb,
                                  int64_t P, int64_t img_stride, float q_lo, float q_hi, float w0, float w1, float w2,
                                  float* loss, void* ws, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  IM2IM_REQUIRE(kind >= IM2IM_LOSS_QUANTILE && kind <= IM2IM_LOSS_RESIDUAL_L1);
+  IM2IM_REQUIRE(kind >= IM2IM_LOSS_QUANTILE && kind <= IM2IM_LOSS_INN);
   IM2IM_REQUIRE(pa && pb && target && loss && ws && N > 0 && P > 0);
-  IM2IM_REQUIRE(kind > IM2IM_LOSS_QUANTILE_L1 || pc != nullptr);
+  IM2IM_REQUIRE((kind > IM2IM_LOSS_QUANTILE_L1 && kind != IM2IM_LOSS_INN) || pc != nullptr);
   LossArgs a{pa, pb, pc, target, N, P, img_stride, q_lo, q_hi, kind};
   float* partial = (float*)ws;
   double* tmp = (double*)((char*)ws + 1024 * 3 * sizeof(float));
@@ -1190,9 +1205,9 @@ extern "C" int im2im_uq_loss_bwd(int32_t kind, const float* pa, const float* pb,
                                  const float* grad_out, float* d_a, float* d_b, float* d_c, int64_t d_stride,
                                  im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  IM2IM_REQUIRE(kind >= IM2IM_LOSS_QUANTILE && kind <= IM2IM_LOSS_RESIDUAL_L1);
+  IM2IM_REQUIRE(kind >= IM2IM_LOSS_QUANTILE && kind <= IM2IM_LOSS_INN);
   IM2IM_REQUIRE(pa && pb && target && grad_out && N > 0 && P > 0);
-  IM2IM_REQUIRE(kind > IM2IM_LOSS_QUANTILE_L1 || pc != nullptr);
+  IM2IM_REQUIRE((kind > IM2IM_LOSS_QUANTILE_L1 && kind != IM2IM_LOSS_INN) || pc != nullptr);
   LossArgs a{pa, pb, pc, target, N, P, img_stride, q_lo, q_hi, kind};
   hipLaunchKernelGGL(qloss_bwd_kernel, dim3(ew_blocks(N * P)), dim3(256), 0, stream, a, grad_out, w0, w1, w2, d_a, d_b, d_c, d_stride);
   return check_launch("qloss_bwd_kernel");

@@ -727,7 +727,7 @@ def softmax_sets_summary(pred):
     return out
 
 
-LOSS_QUANTILE, LOSS_QUANTILE_L1, LOSS_GAUSSIAN, LOSS_RESIDUAL, LOSS_RESIDUAL_L1 = 0, 1, 2, 3, 4
+LOSS_QUANTILE, LOSS_QUANTILE_L1, LOSS_GAUSSIAN, LOSS_RESIDUAL, LOSS_RESIDUAL_L1, LOSS_INN = 0, 1, 2, 3, 4, 5
 
 
 class UQLossPacked(torch.autograd.Function):

@@ -278,12 +278,15 @@ int im2im_quantile_loss_bwd(const float* lo, const float* mid, const float* hi, 
  *                               v = max(var, eps) with the gradient passed straight to var     gaussian_layer.py:19-23
  *   IM2IM_LOSS_RESIDUAL (3)     MSE(a, y) + MSE(b, |y - a|)                                residual_magnitude_layer.py:19-25
  *   IM2IM_LOSS_RESIDUAL_L1 (4)  L1(a, y) + MSE(b, |y - a|)                              residual_magnitude_l1_layer.py:19-25
+ *   IM2IM_LOSS_INN (5)          MSE(b, y) + mean(relu(y - c)^2 + relu(a - y)^2 + beta*|c - a|), beta passed as q_lo
+ *                                                                                         inn_layer.py:22-28, losses/inn.py:12-21
  * Workspace: im2im_quantile_loss_workspace_bytes(). */
 #define IM2IM_LOSS_QUANTILE 0
 #define IM2IM_LOSS_QUANTILE_L1 1
 #define IM2IM_LOSS_GAUSSIAN 2
 #define IM2IM_LOSS_RESIDUAL 3
 #define IM2IM_LOSS_RESIDUAL_L1 4
+#define IM2IM_LOSS_INN 5
 int im2im_uq_loss_fwd(int32_t kind, const float* a, const float* b, const float* c, const float* target, int64_t N,
                       int64_t P, int64_t img_stride, float q_lo, float q_hi, float w0, float w1, float w2,
                       float* loss, void* ws, im2im_stream_t stream);

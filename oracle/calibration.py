@@ -72,7 +72,7 @@ def raw_nested_sets(output, lam, utype="quantiles"):
     if utype == "softmax":                                             # softmax_layer.py:50-51
         lq, pred, uq = softmax_summary(output)
         return pred - (pred - lq).relu() * lam, pred, pred + (uq - pred).relu() * lam
-    if utype in ("quantiles", "quantiles_l1"):
+    if utype in ("quantiles", "quantiles_l1", "inn"):                  # inn_layer.py:35-38 is the same expression
         lo, mid, hi = output[:, 0], output[:, 1], output[:, 2]
         lo = torch.minimum(lo, mid - 1e-6)
         hi = torch.maximum(hi, mid + 1e-6)

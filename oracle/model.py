@@ -45,6 +45,7 @@ HEADS = {
     "gaussian": ("mean", "variance"),                                 # gaussian_layer.py:12-13
     "residual_magnitude": ("prediction", "residual_magnitude"),       # residual_magnitude_layer.py:12-13
     "residual_magnitude_l1": ("prediction", "residual_magnitude"),    # residual_magnitude_l1_layer.py:12-13
+    "inn": ("lower", "prediction", "upper"),                          # inn_layer.py:14-16
 }
 
 
@@ -213,6 +214,10 @@ def uq_loss(pred, target, params, utype="quantiles"):
         p0, m = pred[:, 0].squeeze(), pred[:, 1].squeeze()
         first = F.mse_loss(p0, t) if utype == "residual_magnitude" else F.l1_loss(p0, t)
         return first + F.mse_loss(m, (t - p0).abs())
+    if utype == "inn":                                                 # inn_layer.py:22-28, losses/inn.py:12-21
+        lo, mid, hi = pred[:, 0].squeeze(), pred[:, 1].squeeze(), pred[:, 2].squeeze()
+        interval = torch.relu(t - hi).square() + torch.relu(lo - t).square() + params["beta"] * torch.abs(hi - lo)
+        return F.mse_loss(mid, t) + interval.mean()
     if utype == "softmax":                                             # softmax_layer.py:15-25
         k = pred.shape[1]
         classes = torch.linspace(0, 1, k)

@@ -348,7 +348,7 @@ def g11():
 
 
 # ---------------------------------------------------------------- G12 the other final layers
-def g12():
+def g12(only_types=()):
     """per uncertainty type: (a) final layer forward + train loss + gradients on a fixed feature map with the
     closed-form weights, (b) ModelWithUncertainty.nested_sets_from_output at several lambdas (with the floor) and the
     layer's own raw edges, (c) calibrate_model + get_rcps_metrics_from_outputs on synthetic outputs."""
@@ -360,8 +360,10 @@ def g12():
         def forward(self, x):
             return x
 
-    for utype in ("quantiles_l1", "gaussian", "residual_magnitude", "residual_magnitude_l1"):
-        params = dict(PARAMS, uncertainty_type=utype)
+    for utype in ("quantiles_l1", "gaussian", "residual_magnitude", "residual_magnitude_l1", "inn"):
+        if only_types and utype not in only_types:
+            continue
+        params = dict(PARAMS, uncertainty_type=utype, beta=0.1)
         model = ref_add(Trunk(), params)
         st = om.det_state(1, 1, utype=utype)
         model.last_layer.load_state_dict({k[len("last_layer."):]: v for k, v in st.items() if k.startswith("last_layer.")})
@@ -374,7 +376,7 @@ def g12():
         grads = {"g_" + n.replace(".", "_"): p.grad for n, p in model.last_layer.named_parameters()}
         # (b) nested sets
         lams = torch.tensor([-0.1224, 0.0, 1e-3, 0.5, 1.0, 2.5, 6.0])
-        if utype == "quantiles_l1":
+        if utype in ("quantiles_l1", "inn"):
             out, lab = oc.synth_outputs(3, 1, 16, 16, seed=3)
         else:
             out, lab = oc.synth_outputs_two_plane(3, 1, 16, 16, seed=3, utype=utype)
@@ -386,7 +388,7 @@ def g12():
             raw_lows.append(rlo); raw_ups.append(rhi)
         # (c) calibration on synthetic outputs through the Identity trick (G7)
         cfg = dict(params, batch_size=32, num_lambdas=80, maximum_lambda=8)
-        if utype == "quantiles_l1":
+        if utype in ("quantiles_l1", "inn"):
             cout, cy = oc.synth_outputs(96, 1, 16, 16, seed=7)
         else:
             cout, cy = oc.synth_outputs_two_plane(96, 1, 16, 16, seed=7, utype=utype)
@@ -464,3 +466,5 @@ if __name__ == "__main__":
                      ("g9_g10", g9_g10), ("g11", g11), ("g12", g12), ("g13", g13)):
         if not only or name in only:
             fn()
+    if "g12_inn" in only:
+        g12(("inn",))

@@ -124,7 +124,7 @@ def test_fraction_missed_and_large_image_properties():
     assert int(mis.sum()) == int(counts[:, 300].sum())
 
 
-UTYPES = ["quantiles_l1", "gaussian", "residual_magnitude", "residual_magnitude_l1"]
+UTYPES = ["quantiles_l1", "gaussian", "residual_magnitude", "residual_magnitude_l1", "inn"]
 
 
 def _family(utype):
@@ -132,7 +132,7 @@ def _family(utype):
     from im2im_uq_amd.core.models.add_uncertainty import ModelWithUncertainty
     mod, prefix = {"quantiles_l1": ("quantile_l1_layer", "quantile_regression_l1"), "gaussian": ("gaussian_layer", "gaussian_regression"),
                    "residual_magnitude": ("residual_magnitude_layer", "residual_magnitude"),
-                   "residual_magnitude_l1": ("residual_magnitude_l1_layer", "residual_magnitude_l1")}[utype]
+                   "residual_magnitude_l1": ("residual_magnitude_l1_layer", "residual_magnitude_l1"), "inn": ("inn_layer", "inn")}[utype]
     m = importlib.import_module("im2im_uq_amd.core.models.finallayers." + mod)
     return ModelWithUncertainty(nn.Identity(), nn.Identity(), getattr(m, prefix + "_loss_fn"),
                                 getattr(m, prefix + "_nested_sets_from_output"), dict(BASE, uncertainty_type=utype))

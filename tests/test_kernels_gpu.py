@@ -362,3 +362,19 @@ def test_fused_adam_matches_torch_adam():
         o_ref.step(); o.step()
     for pr, p in zip(ps_ref, ps):
         np.testing.assert_allclose(p.detach().cpu().numpy(), pr.detach().numpy(), rtol=2e-6, atol=2e-7)
+
+
+def test_inn_loss_class_matches_formula():
+    """losses/inn.py mirror: INNLoss(beta)(lower, upper, target), mean and sum reductions, value and gradients."""
+    from im2im_uq_amd.core.models.losses.inn import INNLoss
+    lo, up, y = rnd(3, 20, 24, seed=1), rnd(3, 20, 24, seed=2) + 0.5, rnd(3, 20, 24, seed=3)
+    for red in ("mean", "sum"):
+        l_d, u_d = lo.to(DEV).requires_grad_(True), up.to(DEV).requires_grad_(True)
+        got = INNLoss(beta=0.2, reduction=red)(l_d, u_d, y.to(DEV))
+        got.backward()
+        l_r, u_r = lo.clone().requires_grad_(True), up.clone().requires_grad_(True)
+        ref = torch.relu(y - u_r).square() + torch.relu(l_r - y).square() + 0.2 * torch.abs(u_r - l_r)
+        ref = ref.sum() if red == "sum" else ref.mean()
+        ref.backward()
+        assert got.item() == pytest.approx(ref.item(), rel=2e-5)
+        assert rel_l2(l_d.grad.cpu(), l_r.grad) < 2e-5 and rel_l2(u_d.grad.cpu(), u_r.grad) < 2e-5

@@ -411,7 +411,7 @@ def test_bf16_centering_reduces_train_mode_rounding_error():
     assert e_on < e_off < 8e-2
 
 
-@pytest.mark.parametrize("utype", ["quantiles_l1", "gaussian", "residual_magnitude", "residual_magnitude_l1"])
+@pytest.mark.parametrize("utype", ["quantiles_l1", "gaussian", "residual_magnitude", "residual_magnitude_l1", "inn"])
 def test_g12_other_final_layers_forward_loss_gradients(utype):
     """heads kernel + activation, fused loss forward and backward of the gaussian / residual-magnitude / quantile-L1 final
     layers vs the reference (fixtures g12): output 1e-5, loss 1e-5, gradients 1e-4 rel-L2 (5e-4 for the gaussian NLL), fp32 feature map."""
@@ -425,7 +425,7 @@ def test_g12_other_final_layers_forward_loss_gradients(utype):
         def forward(self, x):
             return x
 
-    model = add_uncertainty(Trunk(), dict(PARAMS, uncertainty_type=utype)).to(DEV)
+    model = add_uncertainty(Trunk(), dict(PARAMS, uncertainty_type=utype, beta=0.1)).to(DEV)
     st = om.det_state(1, 1, utype=utype)
     model.last_layer.load_state_dict({k[len("last_layer."):]: v for k, v in st.items() if k.startswith("last_layer.")})
     model.last_layer.compute_dtype = torch.float32

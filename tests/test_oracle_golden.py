@@ -8,7 +8,7 @@ from oracle import calibration as oc
 from oracle import model as om
 from conftest import load_golden
 
-PARAMS = dict(q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1)
+PARAMS = dict(q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1, beta=0.1)
 T = torch.from_numpy
 
 
@@ -155,7 +155,7 @@ def test_g10_metrics():
     np.testing.assert_allclose(spatial, g["spatial"], rtol=1e-6, atol=1e-7)
 
 
-UTYPES = ["quantiles_l1", "gaussian", "residual_magnitude", "residual_magnitude_l1"]
+UTYPES = ["quantiles_l1", "gaussian", "residual_magnitude", "residual_magnitude_l1", "inn"]
 
 
 @pytest.mark.parametrize("utype", UTYPES)

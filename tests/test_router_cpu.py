@@ -22,24 +22,22 @@ def test_out_of_scope_heads_raise_named_error():
     import pytest
     from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
     from im2im_uq_amd.core.models.trunks.unet import UNet
-    with pytest.raises(NotImplementedError, match="inn"):
-        add_uncertainty(UNet(1, 1), {"uncertainty_type": "inn"})
     with pytest.raises(NotImplementedError):
         add_uncertainty(UNet(1, 1), {"uncertainty_type": "nope"})
 
 
 def test_final_layer_families_keep_the_reference_state_dict_keys():
-    """the six supported uncertainty types build, and their last_layer parameters carry the reference's names
+    """all seven uncertainty types of the reference factory build, and their last_layer parameters carry the reference's names
     (finallayers/*.py __init__), so reference checkpoints load."""
     from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty, sets_form
     from im2im_uq_amd.core.models.trunks.unet import UNet
-    params = dict(q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1, num_softmax=50)
+    params = dict(q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1, num_softmax=50, beta=0.1)
     m = add_uncertainty(UNet(1, 1), dict(params, uncertainty_type="softmax"))
     assert [k for k in m.state_dict() if k.startswith("last_layer.")] == ["last_layer.output_layers.0.weight", "last_layer.output_layers.0.bias"]
     assert tuple(m.last_layer.output_layers[0].weight.shape) == (50, 32, 3, 3) and sets_form(m) == 3
     expect = {"quantiles": ("lower", "prediction", "upper"), "quantiles_l1": ("lower", "prediction", "upper"),
               "gaussian": ("mean", "variance"), "residual_magnitude": ("prediction", "residual_magnitude"),
-              "residual_magnitude_l1": ("prediction", "residual_magnitude")}
+              "residual_magnitude_l1": ("prediction", "residual_magnitude"), "inn": ("lower", "prediction", "upper")}
     for utype, heads in expect.items():
         m = add_uncertainty(UNet(1, 1), dict(params, uncertainty_type=utype))
         keys = [k for k in m.state_dict() if k.startswith("last_layer.")]
