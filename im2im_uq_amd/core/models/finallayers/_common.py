@@ -49,7 +49,7 @@ class TwoHeadLayer(nn.Module):
         self.compute_dtype = None
 
     def forward(self, x):
-        cdt = self.compute_dtype if self.compute_dtype is not None else nn_ops.get_compute_dtype()
+        cdt = getattr(self, "compute_dtype", None) or nn_ops.get_compute_dtype()
         if x.dtype in (torch.float32, torch.bfloat16) and x.permute(0, 2, 3, 1).is_contiguous():
             cdt = x.dtype                      # consume the trunk's channels-last feature map zero-copy
         a, b = (getattr(self, n) for n in self._names)

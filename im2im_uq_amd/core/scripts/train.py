@@ -18,6 +18,7 @@ from torch.utils.data import DataLoader
 
 from .. import _pkg  # noqa: F401
 from ... import nn_ops
+from ...compat import load_reference_checkpoint
 from ._wandb import wandb
 from .eval import eval_net, get_images
 
@@ -101,7 +102,7 @@ def train_net(net, train_dataset, val_dataset, device, epochs, batch_size, lr, l
         checkpoint_final_path = _ckpt_name(checkpoint_dir, epochs, config)
         if os.path.exists(checkpoint_final_path):
             try:
-                net = torch.load(checkpoint_final_path, weights_only=False)
+                net = load_reference_checkpoint(checkpoint_final_path)      # this package's or the reference's pickle
                 net.eval()
                 print(f"Model loaded from checkpoint {checkpoint_final_path}")
                 return net
@@ -112,7 +113,7 @@ def train_net(net, train_dataset, val_dataset, device, epochs, batch_size, lr, l
             for e in reversed(range(epochs)):
                 checkpoint_intermediate_path = _ckpt_name(checkpoint_dir, e, config)
                 if os.path.exists(checkpoint_intermediate_path):
-                    net = torch.load(checkpoint_intermediate_path, weights_only=False)
+                    net = load_reference_checkpoint(checkpoint_intermediate_path)
                     starting_epoch = e
                     print(f"Starting from epoch {e}.")
                     break

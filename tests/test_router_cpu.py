@@ -43,3 +43,36 @@ def test_final_layer_families_keep_the_reference_state_dict_keys():
         keys = [k for k in m.state_dict() if k.startswith("last_layer.")]
         assert keys == [f"last_layer.{h}.{p}" for h in heads for p in ("weight", "bias")], (utype, keys)
         assert sets_form(m) in (0, 1, 2)
+
+
+def test_reference_whole_module_checkpoint_unpickles_into_the_hip_classes(tmp_path):
+    """train.py:191-192 pickles the whole ModelWithUncertainty; im2im_uq_amd.compat aliases the reference's module paths to
+    this package's mirror while unpickling.  Needs the reference tree to write such a file (build container only)."""
+    import os
+    import subprocess
+    import sys
+    import pytest
+    import torch
+    ref = os.environ.get("IM2IM_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "core")):
+        pytest.skip("reference tree not present (GPU box)")
+    ckpt = str(tmp_path / "CP_epoch1_ref.pth")
+    script = (
+        "import sys, torch; sys.path.insert(0, %r); sys.dont_write_bytecode = True\n"
+        "from core.models.trunks.unet import UNet\n"
+        "from core.models.add_uncertainty import add_uncertainty\n"
+        "torch.manual_seed(3)\n"
+        "p = dict(uncertainty_type='gaussian', q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1)\n"
+        "m = add_uncertainty(UNet(1, 1), p); m.set_lhat(torch.tensor(1.25))\n"
+        "torch.save(m, %r); torch.save(m.state_dict(), %r)\n" % (ref, ckpt, ckpt + ".sd"))
+    subprocess.run([sys.executable, "-c", script], check=True, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    from im2im_uq_amd.compat import load_reference_checkpoint
+    model = load_reference_checkpoint(ckpt)
+    assert type(model).__module__ == "im2im_uq_amd.core.models.add_uncertainty"
+    assert type(model.baseModel).__module__ == "im2im_uq_amd.core.models.trunks.unet"
+    assert type(model.last_layer).__name__ == "GaussianRegressionLayer" and type(model.last_layer).__module__.startswith("im2im_uq_amd.")
+    assert model.in_train_loss_fn.__module__.startswith("im2im_uq_amd.") and float(model.lhat) == 1.25
+    sd = torch.load(ckpt + ".sd")
+    got = model.state_dict()
+    assert list(got.keys()) == list(sd.keys()) and all(torch.equal(got[k], sd[k]) for k in sd)
+    assert "core" not in sys.modules or not getattr(sys.modules["core"], "__name__", "").startswith("im2im_uq_amd")
