@@ -15,7 +15,6 @@ import torch
 import torch.nn as nn
 
 from .. import _pkg  # noqa: F401
-from ... import hip_ops
 from .finallayers.quantile_layer import (QuantileRegressionLayer, quantile_regression_loss_fn,
                                          quantile_regression_nested_sets_from_output)
 from .finallayers.quantile_l1_layer import (QuantileRegressionL1Layer, quantile_regression_l1_loss_fn,

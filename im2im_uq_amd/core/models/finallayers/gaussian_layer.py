@@ -1,6 +1,5 @@
 """Gaussian final layer -- drop-in for the reference's core/models/finallayers/gaussian_layer.py
 (layer :7-17, loss :19-23, nested sets :25-34)."""
-import torch
 
 from .... import hip_ops, nn_ops
 from ._common import TwoHeadLayer, fused_nested_sets, lam_value, packed_loss

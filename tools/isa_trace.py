@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run-length-compressed instruction trace of one kernel from `hipcc -S` output (scheduling inspection aid).
 usage: isa_trace.py file.s <substring of kernel symbol> [first_line last_line]"""
-import re, sys
+import sys
 path, pat = sys.argv[1], sys.argv[2]
 lines = open(path).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and pat in l and ": ; @" in l)
