@@ -107,6 +107,33 @@ __global__ void k_bw(const float4* __restrict__ p, size_t n, float* out) {
   if (acc == 123.456f) out[0] = acc;
 }
 
+// pure-register MFMA throughput: 8 independent accumulators per wave, operands held in registers (random or zero bits),
+// no LDS / global traffic inside the loop -- the ceiling a real kernel's data movement is added on top of.
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
+__global__ __launch_bounds__(256) void k_mfma_peak(const uint4* __restrict__ seed, float* __restrict__ out, int iters) {
+  uint4 sa = seed[threadIdx.x], sb = seed[256 + threadIdx.x];
+  bf16x8_t a0, a1, b0, b1;
+  __builtin_memcpy(&a0, &sa, 16); __builtin_memcpy(&b0, &sb, 16);
+  sa.x ^= 0x5a5a5a5a; sb.y ^= 0x3c3c3c3c;
+  __builtin_memcpy(&a1, &sa, 16); __builtin_memcpy(&b1, &sb, 16);
+  f32x16_t acc[8];
+  for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[3], 0, 0, 0);
+    acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[4], 0, 0, 0);
+    acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[5], 0, 0, 0);
+    acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[6], 0, 0, 0);
+    acc[7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[7], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 12345.678f) out[0] = s;
+}
+
 static void ref_mm(const float* A, const float* B, float* D, int M, int N, int K) {
   for (int i = 0; i < M; i++) for (int j = 0; j < N; j++) {
     float s = 0; for (int k = 0; k < K; k++) s += A[i * K + k] * B[k * N + j];
@@ -194,6 +221,29 @@ int main() {
       hipEventRecord(e1); CK(hipEventSynchronize(e1));
       float ms; hipEventElapsedTime(&ms, e0, e1);
       printf("BW read 2GiB float4: %.3f ms = %.2f TB/s\n", ms, bytes / ms / 1e9);
+    }
+  }
+    {
+    uint4* seed; float* o;
+    CK(hipMalloc(&seed, 512 * sizeof(uint4))); CK(hipMalloc(&o, 4));
+    std::vector<uint32_t> h(2048);
+    for (int mode = 0; mode < 2; ++mode) {
+      for (size_t i = 0; i < h.size(); ++i) {
+        // random bf16 pairs with exponents near 1.0 (finite, no denormals); mode 1 = all zero bits
+        uint32_t r = (uint32_t)(1103515245u * (uint32_t)(i * 2654435761u + 12345u) + 12345u);
+        uint32_t lo = 0x3f00u | (r & 0x00ffu) | ((r >> 1) & 0x8000u), hi = 0x3f00u | ((r >> 8) & 0x00ffu) | ((r >> 9) & 0x8000u);
+        h[i] = mode ? 0u : (lo | (hi << 16));
+      }
+      CK(hipMemcpy(seed, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+      const int iters = 4096, blocks = 256 * 8;                 // 2 workgroups of 4 waves per SIMD-quad -> 2 waves / SIMD
+      hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, 0, seed, o, iters);
+      CK(hipEventRecord(e0));
+      for (int rep = 0; rep < 10; ++rep) hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, 0, seed, o, iters);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+      const double flop = (double)blocks * 4 * iters * 8 * 2.0 * 32 * 32 * 16;
+      printf("MFMA 32x32x16 bf16 register-only, %s operands: %.3f ms = %.0f TFLOP/s\n", mode ? "zero" : "random", ms, flop / ms / 1e9);
     }
   }
   return 0;
