@@ -94,11 +94,18 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # IM2IM_DIST_BACKEND=gloo lets the N > 1 code path be exercised with several ranks sharing ONE GPU (RCCL refuses
+    # duplicate devices); the measured configuration is always nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("IM2IM_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from im2im_uq_amd import hip_ops, nn_ops
     from im2im_uq_amd.core.calibration.calibrate_model import calibrate_model
