@@ -187,6 +187,13 @@ def main():
                     "traffic": None, "launches_per_step": n // 2, "avg_launch_ms": t / n,
                     "algorithmic_gflop_per_launch": f / n / 1e9}
         roof = dict(agg(ig), kernel="conv_igemm_kernel (forward + data-gradient launches, all tile variants)")
+        try:                            # HBM bytes per launch from the committed PMC passes (same batch and size only)
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                rec = json.load(f)["conv_igemm_kernel"]
+            if rec["per_gpu_batch"] == B and rec["hw"] == hw and args.uncertainty_type == "quantiles":
+                roof["traffic"] = rec["traffic_bytes_per_launch"]
+        except Exception:  # noqa: BLE001
+            pass
         roof_w = dict(agg(wg), kernel="conv_wgrad_kernel (+ its split-K reduce)")
 
     # ---------------------------------------------------------------- calibration leg
