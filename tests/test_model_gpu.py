@@ -532,3 +532,26 @@ def test_softmax_train_and_calibrate_end_to_end_bf16():
     assert table.shape == (4, 40) and bool(torch.isfinite(table).all())
     lo, mid, hi = model.nested_sets((x[:2].to(DEV),))
     assert lo.shape == (2, 1, 48, 48) and bool((lo <= mid).all()) and bool((mid <= hi).all())
+
+
+def test_train_step_is_bitwise_reproducible_bf16():
+    """no atomics on floating-point data anywhere in the step (fixed-order two-stage reductions, split-K slabs reduced in
+    order): two runs from the same state give identical loss, gradients and updated weights."""
+    from oracle import model as om
+    from im2im_uq_amd import nn_ops
+    x, y = om.det_images(4, 1, 80, 96, salt=9)
+    runs = []
+    for _ in range(2):
+        model = build(1, "bf16")
+        model.train()
+        opt = nn_ops.FusedAdam(model.parameters(), lr=1e-3)
+        loss = model.loss_fn(model(x.to(DEV)), y.to(DEV))
+        loss.backward()
+        grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        opt.step()
+        runs.append((loss.item(), grads, {n: p.detach().clone() for n, p in model.named_parameters()},
+                     {n: b.clone() for n, b in model.named_buffers() if b is not None}))
+    assert runs[0][0] == runs[1][0]
+    for i in (1, 2, 3):
+        for n in runs[0][i]:
+            assert torch.equal(runs[0][i][n], runs[1][i][n]), (i, n)
