@@ -459,11 +459,46 @@ def g13():
                        cfg["maximum_lambda_softmax"], cfg["batch_size"]], dtype=np.float64))
 
 
+# ---------------------------------------------------------------- G14 UNet blocks at kernel-supported channel counts
+def g14():
+    """G3's blocks again with channel counts the MFMA kernels take (multiples of 32; <= 8 for a first conv), closed-form
+    weights (oracle.model.det_fill keyed by the parameter name, so nothing but inputs and results is stored): forward,
+    input/parameter gradients and running statistics in train mode, forward in eval mode."""
+    parts = {
+        "doubleconv": (DoubleConv(2, 64, 32), [(2, 2, 12, 16)]),
+        "down": (Down(32, 64), [(2, 32, 12, 16)]),
+        "up_bilinear": (Up(128, 64, True), [(2, 64, 6, 8), (2, 64, 12, 16)]),
+        "up_bilinear_pad": (Up(128, 64, True), [(2, 64, 5, 7), (2, 64, 11, 15)]),
+        "outconv": (OutConv(64, 32), [(2, 64, 12, 16)]),
+    }
+    for name, (mod, shapes) in parts.items():
+        mod.load_state_dict({k: om.det_fill("g14." + name + "." + k, tuple(v.shape)) for k, v in mod.state_dict().items()})
+        ins = []
+        for i, shp in enumerate(shapes):
+            n = int(np.prod(shp))
+            idx = torch.arange(n, dtype=torch.float64)
+            ins.append((torch.sin(0.731 * idx * (1 + (idx % 5)) + i) + 0.3 * torch.cos(0.0137 * idx)).to(torch.float32).reshape(shp))
+        init = {k: v.clone() for k, v in mod.state_dict().items()}
+        rec = {}
+        for train in (True, False):
+            mod.load_state_dict(init)
+            mod.zero_grad()
+            r = run_part(mod, ins, train)
+            keep = {k: v for k, v in r.items() if not k.startswith("state_after.") or "running" in k}
+            for k in list(keep):                              # big conv weight gradients: every 5th element + the L2 norm
+                if k.startswith("grad.") and keep[k].dim() == 4 and keep[k].numel() > 20000:
+                    gfull = keep.pop(k)
+                    keep[k + ".every5"] = gfull.reshape(-1)[::5].clone()
+                    keep[k + ".norm"] = gfull.double().norm()
+            rec.update({("train." if train else "eval.") + k: v for k, v in keep.items() if train or k in ("y",) or k.startswith("x")})
+        save("g14_" + name, **rec)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
     for name, fn in (("g1_g2", g1_g2), ("g3", g3), ("g4", g4), ("g5", g5), ("g6", g6), ("g7", g7), ("g8", g8),
-                     ("g9_g10", g9_g10), ("g11", g11), ("g12", g12), ("g13", g13)):
+                     ("g9_g10", g9_g10), ("g11", g11), ("g12", g12), ("g13", g13), ("g14", g14)):
         if not only or name in only:
             fn()
     if "g12_inn" in only:

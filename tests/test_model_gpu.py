@@ -555,3 +555,56 @@ def test_train_step_is_bitwise_reproducible_bf16():
     for i in (1, 2, 3):
         for n in runs[0][i]:
             assert torch.equal(runs[0][i][n], runs[1][i][n]), (i, n)
+
+
+def _g14_block(name):
+    from im2im_uq_amd.core.models.trunks import unet_parts as up
+    return {"doubleconv": lambda: up.DoubleConv(2, 64, 32), "down": lambda: up.Down(32, 64),
+            "up_bilinear": lambda: up.Up(128, 64, True), "up_bilinear_pad": lambda: up.Up(128, 64, True),
+            "outconv": lambda: up.OutConv(64, 32)}[name]()
+
+
+@pytest.mark.parametrize("name", ["doubleconv", "down", "up_bilinear", "up_bilinear_pad", "outconv"])
+def test_g14_unet_blocks_vs_reference_fp32(name):
+    """the public DoubleConv / Down / Up / OutConv modules (fp32 mode) against the REFERENCE's own modules run on the same
+    closed-form weights and inputs (fixtures g14): train-mode forward, input and parameter gradients, running statistics,
+    eval-mode forward."""
+    from oracle import model as om
+    g = load_golden("g14_" + name)
+    mod = _g14_block(name)
+    mod.load_state_dict({k: om.det_fill("g14." + name + "." + k, tuple(v.shape)) for k, v in mod.state_dict().items()})
+    mod = mod.to(DEV)
+    for m in mod.modules():
+        if hasattr(m, "compute_dtype"):
+            m.compute_dtype = torch.float32
+    n_in = 2 if "up_" in name else 1
+    init = {k: v.clone() for k, v in mod.state_dict().items()}
+    # eval forward
+    mod.eval()
+    with torch.no_grad():
+        y = mod(*[torch.from_numpy(g[f"eval.x{i}"]).to(DEV) for i in range(n_in)])
+    np.testing.assert_allclose(y.float().cpu().numpy(), g["eval.y"], rtol=2e-4, atol=2e-5)
+    # train forward + backward
+    mod.load_state_dict(init)
+    mod.train()
+    xs = [torch.from_numpy(g[f"train.x{i}"]).to(DEV).requires_grad_(True) for i in range(n_in)]
+    y = mod(*xs)
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), g["train.y"], rtol=2e-4, atol=5e-5)
+    y.backward(torch.from_numpy(g["train.gy"]).to(DEV))
+    for i, x in enumerate(xs):
+        if name == "doubleconv":                              # a <= 8-channel input is the network input: its gradient is not
+            assert x.grad is None                             # computed (nothing upstream of it trains; SURVEY 8d excludes it too)
+            continue
+        assert rel_l2(x.grad.float().cpu(), torch.from_numpy(g[f"train.gx{i}"])) < 2e-3, f"gx{i}"
+    for k, p in mod.named_parameters():
+        if ".double_conv.0.bias" in k or ".double_conv.3.bias" in k or k in ("double_conv.0.bias", "double_conv.3.bias"):
+            continue                                          # bias in front of train-mode BatchNorm: analytically zero
+        if f"train.grad.{k}" in g:
+            assert rel_l2(p.grad.cpu(), torch.from_numpy(g[f"train.grad.{k}"])) < 2e-3, k
+        else:
+            got = p.grad.cpu().reshape(-1)
+            assert rel_l2(got[::5], torch.from_numpy(g[f"train.grad.{k}.every5"])) < 2e-3, k
+            assert float(got.double().norm()) == pytest.approx(float(g[f"train.grad.{k}.norm"]), rel=2e-3)
+    for k, v in mod.state_dict().items():
+        if "running_mean" in k or "running_var" in k:
+            np.testing.assert_allclose(v.cpu().numpy(), g["train.state_after." + k], rtol=2e-5, atol=2e-6)

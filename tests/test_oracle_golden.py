@@ -223,3 +223,28 @@ def test_g13_softmax_layer_loss_nested_sets_calibration():
     assert np.array_equal(table.numpy(), g["table"]) and float(lhat) == float(g["lhat"])
     losses, spatial = oc.risk_and_miscoverage(cout, T(g["cal_label"]), T(g["lhat"]), "softmax")
     assert np.array_equal(losses.numpy(), g["risk"])
+
+
+@pytest.mark.parametrize("name", ["doubleconv", "down", "up_bilinear", "up_bilinear_pad"])
+def test_g14_blocks_at_kernel_channel_counts(name):
+    """the oracle's blocks against the reference's at the channel counts the GPU tests use (fixtures g14)."""
+    g = load_golden("g14_" + name)
+    prefix = {"doubleconv": "", "down": "maxpool_conv.1.", "up_bilinear": "conv.", "up_bilinear_pad": "conv."}[name]
+    cin, mid, cout = {"doubleconv": (2, 32, 64), "down": (32, 64, 64)}.get(name, (128, 64, 64))
+    st = {}
+    for idx, (ci, co) in ((0, (cin, mid)), (3, (mid, cout))):
+        for leaf, shp in (("weight", (co, ci, 3, 3)), ("bias", (co,))):
+            st[f"baseModel.blk.double_conv.{idx}.{leaf}"] = om.det_fill(f"g14.{name}.{prefix}double_conv.{idx}.{leaf}", shp)
+        for leaf in ("weight", "bias", "running_mean", "running_var"):
+            st[f"baseModel.blk.double_conv.{idx + 1}.{leaf}"] = om.det_fill(f"g14.{name}.{prefix}double_conv.{idx + 1}.{leaf}", (co,))
+        st[f"baseModel.blk.double_conv.{idx + 1}.num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+    for mode in ("eval", "train"):
+        work = {k: v.clone() for k, v in st.items()}
+        x0 = T(g[f"{mode}.x0"])
+        if name == "doubleconv":
+            y = om.double_conv(x0, work, "blk", mode == "train")
+        elif name == "down":
+            y = om.double_conv(torch.nn.functional.max_pool2d(x0, 2), work, "blk", mode == "train")
+        else:
+            y = om.up_block(x0, T(g[f"{mode}.x1"]), work, "blk", mode == "train")
+        np.testing.assert_allclose(y.numpy(), g[f"{mode}.y"], rtol=1e-4, atol=2e-5)
