@@ -308,7 +308,8 @@ class ConvStats(torch.autograd.Function):
             xin = x.detach().to(F32).contiguous()
             _, wd = pack_weight(weight, F32)
             z, stats = smallconv_s2l(xin, wd, bias.detach(), None, co, cdt, flip=True, want_stats=True, center=center)
-            wd = None
+            if not x.requires_grad:
+                wd = None                                  # the network input: no data-gradient needed
         else:
             xin = nhwc(x.detach(), cdt)
             wf, wd = pack_weight(weight, cdt)
@@ -336,6 +337,8 @@ class ConvStats(torch.autograd.Function):
         if ctx.small:
             dw, _ = smallconv_wgrad(xin, dz, l_major=True, want_bias=False)
             dw = dw.view(dz.shape[3], xin.shape[1], 3, 3)
+            if ctx.needs_input_grad[0] and wd.numel():
+                dx = smallconv_l2s(dz, wd, None, xin.shape[1])      # [B,Cin,H,W] fp32: correlation with the flipped taps
         else:
             ci = xin.shape[3] * (2 if xin_hi is not None else 1)
             dw = conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi).view(dz.shape[3], ci, 3, 3)

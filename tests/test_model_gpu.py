@@ -592,9 +592,6 @@ def test_g14_unet_blocks_vs_reference_fp32(name):
     np.testing.assert_allclose(y.detach().float().cpu().numpy(), g["train.y"], rtol=2e-4, atol=5e-5)
     y.backward(torch.from_numpy(g["train.gy"]).to(DEV))
     for i, x in enumerate(xs):
-        if name == "doubleconv":                              # a <= 8-channel input is the network input: its gradient is not
-            assert x.grad is None                             # computed (nothing upstream of it trains; SURVEY 8d excludes it too)
-            continue
         assert rel_l2(x.grad.float().cpu(), torch.from_numpy(g[f"train.gx{i}"])) < 2e-3, f"gx{i}"
     for k, p in mod.named_parameters():
         if ".double_conv.0.bias" in k or ".double_conv.3.bias" in k or k in ("double_conv.0.bias", "double_conv.3.bias"):
