@@ -108,13 +108,23 @@ class Up(nn.Module):
             self.up = _BilinearUp()
             self.conv = DoubleConv(in_channels, out_channels, in_channels // 2)
         else:
-            raise NotImplementedError("bilinear=False (ConvTranspose2d upsampling) is not built yet; router.py and the "
-                                      "experiment configs only ever use the bilinear default (SURVEY D2)")
+            self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)   # parameter container
+            self.conv = DoubleConv(in_channels, out_channels)
+        self.compute_dtype = None
 
     def forward(self, x1, x2, lazy=False):
         # x1: deep feature map, x2: skip connection.  cat([x2, pad(up(x1))]) is not materialised: the first conv reads the
         # skip half in place and the upsampled half from its own tensor (odd widths fall back to one fused
         # upsample + pad + concat kernel).
+        if isinstance(self.up, nn.ConvTranspose2d):
+            # learned upsampling (reference :53): 1x1 MFMA conv to 4*Co channels + depth-to-space, then zero-pad to the skip
+            x1 = nn_ops.ConvTranspose2x2.apply(x1, self.up.weight, self.up.bias, _cdt(self))
+            dy, dx = x2.shape[2] - x1.shape[2], x2.shape[3] - x1.shape[3]
+            if dy or dx:
+                x1 = torch.nn.functional.pad(x1, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+            if nn_ops.SPLIT_CONCAT and x1.shape[1] == x2.shape[1] and x2.shape[1] % 64 == 0:
+                return self.conv(x2, lazy=lazy, x_hi=x1)
+            return self.conv(torch.cat([nn_ops.materialize(x2), x1], dim=1), lazy=lazy)
         if nn_ops.can_split_concat(x1, x2):
             up = nn_ops.Upsample2x.apply(x1, x2.shape[2], x2.shape[3])
             return self.conv(x2, lazy=lazy, x_hi=up)

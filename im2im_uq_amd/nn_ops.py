@@ -538,6 +538,40 @@ class Upsample2x(torch.autograd.Function):
         return nchw(ddeep), None, None
 
 
+class ConvTranspose2x2(torch.autograd.Function):
+    """nn.ConvTranspose2d(Ci, Co, kernel_size=2, stride=2) (Up with bilinear=False, unet_parts.py:53): every input pixel
+    produces a 2x2 output patch and patches do not overlap, so it is ONE 1x1 convolution to 4*Co channels on the MFMA
+    kernel followed by a depth-to-space rearrangement; the backward is the mirror image (space-to-depth, 1x1 data- and
+    weight-gradient).  The input may be a lazy activation."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cdt):
+        ss = lazy_ss(x)
+        xin = nhwc(x.detach(), cdt)
+        b, h, w_, ci = xin.shape
+        co = weight.shape[1]
+        w1 = weight.detach().permute(2, 3, 1, 0).reshape(4 * co, ci, 1, 1)        # row (a, b, co) <- weight[ci, co, a, b]
+        wf, wd = pack_weight(w1, cdt)
+        y4 = conv_fwd(xin, wf, bias.detach().to(F32).repeat(4), in_ss=ss)          # [B,h,w,(a,b,co)]
+        y = y4.view(b, h, w_, 2, 2, co).permute(0, 1, 3, 2, 4, 5).reshape(b, 2 * h, 2 * w_, co)
+        ctx.has_ss = ss is not None
+        ctx.save_for_backward(xin, wd, ss if ss is not None else torch.empty(0))
+        return nchw(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xin, wd, ss = ctx.saved_tensors
+        ss = ss if ctx.has_ss else None
+        b, h, w_, ci = xin.shape
+        dy = nhwc(dy, xin.dtype)
+        co = dy.shape[3]
+        d4 = dy.view(b, h, 2, w_, 2, co).permute(0, 1, 3, 2, 4, 5).reshape(b, h, w_, 4 * co)
+        dx = nchw(conv_fwd(d4, wd)) if ctx.needs_input_grad[0] else None
+        dw = conv_wgrad(xin, d4, 1, x_ss=ss).view(2, 2, co, ci).permute(3, 2, 0, 1).contiguous()
+        db = colsum(dy.contiguous())                           # every output pixel gets the bias once
+        return dx, dw, db, None
+
+
 class Conv1x1(torch.autograd.Function):
     """OutConv (unet_parts.py:87-94): 1x1 conv with bias on the MFMA kernel (taps = 1); input may be lazy."""
 

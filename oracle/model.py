@@ -125,9 +125,13 @@ def double_conv(x, state, prefix, training, emulate_bf16=False):
 
 
 def up_block(x_deep, x_skip, state, prefix, training, emulate_bf16=False):
-    """bilinear x2 (align_corners=True) -> zero-pad to skip -> cat([skip, up]) -> DoubleConv,
-    unet_parts.py:58-69."""
-    u = F.interpolate(x_deep, scale_factor=2, mode="bilinear", align_corners=True)
+    """bilinear x2 (align_corners=True) [or ConvTranspose2d(k=2, s=2) when the state holds `<block>.up.weight`] -> zero-pad
+    to skip -> cat([skip, up]) -> DoubleConv, unet_parts.py:50-69."""
+    if f"baseModel.{prefix[:-len('.conv')] if prefix.endswith('.conv') else prefix}.up.weight" in state:      # bilinear=False, unet_parts.py:53
+        stem = prefix[:-len(".conv")] if prefix.endswith(".conv") else prefix
+        u = F.conv_transpose2d(x_deep, state[f"baseModel.{stem}.up.weight"], state[f"baseModel.{stem}.up.bias"], stride=2)
+    else:
+        u = F.interpolate(x_deep, scale_factor=2, mode="bilinear", align_corners=True)
     dy = x_skip.shape[2] - u.shape[2]
     dx = x_skip.shape[3] - u.shape[3]
     u = F.pad(u, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])

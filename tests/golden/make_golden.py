@@ -460,7 +460,7 @@ def g13():
 
 
 # ---------------------------------------------------------------- G14 UNet blocks at kernel-supported channel counts
-def g14():
+def g14(only_parts=()):
     """G3's blocks again with channel counts the MFMA kernels take (multiples of 32; <= 8 for a first conv), closed-form
     weights (oracle.model.det_fill keyed by the parameter name, so nothing but inputs and results is stored): forward,
     input/parameter gradients and running statistics in train mode, forward in eval mode."""
@@ -470,8 +470,12 @@ def g14():
         "up_bilinear": (Up(128, 64, True), [(2, 64, 6, 8), (2, 64, 12, 16)]),
         "up_bilinear_pad": (Up(128, 64, True), [(2, 64, 5, 7), (2, 64, 11, 15)]),
         "outconv": (OutConv(64, 32), [(2, 64, 12, 16)]),
+        "up_convT": (Up(128, 64, False), [(2, 128, 6, 8), (2, 64, 12, 16)]),
+        "up_convT_pad": (Up(128, 64, False), [(2, 128, 5, 7), (2, 64, 11, 15)]),
     }
     for name, (mod, shapes) in parts.items():
+        if only_parts and name not in only_parts:
+            continue
         mod.load_state_dict({k: om.det_fill("g14." + name + "." + k, tuple(v.shape)) for k, v in mod.state_dict().items()})
         ins = []
         for i, shp in enumerate(shapes):
@@ -503,3 +507,5 @@ if __name__ == "__main__":
             fn()
     if "g12_inn" in only:
         g12(("inn",))
+    if "g14_convT" in only:
+        g14(("up_convT", "up_convT_pad"))

@@ -561,10 +561,11 @@ def _g14_block(name):
     from im2im_uq_amd.core.models.trunks import unet_parts as up
     return {"doubleconv": lambda: up.DoubleConv(2, 64, 32), "down": lambda: up.Down(32, 64),
             "up_bilinear": lambda: up.Up(128, 64, True), "up_bilinear_pad": lambda: up.Up(128, 64, True),
+            "up_convT": lambda: up.Up(128, 64, False), "up_convT_pad": lambda: up.Up(128, 64, False),
             "outconv": lambda: up.OutConv(64, 32)}[name]()
 
 
-@pytest.mark.parametrize("name", ["doubleconv", "down", "up_bilinear", "up_bilinear_pad", "outconv"])
+@pytest.mark.parametrize("name", ["doubleconv", "down", "up_bilinear", "up_bilinear_pad", "up_convT", "up_convT_pad", "outconv"])
 def test_g14_unet_blocks_vs_reference_fp32(name):
     """the public DoubleConv / Down / Up / OutConv modules (fp32 mode) against the REFERENCE's own modules run on the same
     closed-form weights and inputs (fixtures g14): train-mode forward, input and parameter gradients, running statistics,
@@ -605,3 +606,27 @@ def test_g14_unet_blocks_vs_reference_fp32(name):
     for k, v in mod.state_dict().items():
         if "running_mean" in k or "running_var" in k:
             np.testing.assert_allclose(v.cpu().numpy(), g["train.state_after." + k], rtol=2e-5, atol=2e-6)
+
+
+def test_unet_with_learned_upsampling_trains_bf16():
+    """UNet(bilinear=False): ConvTranspose2d upsampling in every Up block (unet.py:18-29 with factor 1) -- one bf16 train
+    step and an eval forward run with finite values and the right shapes (the Up block itself is pinned by fixture g14)."""
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from im2im_uq_amd.core.models.trunks.unet import UNet
+    from im2im_uq_amd import nn_ops
+    from oracle import model as om
+    torch.manual_seed(0)
+    model = add_uncertainty(UNet(1, 1, bilinear=False), dict(PARAMS)).to(DEV)
+    assert tuple(model.baseModel.up1.up.weight.shape) == (1024, 512, 2, 2)
+    x, y = om.det_images(2, 1, 64, 48, salt=1)
+    model.train()
+    opt = nn_ops.FusedAdam(model.parameters(), lr=1e-3)
+    loss = model.loss_fn(model(x.to(DEV)), y.to(DEV))
+    loss.backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for n, p in model.named_parameters()
+               if ".double_conv.0.bias" not in n and ".double_conv.3.bias" not in n)
+    opt.step()
+    model.eval()
+    with torch.no_grad():
+        out = model(x.to(DEV))
+    assert out.shape == (2, 3, 1, 64, 48) and bool(torch.isfinite(out).all())

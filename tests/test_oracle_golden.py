@@ -225,13 +225,16 @@ def test_g13_softmax_layer_loss_nested_sets_calibration():
     assert np.array_equal(losses.numpy(), g["risk"])
 
 
-@pytest.mark.parametrize("name", ["doubleconv", "down", "up_bilinear", "up_bilinear_pad"])
+@pytest.mark.parametrize("name", ["doubleconv", "down", "up_bilinear", "up_bilinear_pad", "up_convT", "up_convT_pad"])
 def test_g14_blocks_at_kernel_channel_counts(name):
     """the oracle's blocks against the reference's at the channel counts the GPU tests use (fixtures g14)."""
     g = load_golden("g14_" + name)
-    prefix = {"doubleconv": "", "down": "maxpool_conv.1.", "up_bilinear": "conv.", "up_bilinear_pad": "conv."}[name]
+    prefix = {"doubleconv": "", "down": "maxpool_conv.1."}.get(name, "conv.")
     cin, mid, cout = {"doubleconv": (2, 32, 64), "down": (32, 64, 64)}.get(name, (128, 64, 64))
     st = {}
+    if "convT" in name:                                       # Up(bilinear=False): ConvTranspose2d(128, 64, 2, 2)
+        st["baseModel.blk.up.weight"] = om.det_fill(f"g14.{name}.up.weight", (128, 64, 2, 2))
+        st["baseModel.blk.up.bias"] = om.det_fill(f"g14.{name}.up.bias", (64,))
     for idx, (ci, co) in ((0, (cin, mid)), (3, (mid, cout))):
         for leaf, shp in (("weight", (co, ci, 3, 3)), ("bias", (co,))):
             st[f"baseModel.blk.double_conv.{idx}.{leaf}"] = om.det_fill(f"g14.{name}.{prefix}double_conv.{idx}.{leaf}", shp)
