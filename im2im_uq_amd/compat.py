@@ -16,7 +16,7 @@ import torch
 
 _MIRRORED = (
     "core", "core.models", "core.models.add_uncertainty", "core.models.trunks", "core.models.trunks.unet",
-    "core.models.trunks.unet_parts", "core.models.finallayers", "core.models.finallayers.quantile_layer",
+    "core.models.trunks.unet_parts", "core.models.trunks.wnet", "core.models.finallayers", "core.models.finallayers.quantile_layer",
     "core.models.finallayers.quantile_l1_layer", "core.models.finallayers.gaussian_layer",
     "core.models.finallayers.residual_magnitude_layer", "core.models.finallayers.residual_magnitude_l1_layer",
     "core.models.finallayers.softmax_layer", "core.models.finallayers.inn_layer", "core.models.losses",

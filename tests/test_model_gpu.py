@@ -630,3 +630,29 @@ def test_unet_with_learned_upsampling_trains_bf16():
     with torch.no_grad():
         out = model(x.to(DEV))
     assert out.shape == (2, 3, 1, 64, 48) and bool(torch.isfinite(out).all())
+
+
+def test_wnet_trunk_trains_bf16():
+    """WNet (two half-width encoders, wnet.py:9-59) with the quantile layer: one bf16 train step and an eval forward."""
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from im2im_uq_amd.core.models.trunks.wnet import WNet
+    from im2im_uq_amd import nn_ops
+    from oracle import model as om
+    torch.manual_seed(0)
+    # each path's first conv takes n_channels_in channels but is fed ONE input channel (wnet.py:19,25,38-39), so the
+    # reference's WNet only runs as WNet(1, .) on a two-channel input
+    model = add_uncertainty(WNet(1, 1), dict(PARAMS)).to(DEV)
+    keys = list(model.state_dict().keys())
+    assert keys[0] == "baseModel.p1inc.double_conv.0.weight" and "baseModel.p2down4.maxpool_conv.1.double_conv.4.running_var" in keys
+    x, y = om.det_images(2, 2, 64, 48, salt=1)
+    model.train()
+    opt = nn_ops.FusedAdam(model.parameters(), lr=1e-3)
+    loss = model.loss_fn(model(x.to(DEV)), y[:, :1].to(DEV))
+    loss.backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for n, p in model.named_parameters()
+               if ".double_conv.0.bias" not in n and ".double_conv.3.bias" not in n)
+    opt.step()
+    model.eval()
+    with torch.no_grad():
+        out = model(x.to(DEV))
+    assert out.shape == (2, 3, 1, 64, 48) and bool(torch.isfinite(out).all())

@@ -76,3 +76,24 @@ def test_reference_whole_module_checkpoint_unpickles_into_the_hip_classes(tmp_pa
     got = model.state_dict()
     assert list(got.keys()) == list(sd.keys()) and all(torch.equal(got[k], sd[k]) for k in sd)
     assert "core" not in sys.modules or not getattr(sys.modules["core"], "__name__", "").startswith("im2im_uq_amd")
+
+
+def test_wnet_state_dict_matches_the_reference(tmp_path):
+    """same parameter names, order and shapes as the reference's WNet (needs the reference tree: build container only)."""
+    import os
+    import subprocess
+    import sys
+    import pytest
+    import torch
+    ref = os.environ.get("IM2IM_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "core")):
+        pytest.skip("reference tree not present (GPU box)")
+    out = str(tmp_path / "keys.pt")
+    script = ("import sys, torch; sys.path.insert(0, %r); sys.dont_write_bytecode = True\n"
+              "from core.models.trunks.wnet import WNet\n"
+              "torch.save({k: tuple(v.shape) for k, v in WNet(2, 1).state_dict().items()}, %r)\n" % (ref, out))
+    subprocess.run([sys.executable, "-c", script], check=True, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    from im2im_uq_amd.core.models.trunks.wnet import WNet
+    want = torch.load(out)
+    got = {k: tuple(v.shape) for k, v in WNet(2, 1).state_dict().items()}
+    assert list(got.items()) == list(want.items())
