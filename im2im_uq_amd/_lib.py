@@ -46,6 +46,9 @@ SIGNATURES = {
     # x, in_ss, x_hi, in_ss_hi, Ci_lo, wf, bias, center, scale, shift, y, y_hi, Co_lo, stats, B, H, W, Ci, Co, taps, relu, dtype, stream
     "im2im_conv_fwd_split": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr,
                                     _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
+    # dz, wd, dx, bn_z, bn_ss, bn_mi, bn_partial, B, H, W, Ci, Co, taps, dtype, stream
+    "im2im_conv_dgrad_bn": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
+    "im2im_bn_relu_bwd_from_partial": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i64, _ptr]),
     "im2im_conv_wgrad_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32]),
     # x, x_ss, x_hi, x_ss_hi, Ci_lo, dz, dw, ws, ws_bytes, B, H, W, Ci, Co, taps, dtype, stream
     "im2im_conv_wgrad_split": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _i64, _i32, _i32, _i32, _i32, _i32, _i32,

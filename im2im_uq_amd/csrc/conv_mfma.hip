@@ -48,6 +48,12 @@ struct ConvArgs {
   int Ci_lo;
   void* y_hi;           // null, or: output channels [Co_lo, Co) go here (pixel stride Co - Co_lo), [0, Co_lo) to y
   int Co_lo;
+  // EPI 3 (data-gradient whose result is the gradient of a lazy BatchNorm+ReLU activation): the producer's pre-BN
+  // output, its BatchNorm coefficients, and where this tile's partial sums of g and g*xhat go ([tiles][2][Co])
+  const void* bn_z;
+  const float* bn_ss;   // [2][Co] scale, shift
+  const float* bn_mi;   // [2][Co] mean, invstd
+  float* bn_partial;
 };
 
 template <typename T> struct Frag;
@@ -83,7 +89,10 @@ __device__ __forceinline__ void merge_moments_f32(float& n, float& m, float& q, 
 }
 
 // EPI: 0 = (+bias) store only [data-gradient, 1x1 conv]; 1 = +bias, store, BatchNorm partial statistics [train forward];
-//      2 = folded BatchNorm affine + ReLU [eval forward].  Compile-time so the 128 values per lane pay only for what
+//      2 = folded BatchNorm affine + ReLU [eval forward];  3 = data-gradient that also starts the BatchNorm+ReLU backward
+//      of the layer it differentiates into: while the rows go out, the same lanes read the producer's z at the same
+//      addresses and accumulate sum(g) and sum(g*xhat), g = da*[z*scale+shift > 0] -- bn_relu_bwd_reduce without its
+//      own pass over da and z.  Compile-time so the 128 values per lane pay only for what
 //      the launch needs (the generic epilogue was ~10 VALU per value; the data-gradient needs ~1).
 template <typename T, int TB, int TH, int TW, int BN, int WM, int WN, int TAPS, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
@@ -372,6 +381,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     }
   }
   // wave-private region: LDS operations of one wave complete in issue order, no barrier needed
+  float bsc[EPP], bsh[EPP], bmu[EPP], bis[EPP], bs1[EPP], bs2[EPP];      // EPI 3: this lane's EPP channels (fixed over the passes)
+  const T* __restrict__ bz = nullptr;
+  if constexpr (EPI == 3) {
+    const int c0 = ncol + (lane % EPR) * EPP;
+    bz = reinterpret_cast<const T*>(a.bn_z) + ncol;
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) {
+      bsc[k] = a.bn_ss[c0 + k]; bsh[k] = a.bn_ss[a.Co + c0 + k];
+      bmu[k] = a.bn_mi[c0 + k]; bis[k] = a.bn_mi[a.Co + c0 + k];
+      bs1[k] = 0.f; bs2[k] = 0.f;
+    }
+  }
 #pragma unroll
   for (int pass = 0; pass < WROWS / ROWS_PER_PASS; ++pass) {
     const int row = pass * ROWS_PER_PASS + lane / EPR;
@@ -379,8 +400,47 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     const uint4 v = *reinterpret_cast<const uint4*>(wbuf + row * WP + piece * 16);
     const int m = wm * WROWS + row;
     const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
-    if (bb < a.B && yy < a.H && xx < a.W)
-      *reinterpret_cast<uint4*>(yg + (((size_t)bb * a.H + yy) * a.W + xx) * ystride + piece * EPP) = v;
+    if (bb < a.B && yy < a.H && xx < a.W) {
+      const size_t off = (((size_t)bb * a.H + yy) * a.W + xx) * ystride + piece * EPP;
+      *reinterpret_cast<uint4*>(yg + off) = v;
+      if constexpr (EPI == 3) {
+        float g[EPP], zz[EPP];
+        Vec16<T>::load(reinterpret_cast<const T*>(&v), g);
+        Vec16<T>::load(bz + off, zz);
+#pragma unroll
+        for (int k = 0; k < EPP; ++k) {
+          const float gg = (zz[k] * bsc[k] + bsh[k] > 0.f) ? g[k] : 0.f;      // same test as bn_relu_bwd_reduce_kernel
+          bs1[k] += gg;
+          bs2[k] += gg * ((zz[k] - bmu[k]) * bis[k]);
+        }
+      }
+    }
+  }
+  if constexpr (EPI == 3) {
+    // lanes piece, piece + EPR, ... hold the same channels: butterfly over them, then the WM waves through LDS
+#pragma unroll
+    for (int off = EPR; off < 64; off <<= 1) {
+#pragma unroll
+      for (int k = 0; k < EPP; ++k) { bs1[k] += __shfl_xor(bs1[k], off, 64); bs2[k] += __shfl_xor(bs2[k], off, 64); }
+    }
+    __syncthreads();                                         // the scratch aliases wave 0's tile
+    if (lane < EPR) {
+#pragma unroll
+      for (int k = 0; k < EPP; ++k) {
+        const int nl = wn * WCOLS + lane * EPP + k;
+        ldsS[(wm * BN + nl) * 2 + 0] = bs1[k];
+        ldsS[(wm * BN + nl) * 2 + 1] = bs2[k];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) { s1 += ldsS[(i * BN + tid) * 2 + 0]; s2 += ldsS[(i * BN + tid) * 2 + 1]; }
+      float* pr = a.bn_partial + (size_t)tile_id * 2 * a.Co;
+      pr[n0 + tid] = s1;
+      pr[a.Co + n0 + tid] = s2;
+    }
   }
   if (want_stats) {
     __syncthreads();                                         // the stats scratch aliases wave 0's tile
@@ -813,6 +873,7 @@ int launch_conv_epi(const ConvArgs& a_in, hipStream_t stream) {
 
 template <typename T, int TB, int TH, int TW, int BN, int WM, int WN, int TAPS>
 int launch_conv(const ConvArgs& a, hipStream_t stream) {
+  if (a.bn_partial) return launch_conv_epi<T, TB, TH, TW, BN, WM, WN, TAPS, 3>(a, stream);
   if (a.stats) return launch_conv_epi<T, TB, TH, TW, BN, WM, WN, TAPS, 1>(a, stream);
   if (a.scale) return launch_conv_epi<T, TB, TH, TW, BN, WM, WN, TAPS, 2>(a, stream);
   return launch_conv_epi<T, TB, TH, TW, BN, WM, WN, TAPS, 0>(a, stream);
@@ -885,7 +946,23 @@ extern "C" int im2im_conv_fwd_split(const void* x, const float* in_scale_shift, 
   IM2IM_REQUIRE(!(stats && scale));                              // statistics describe the raw conv output
   IM2IM_REQUIRE(Ci <= 2048);
   ConvArgs a{x, w, bias, scale, shift, y, stats, B, H, W, Ci, Co, 0, 0, relu, center, in_scale_shift,
-             x_hi, in_scale_shift_hi, Ci_lo, y_hi, Co_lo};
+             x_hi, in_scale_shift_hi, Ci_lo, y_hi, Co_lo, nullptr, nullptr, nullptr, nullptr};
+  if (dtype == IM2IM_BF16) return taps == 9 ? dispatch_conv<bf16_t, 9>(a, stream) : dispatch_conv<bf16_t, 1>(a, stream);
+  return taps == 9 ? dispatch_conv<float, 9>(a, stream) : dispatch_conv<float, 1>(a, stream);
+}
+
+extern "C" int im2im_conv_dgrad_bn(const void* dz, const void* wd, void* dx, const void* bn_z, const float* bn_scale_shift,
+                                   const float* bn_mean_invstd, float* bn_partial, int32_t B, int32_t H, int32_t W, int32_t Ci,
+                                   int32_t Co, int32_t taps, int32_t dtype, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(dz && wd && dx && bn_z && bn_scale_shift && bn_mean_invstd && bn_partial);
+  IM2IM_REQUIRE(B > 0 && H > 0 && W > 0);
+  IM2IM_REQUIRE(Ci > 0 && Ci % 32 == 0 && Ci <= 2048);
+  IM2IM_REQUIRE(Co > 0 && Co % 32 == 0);
+  IM2IM_REQUIRE(taps == 9 || taps == 1);
+  IM2IM_REQUIRE(dtype == IM2IM_F32 || dtype == IM2IM_BF16);
+  ConvArgs a{dz, wd, nullptr, nullptr, nullptr, dx, nullptr, B, H, W, Ci, Co, 0, 0, 0, nullptr, nullptr,
+             nullptr, nullptr, Ci, nullptr, Co, bn_z, bn_scale_shift, bn_mean_invstd, bn_partial};
   if (dtype == IM2IM_BF16) return taps == 9 ? dispatch_conv<bf16_t, 9>(a, stream) : dispatch_conv<bf16_t, 1>(a, stream);
   return taps == 9 ? dispatch_conv<float, 9>(a, stream) : dispatch_conv<float, 1>(a, stream);
 }

@@ -1094,6 +1094,30 @@ extern "C" int im2im_bn_relu_pool_bwd(const void* da, const void* dpool, const v
   });
 }
 
+extern "C" int im2im_bn_relu_bwd_from_partial(const void* da, const void* z, const float* scale_shift, const float* mean_invstd,
+                                              const float* partial, int64_t R, void* dz, float* dgamma, float* dbeta, int64_t M,
+                                              int32_t C, int32_t dtype, void* ws, int64_t ws_bytes, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(da && z && scale_shift && mean_invstd && partial && dz && dgamma && dbeta && ws && M > 0 && C > 0 && C % 8 == 0 && R > 0);
+  IM2IM_REQUIRE(ws_bytes >= reduce_tmp_bytes(2 * (int64_t)C) + 2 * (int64_t)C * (int64_t)sizeof(float));
+  IM2IM_REQUIRE(C <= 1024);
+  double* tmp = (double*)ws;
+  float* coef = (float*)((char*)tmp + reduce_tmp_bytes(2 * (int64_t)C));
+  return for_dtype(dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    int rc;
+    const int S = launch_reduce_stage1(partial, R, 2 * (int64_t)C, tmp, stream, &rc);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, stream, (const double*)tmp, S, (int)C,
+                       (double)M, dgamma, dbeta, coef);
+    if (int rc2 = check_launch("bn_bwd_finalize_kernel")) return rc2;
+    const int64_t nvec = M * C / Vec16<T>::N;
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, stream, (const T*)da, (const T*)z,
+                       scale_shift, mean_invstd, coef, (T*)dz, nvec, (int)C);
+    return check_launch("bn_relu_bwd_apply_kernel");
+  });
+}
+
 extern "C" int64_t im2im_colsum_workspace_bytes(int64_t M, int32_t C) {
   const int64_t nblk = std::min<int64_t>(cdiv(M, 64), 2048);
   return nblk * C * (int64_t)sizeof(float) + reduce_tmp_bytes(C);

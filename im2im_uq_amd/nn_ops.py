@@ -159,6 +159,35 @@ def conv_fwd(x, wf, bias=None, scale_shift=None, relu=False, want_stats=False, i
     return (y, stats) if want_stats else y
 
 
+def conv_dgrad_bn(dz, wd, bn_z, bn_ss, bn_mi):
+    """data-gradient dx = da of a lazy BatchNorm+ReLU activation, plus the per-tile partial sums of the BatchNorm backward
+    (sum g, sum g*xhat) accumulated by the same epilogue -> (dx [B,H,W,Co], partial [R,2,Co])."""
+    b, h, w_, ci = dz.shape
+    co, taps = wd.shape[0], wd.shape[1]
+    dx = torch.empty((b, h, w_, co), dtype=dz.dtype, device=dz.device)
+    partial = torch.empty((lib.im2im_conv_stats_rows(b, h, w_, co), 2, co), dtype=F32, device=dz.device)
+    ev = TIMER.wrap(_tile_name("igemm", h, w_, co, taps, dz.dtype), 2.0 * b * h * w_ * co * ci * taps, dz.device) if TIMER else None
+    check(lib.im2im_conv_dgrad_bn(dptr(dz), dptr(wd), dptr(dx), dptr(bn_z), dptr(bn_ss), dptr(bn_mi), dptr(partial), b, h, w_, ci, co,
+                                  taps, _DT[dz.dtype], stream_ptr(dz.device)), "im2im_conv_dgrad_bn")
+    if ev is not None:
+        ev.record(torch.cuda.current_stream(dz.device))
+    return dx, partial
+
+
+def bn_relu_bwd_from_partial(da, z, scale_shift, mean_invstd, partial):
+    c = z.shape[-1]
+    m = z.numel() // c
+    dev = z.device
+    dz = torch.empty_like(z)
+    dgamma = torch.empty((c,), dtype=F32, device=dev)
+    dbeta = torch.empty((c,), dtype=F32, device=dev)
+    ws = _Scratch.get(lib.im2im_reduce_workspace_bytes(2 * c) + 2 * c * 4, dev)
+    check(lib.im2im_bn_relu_bwd_from_partial(dptr(da), dptr(z), dptr(scale_shift), dptr(mean_invstd), dptr(partial), partial.shape[0],
+                                             dptr(dz), dptr(dgamma), dptr(dbeta), m, c, _DT[z.dtype], dptr(ws), ws.numel(),
+                                             stream_ptr(dev)), "im2im_bn_relu_bwd_from_partial")
+    return dz, dgamma, dbeta
+
+
 def conv_wgrad(x, dz, taps, x_ss=None, x_hi=None, x_ss_hi=None):
     """x [B,H,W,Ci], dz [B,H,W,Co] -> dw [Co,Ci,taps] fp32 (x_ss: lazy BatchNorm+ReLU of x, as in conv_fwd; x_hi: second
     half of the input channels as in conv_fwd)."""
@@ -278,12 +307,27 @@ def smallconv_wgrad(s_nchw, l_nhwc, l_major, want_bias):
 
 # ----------------------------------------------------------------------------------------- autograd
 LAZY_ATTR = "_im2im_lazy_ss"
+LINK_ATTR = "_im2im_bn_link"
+FUSE_BN_REDUCE = True     # a conv that is the only consumer of a lazy activation folds that layer's BatchNorm-backward
+                          # reduction into its own data-gradient epilogue (im2im_conv_dgrad_bn)
+
+
+class BnLink:
+    """what a lazy activation's consumers need to start its BatchNorm backward for it: the producer's z and coefficients,
+    how many consumers read the activation in this forward, and (set by the consumer's backward) the partial sums."""
+    __slots__ = ("z", "ss", "mi", "consumers", "partial")
+
+    def __init__(self, z, ss, mi):
+        self.z, self.ss, self.mi, self.consumers, self.partial = z, ss, mi, 0, None
 
 
 def lazy_ss(x):
     """scale/shift [2,C] of a *lazy activation*: a tensor that physically holds the pre-BatchNorm conv output z and
     stands for a = relu(z*scale + shift).  Only the HIP consumers in this module understand it (they apply the
     transform while staging their operand); anything else must call materialize()."""
+    link = getattr(x, LINK_ATTR, None)
+    if link is not None:
+        link.consumers += 1                    # every consumer of a lazy activation asks for its coefficients exactly once
     return getattr(x, LAZY_ATTR, None)
 
 
@@ -303,6 +347,7 @@ class ConvStats(torch.autograd.Function):
         in_ss = lazy_ss(x)
         in_ss_hi = lazy_ss(x_hi) if x_hi is not None else None
         xin_hi = nhwc(x_hi.detach(), cdt) if x_hi is not None else None
+        ctx.link = getattr(x, LINK_ATTR, None) if (x_hi is None and not small) else None
         center = running_mean if (BF16_CENTERING and cdt == BF16 and running_mean is not None) else None
         if small:
             xin = x.detach().to(F32).contiguous()
@@ -347,7 +392,13 @@ class ConvStats(torch.autograd.Function):
                 dx, dx_hi = conv_fwd(dz, wd, split_out=xin.shape[3])
                 dx, dx_hi = nchw(dx), nchw(dx_hi)
             elif ctx.needs_input_grad[0]:
-                dx = nchw(conv_fwd(dz, wd))               # gradient w.r.t. the (lazy) input activation
+                link = ctx.link
+                if FUSE_BN_REDUCE and link is not None and link.consumers == 1 and link.z.dtype == dz.dtype:
+                    # sole consumer of a lazy activation: its BatchNorm-backward sums ride on this data-gradient's epilogue
+                    dx, link.partial = conv_dgrad_bn(dz, wd, link.z, link.ss, link.mi)
+                    dx = nchw(dx)
+                else:
+                    dx = nchw(conv_fwd(dz, wd))           # gradient w.r.t. the (lazy) input activation
         return dx, dx_hi, dw, None, None, None, None, None, None, None, None
 
 
@@ -357,16 +408,23 @@ class BnReluLazy(torch.autograd.Function):
     consumers (unet_parts.py:17-18 / 20-21)."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, scale_shift, mean_invstd):
+    def forward(ctx, z, gamma, beta, scale_shift, mean_invstd, link=None):
         ctx.save_for_backward(z, scale_shift, mean_invstd)
+        ctx.link = link
         return z.detach().view_as(z)
 
     @staticmethod
     def backward(ctx, da):
         z, scale_shift, mean_invstd = ctx.saved_tensors
         zz = nhwc(z)
-        dz, dgamma, dbeta = bn_relu_bwd(nhwc(da, zz.dtype), zz, scale_shift, mean_invstd)
-        return nchw(dz), dgamma, dbeta, None, None
+        link = ctx.link
+        partial = link.partial if link is not None else None
+        if partial is not None:
+            link.partial = None                       # the consumer's data-gradient already reduced g and g*xhat per tile
+            dz, dgamma, dbeta = bn_relu_bwd_from_partial(nhwc(da, zz.dtype), zz, scale_shift, mean_invstd, partial)
+        else:
+            dz, dgamma, dbeta = bn_relu_bwd(nhwc(da, zz.dtype), zz, scale_shift, mean_invstd)
+        return nchw(dz), dgamma, dbeta, None, None, None
 
 
 FUSE_POOL_BWD = True      # skip layers: max-pool backward + gradient add folded into the BatchNorm backward kernels
@@ -431,8 +489,11 @@ def conv_bn_relu_train(x, weight, bias, gamma, beta, running_mean, running_var, 
         a, pooled = BnReluLazyPool.apply(z, gamma, beta, scale_shift, mean_invstd)
         setattr(a, LAZY_ATTR, scale_shift)
         return a, pooled
-    a = BnReluLazy.apply(z, gamma, beta, scale_shift, mean_invstd)
+    link = BnLink(nhwc(z.detach()), scale_shift, mean_invstd) if lazy_out else None
+    a = BnReluLazy.apply(z, gamma, beta, scale_shift, mean_invstd, link)
     setattr(a, LAZY_ATTR, scale_shift)
+    if link is not None:
+        setattr(a, LINK_ATTR, link)
     a = a if lazy_out else materialize(a)
     return (a, MaxPool2.apply(a)) if pool else a
 

@@ -148,6 +148,17 @@ int im2im_conv_fwd_split(const void* x, const float* in_scale_shift, const void*
                          int32_t Co_lo, float* stats, int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co,
                          int32_t taps, int32_t relu, int32_t dtype, im2im_stream_t stream);
 
+/* Data-gradient of a convolution whose input was a lazy BatchNorm+ReLU activation (unet_parts.py:16-21 chained): dx is
+ * the gradient da of that activation, and the epilogue that writes it also reads the producer's pre-BN output bn_z
+ * [B][H][W][Co] and accumulates the two BatchNorm-backward sums per channel, sum(g) and sum(g*xhat) with
+ * g = da*[z*scale+shift > 0], xhat = (z-mean)*invstd, into bn_partial [im2im_conv_stats_rows(B,H,W,Co)][2][Co]
+ * (one row per tile, no atomics).  im2im_bn_relu_bwd_from_partial then finishes the BatchNorm+ReLU backward without the
+ * separate reduction pass over da and z.  dz is the incoming gradient [B][H][W][Ci], wd the data-gradient operand from
+ * im2im_pack_conv_weight. */
+int im2im_conv_dgrad_bn(const void* dz, const void* wd, void* dx, const void* bn_z, const float* bn_scale_shift,
+                        const float* bn_mean_invstd, float* bn_partial, int32_t B, int32_t H, int32_t W, int32_t Ci,
+                        int32_t Co, int32_t taps, int32_t dtype, im2im_stream_t stream);
+
 /* dw[co][ci][tap] (fp32, torch layout) = sum_{b,h,w} dz[b,h,w,co] * x[b,h+kh-1,w+kw-1,ci]
  *   Ci % 32 == 0, Co % 32 == 0.  workspace: im2im_conv_wgrad_workspace_bytes(...) bytes (split-K slabs,
  *   reduced deterministically). */
@@ -193,6 +204,11 @@ int64_t im2im_bn_bwd_workspace_bytes(int64_t M, int32_t C);
 int im2im_bn_relu_bwd(const void* da, const void* z, const float* scale_shift, const float* mean_invstd,
                       void* dz, float* dgamma, float* dbeta, int64_t M, int32_t C, int32_t dtype,
                       void* ws, int64_t ws_bytes, im2im_stream_t stream);
+/* im2im_bn_relu_bwd with the reduction already done by im2im_conv_dgrad_bn: partial [R][2][C].
+ * ws: im2im_reduce_workspace_bytes(2*C) + 2*C*4 bytes. */
+int im2im_bn_relu_bwd_from_partial(const void* da, const void* z, const float* scale_shift, const float* mean_invstd,
+                                   const float* partial, int64_t R, void* dz, float* dgamma, float* dbeta, int64_t M,
+                                   int32_t C, int32_t dtype, void* ws, int64_t ws_bytes, im2im_stream_t stream);
 
 /* BatchNorm+ReLU backward of a skip-connection layer fused with the backward of the MaxPool2d(2) that consumes the
  * same activation (unet.py:35-38; unet_parts.py:34 / 17-18,20-21): the activation's gradient

@@ -154,6 +154,31 @@ def test_upsample2x_alone_matches_concat_kernel_and_torch(dt):
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("case", [(2, 20, 24, 64, 64), (1, 70, 66, 32, 128), (3, 16, 16, 128, 32), (1, 80, 40, 64, 256)])
+def test_dgrad_with_batchnorm_backward_sums(case, dt):
+    """im2im_conv_dgrad_bn: dx identical to the plain data-gradient, partial sums == sum(g), sum(g*xhat) of that dx."""
+    from im2im_uq_amd import nn_ops
+    b, h, w, ci, co = case                                        # dz has ci channels, dx / z have co
+    dz = rnd(b, h, w, ci, seed=1).to(dt).to(DEV)
+    wt = rnd(ci, co, 3, 3, seed=2, scale=0.05).to(DEV)          # the forward conv's weight [Co_fwd = ci][Ci_fwd = co]
+    _, wd = nn_ops.pack_weight(wt, dt)
+    z = rnd(b, h, w, co, seed=3).to(dt).to(DEV)
+    ss = torch.stack([1.0 + 0.2 * rnd(co, seed=4), 0.3 * rnd(co, seed=5)]).to(DEV)
+    mi = torch.stack([0.1 * rnd(co, seed=6), 1.0 + 0.2 * rnd(co, seed=7).abs()]).to(DEV)
+    dx, partial = nn_ops.conv_dgrad_bn(dz, wd, z, ss, mi)
+    assert torch.equal(dx, nn_ops.conv_fwd(dz, wd))
+    g = dx.double() * ((z.double() * ss[0].double() + ss[1].double()) > 0)
+    mask32 = (z.float() * ss[0] + ss[1]) > 0                    # the kernel's own fp32 test decides the mask
+    g = dx.double() * mask32
+    xhat = (z.double() - mi[0].double()) * mi[1].double()
+    s1, s2 = g.sum(dim=(0, 1, 2)), (g * xhat).sum(dim=(0, 1, 2))
+    got = partial.double().sum(0)
+    t = 2e-5 if dt == F32 else 2e-5
+    assert float((got[0] - s1).abs().max() / (s1.abs().max() + 1e-30)) < t
+    assert float((got[1] - s2).abs().max() / (s2.abs().max() + 1e-30)) < t
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
 @pytest.mark.parametrize("shape", [(2, 1, 37, 29, 64), (1, 2, 48, 48, 64), (2, 3, 16, 20, 32), (1, 6, 33, 18, 32)])
 def test_smallconv_family(shape, dt):
     from im2im_uq_amd import nn_ops

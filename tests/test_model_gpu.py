@@ -303,6 +303,7 @@ def test_lazy_batchnorm_path_is_bit_identical_to_materialised(dt, monkeypatch):
         monkeypatch.setattr(nn_ops, "SPLIT_CONCAT", lazy)
         # the fused max-pool/BatchNorm backward sums its statistics in another order (tolerance-checked below instead)
         monkeypatch.setattr(nn_ops, "FUSE_POOL_BWD", False)
+        monkeypatch.setattr(nn_ops, "FUSE_BN_REDUCE", False)      # likewise the BatchNorm-backward sums from the dgrad epilogue
         model = build(1, dt)
         model.train()
         u = model.baseModel
@@ -341,6 +342,29 @@ def test_fused_pool_batchnorm_backward_matches_unfused(dt, tolerance, monkeypatc
     assert torch.equal(res[0][0], res[1][0])
     for n in res[0][1]:
         assert rel_l2(res[0][1][n], res[1][1][n]) < tolerance, n
+
+
+@pytest.mark.parametrize("dt,tolerance", [("fp32", 2e-5), ("bf16", 2e-2)])
+def test_batchnorm_backward_sums_from_dgrad_epilogue_match_separate_reduction(dt, tolerance, monkeypatch):
+    """A conv that is the only consumer of a lazy activation accumulates that layer's BatchNorm-backward sums in its
+    data-gradient epilogue (im2im_conv_dgrad_bn) instead of a separate pass over da and z.  Same forward bits; gradients
+    agree with the separate reduction up to summation order (fp32 2e-5; bf16 2e-2, a changed last bit of dz can flip
+    roundings downstream)."""
+    from oracle import model as om
+    from im2im_uq_amd import nn_ops
+    x, y = om.det_images(3, 1, 50, 46, salt=7)
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(nn_ops, "FUSE_BN_REDUCE", fused)
+        model = build(1, dt)
+        model.train()
+        pred = model(x.to(DEV))
+        model.loss_fn(pred, y.to(DEV)).backward()
+        res.append((pred.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0])
+    worst = max(rel_l2(res[0][1][n], res[1][1][n]) for n in res[0][1])
+    assert worst < tolerance, worst
+    assert any(not torch.equal(res[0][1][n], res[1][1][n]) for n in res[0][1]) or dt == "fp32"     # the fused path really ran
 
 
 def test_two_input_channels_train_step_vs_oracle_fp32():
