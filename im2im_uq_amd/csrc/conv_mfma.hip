@@ -326,6 +326,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   T* __restrict__ yg = reinterpret_cast<T*>(to_hi ? a.y_hi : a.y) + (to_hi ? ncol - a.Co_lo : ncol);
   const int ystride = a.y_hi == nullptr ? a.Co : (to_hi ? a.Co - a.Co_lo : a.Co_lo);
   constexpr bool want_stats = (EPI == 1);
+  // EPI 3: the producer's z pieces this lane will need in the row-copy loop below are requested NOW, so their HBM
+  // latency runs under the accumulator conversion and the LDS transpose instead of stalling each pass
+  constexpr int PASSES = WROWS / ROWS_PER_PASS;
+  uint4 zreg[EPI == 3 ? PASSES : 1];
+  if constexpr (EPI == 3) {
+    const T* __restrict__ bzp = reinterpret_cast<const T*>(a.bn_z) + ncol + (lane % EPR) * EPP;
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+      const int m = wm * WROWS + pass * ROWS_PER_PASS + lane / EPR;
+      const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
+      zreg[pass] = make_uint4(0, 0, 0, 0);
+      if (bb < a.B && yy < a.H && xx < a.W)
+        zreg[pass] = *reinterpret_cast<const uint4*>(bzp + (((size_t)bb * a.H + yy) * a.W + xx) * a.Co);
+    }
+  }
   __syncthreads();                                           // every wave is done reading the operand buffers
   char* wbuf = smem + wave * WBYTES;
   // BatchNorm partial statistics of this lane's values of channel nt: count, mean and M2 (sum of squared deviations).
@@ -382,10 +397,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   }
   // wave-private region: LDS operations of one wave complete in issue order, no barrier needed
   float bsc[EPP], bsh[EPP], bmu[EPP], bis[EPP], bs1[EPP], bs2[EPP];      // EPI 3: this lane's EPP channels (fixed over the passes)
-  const T* __restrict__ bz = nullptr;
   if constexpr (EPI == 3) {
     const int c0 = ncol + (lane % EPR) * EPP;
-    bz = reinterpret_cast<const T*>(a.bn_z) + ncol;
 #pragma unroll
     for (int k = 0; k < EPP; ++k) {
       bsc[k] = a.bn_ss[c0 + k]; bsh[k] = a.bn_ss[a.Co + c0 + k];
@@ -394,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     }
   }
 #pragma unroll
-  for (int pass = 0; pass < WROWS / ROWS_PER_PASS; ++pass) {
+  for (int pass = 0; pass < PASSES; ++pass) {
     const int row = pass * ROWS_PER_PASS + lane / EPR;
     const int piece = lane % EPR;
     const uint4 v = *reinterpret_cast<const uint4*>(wbuf + row * WP + piece * 16);
@@ -406,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
       if constexpr (EPI == 3) {
         float g[EPP], zz[EPP];
         Vec16<T>::load(reinterpret_cast<const T*>(&v), g);
-        Vec16<T>::load(bz + off, zz);
+        Vec16<T>::load(reinterpret_cast<const T*>(&zreg[pass]), zz);
 #pragma unroll
         for (int k = 0; k < EPP; ++k) {
           const float gg = (zz[k] * bsc[k] + bsh[k] > 0.f) ? g[k] : 0.f;      // same test as bn_relu_bwd_reduce_kernel

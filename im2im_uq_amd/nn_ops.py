@@ -643,6 +643,7 @@ class Conv1x1(torch.autograd.Function):
         wf, wd = pack_weight(weight, cdt)
         y = conv_fwd(xin, wf, bias.detach(), in_ss=ss)
         ctx.has_ss = ss is not None
+        ctx.link = getattr(x, LINK_ATTR, None)
         ctx.save_for_backward(xin, wd, ss if ss is not None else torch.empty(0))
         return nchw(y)
 
@@ -651,7 +652,14 @@ class Conv1x1(torch.autograd.Function):
         xin, wd, ss = ctx.saved_tensors
         ss = ss if ctx.has_ss else None
         dy = nhwc(dy, xin.dtype)
-        dx = nchw(conv_fwd(dy, wd)) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            link = ctx.link
+            if FUSE_BN_REDUCE and link is not None and link.consumers == 1 and link.z.dtype == dy.dtype:
+                dx, link.partial = conv_dgrad_bn(dy, wd, link.z, link.ss, link.mi)     # as in ConvStats.backward
+                dx = nchw(dx)
+            else:
+                dx = nchw(conv_fwd(dy, wd))
         dw = conv_wgrad(xin, dy, 1, x_ss=ss).view(dy.shape[3], xin.shape[3], 1, 1)
         return dx, dw, colsum(dy), None
 
