@@ -565,6 +565,7 @@ class UpsampleConcat(torch.autograd.Function):
         return nchw(ddeep), nchw(dskip)
 
 
+MATERIALIZE_BEFORE_UPSAMPLE = True
 SPLIT_CONCAT = True       # Up blocks: the first conv reads [skip, upsampled] from two tensors instead of a concatenated copy
 
 
@@ -582,6 +583,11 @@ class Upsample2x(torch.autograd.Function):
     def forward(ctx, deep, hh, ww):
         dss = lazy_ss(deep)
         d = nhwc(deep.detach())
+        if dss is not None and MATERIALIZE_BEFORE_UPSAMPLE:
+            # the interpolation kernel is VALU-bound when it applies BatchNorm+ReLU to each of its four taps; the deep map
+            # is 1/4 the size of the result, so normalising it once first is cheaper (same values: the in-kernel path rounds
+            # each tap to the storage type exactly like this pass does)
+            d, dss = bn_relu_apply(d, dss), None
         b, h, w_, cd = d.shape
         out = torch.empty((b, hh, ww, cd), dtype=d.dtype, device=d.device)
         check(lib.im2im_upsample2x_concat_fwd(dptr(d), dptr(dss), None, None, dptr(out), b, h, w_, cd, hh, ww, 0,
