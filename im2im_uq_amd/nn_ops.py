@@ -308,8 +308,11 @@ def smallconv_wgrad(s_nchw, l_nhwc, l_major, want_bias):
 # ----------------------------------------------------------------------------------------- autograd
 LAZY_ATTR = "_im2im_lazy_ss"
 LINK_ATTR = "_im2im_bn_link"
-FUSE_BN_REDUCE = True     # a conv that is the only consumer of a lazy activation folds that layer's BatchNorm-backward
-                          # reduction into its own data-gradient epilogue (im2im_conv_dgrad_bn)
+FUSE_BN_REDUCE = False    # opt-in: a conv that is the only consumer of a lazy activation folds that layer's BatchNorm-backward
+                          # reduction into its own data-gradient epilogue (im2im_conv_dgrad_bn).  Measured (tools/bench_bn_fuse.py,
+                          # profiles): every layer gains 0.02-0.18 ms in isolation, but in the step the power-limited MFMA
+                          # kernels pay for the extra epilogue work and the net is +0.5 % -- not worth making the conv kernel
+                          # slower, so the separate bandwidth-bound reduction stays the default
 
 
 class BnLink:
