@@ -206,3 +206,18 @@ def test_g13_softmax_nested_sets_and_calibration():
     assert abs(float(model.lhat) - float(g["lhat"])) <= step + 1e-6
     print("softmax: worst differing-pixel fraction", worst, "table max diff", float(np.abs(table.numpy() - g["table"]).max()),
           "lhat", float(model.lhat), float(g["lhat"]))
+
+
+def test_lambda_grid_size_limits():
+    """the largest lambda grid the scoring kernel takes (8192 points: histogram + grid fill the 64 KiB of LDS) is still
+    bit-exact, and one more point is refused with a named error instead of a silent truncation."""
+    from im2im_uq_amd import hip_ops, _lib
+    from oracle import calibration as oc
+    out, y = oc.synth_outputs(3, 1, 16, 16, seed=0)
+    lam = torch.linspace(0, 6, 8192)
+    table = hip_ops.rcps_loss_table(out.to(DEV), y.to(DEV), lam).cpu()
+    cols = list(range(0, 8192, 97)) + [8191]
+    ref = torch.stack([oc.fraction_missed(*oc.nested_sets(out, lam[j])[::2], y) for j in cols], dim=1)
+    assert np.array_equal(table[:, cols].numpy(), ref.numpy())
+    with pytest.raises(_lib.Im2ImError, match="MAX_L"):
+        hip_ops.rcps_loss_table(out.to(DEV), y.to(DEV), torch.linspace(0, 6, 8193))
