@@ -318,11 +318,11 @@ extern "C" int im2im_rcps_loss_table(const float* out3, const float* label, int6
                                      const float* lam, int32_t L, int32_t form, int32_t* hist_ws, float* table,
                                      int32_t* counts, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  IM2IM_REQUIRE(out3 && label && lam && hist_ws && table);
   IM2IM_REQUIRE(form >= 0 && form <= 3);
   IM2IM_REQUIRE(N >= 0 && P > 0 && L >= 1 && L <= MAX_L);
   IM2IM_REQUIRE(P < (1 << 24));                               // fp32(count) exact, as in the reference's fp32 mean
-  if (N == 0) return IM2IM_OK;
+  if (N == 0) return IM2IM_OK;                                // an empty shard: nothing to read or write (pointers may be null)
+  IM2IM_REQUIRE(out3 && label && lam && hist_ws && table);
   const size_t smem = sizeof(int) * (size_t)(((L + 1) + 3) & ~3) + sizeof(float) * (size_t)L;
   int64_t grid, per, maxseg, units_per_img;
   rcps_partition(N, P, L, &grid, &per, &maxseg, &units_per_img);
@@ -347,11 +347,12 @@ extern "C" int64_t im2im_rcps_workspace_bytes(int64_t N, int64_t P, int32_t L) {
 extern "C" int im2im_rcps_miscoverage(const float* out3, const float* label, int64_t N, int32_t C, int64_t HW,
                                       float lam, int32_t form, int32_t* map, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  IM2IM_REQUIRE(out3 && label && map);
+  IM2IM_REQUIRE(map);
   IM2IM_REQUIRE(form >= 0 && form <= 3);
   IM2IM_REQUIRE(N >= 0 && C >= 1 && C <= 65535 && HW > 0);
   IM2IM_HIP(hipMemsetAsync(map, 0, sizeof(int32_t) * (size_t)C * HW, stream));
   if (N == 0) return IM2IM_OK;
+  IM2IM_REQUIRE(out3 && label);
   const int64_t bx = im2im::cdiv(HW, 256 * 4);
   int64_t nz = im2im::cdiv(4096, bx * C);
   if (nz > N) nz = N;

@@ -221,3 +221,14 @@ def test_lambda_grid_size_limits():
     assert np.array_equal(table[:, cols].numpy(), ref.numpy())
     with pytest.raises(_lib.Im2ImError, match="MAX_L"):
         hip_ops.rcps_loss_table(out.to(DEV), y.to(DEV), torch.linspace(0, 6, 8193))
+
+
+def test_empty_shard_is_a_no_op():
+    """a rank whose calibration shard is empty (fewer images than ranks): the scoring entry points accept N = 0."""
+    from im2im_uq_amd import hip_ops
+    out = torch.empty((0, 3, 1, 16, 16), device=DEV)
+    lab = torch.empty((0, 1, 16, 16), device=DEV)
+    table = hip_ops.rcps_loss_table(out, lab, torch.linspace(0, 6, 50))
+    assert tuple(table.shape) == (0, 50)
+    counts = hip_ops.rcps_miscoverage(out, lab, 1.0)
+    assert tuple(counts.shape) == (1, 256) and int(counts.abs().sum()) == 0
