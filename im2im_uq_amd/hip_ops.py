@@ -80,7 +80,9 @@ def rcps_miscoverage(outputs: torch.Tensor, labels: torch.Tensor, lam: float, fo
     labels = require_gpu(labels, F32, "labels")
     _check_form(outputs, form)
     n, three, c = outputs.shape[0], outputs.shape[1], outputs.shape[2]
-    hw = outputs[0, 0, 0].numel()
+    hw = 1
+    for d in outputs.shape[3:]:
+        hw *= int(d)
     out = torch.empty((c, hw), dtype=torch.int32, device=outputs.device)
     with torch.cuda.device(outputs.device):
         check(lib.im2im_rcps_miscoverage(dptr(outputs), dptr(labels), n, c, hw, float(lam), int(form), dptr(out),
