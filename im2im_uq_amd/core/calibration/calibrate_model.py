@@ -202,7 +202,9 @@ def collect_outputs(model, dataset, config, device, shard=True):
         labels[counter:counter + b] = batch[1].to(device=device, dtype=torch.float32)
         counter += b
     if outputs is None:
-        raise ValueError("calibration dataset (shard) is empty")
+        if dist is not None:                                  # fewer images than ranks: this rank simply contributes no rows
+            return None, None
+        raise ValueError("calibration dataset is empty")
     return outputs, labels
 
 
@@ -252,7 +254,9 @@ def calibrate_model(model, dataset, config):
         dlambda = lambdas[1] - lambdas[0]
         model.set_lhat(lambdas[-1] + dlambda - 1e-9)
         form = sets_form(model)
-        if rcps_loss_fn is fraction_missed_loss and form is not None:
+        if outputs is None:                                   # empty shard of a multi-rank run
+            table = torch.zeros((0, lambdas.numel()), dtype=torch.float32, device=device)
+        elif rcps_loss_fn is fraction_missed_loss and form is not None:
             table = hip_ops.rcps_loss_table(outputs, labels, lambdas - dlambda, form=form)   # one pass, all lambdas
         else:                                                 # plugin loss: per-lambda, still device-resident
             ds = TensorDataset(outputs, labels)

@@ -53,7 +53,7 @@ def _worker(rank, world, port, n_total, tmpdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [16, 7])      # 7 over 2 ranks: ragged shards (4 + 3)
+@pytest.mark.parametrize("n_total", [16, 7, 1])   # 7 over 2 ranks: ragged shards (4 + 3); 1: rank 1's shard is empty
 def test_two_rank_gloo_calibration_and_grad_allreduce(tmp_path, n_total):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), n_total, str(tmp_path)), nprocs=world, join=True)
