@@ -50,6 +50,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // FORM 2  planes (p, v):    d_lo = d_up = sqrt(v)  (correctly rounded, as torch)      gaussian_layer.py:31-32
 // FORM 3  planes (lq, p, uq): d_lo = relu(p - lq), d_up = relu(uq - p)               softmax_layer.py:50-51 (lq, p, uq are
 //         the lambda-independent quantile summary of the softmax output, im2im_softmax_sets_summary)
+// torch.maximum / torch.minimum / relu propagate NaN (fmaxf / fminf return the other operand): a NaN bound must stay NaN so
+// that, as in the reference, every comparison with it is false and the pixel is not counted as missed
+__device__ __forceinline__ float nan_max(float a, float b) { return (a != a) ? a : fmaxf(a, b); }
+__device__ __forceinline__ float nan_min(float a, float b) { return (a != a) ? a : fminf(a, b); }
+
 template <int FORM> struct SetForm {
   static constexpr int PLANES = (FORM == 0 || FORM == 3) ? 3 : 2;
   static constexpr int PRED = (FORM == 0 || FORM == 3) ? 1 : 0;
@@ -57,14 +62,14 @@ template <int FORM> struct SetForm {
   static __device__ __forceinline__ void widths(float a, float b, float c, float& p, float& d_lo, float& d_up) {
     if constexpr (FORM == 0) {
       p = b;
-      d_lo = __fsub_rn(p, fminf(a, __fsub_rn(p, 1e-6f)));
-      d_up = __fsub_rn(fmaxf(c, __fadd_rn(p, 1e-6f)), p);
+      d_lo = __fsub_rn(p, nan_min(a, __fsub_rn(p, 1e-6f)));
+      d_up = __fsub_rn(nan_max(c, __fadd_rn(p, 1e-6f)), p);
     } else if constexpr (FORM == 1) {
       p = a; d_lo = b; d_up = b;
     } else if constexpr (FORM == 3) {
       p = b;
-      d_lo = fmaxf(__fsub_rn(p, a), 0.f);
-      d_up = fmaxf(__fsub_rn(c, p), 0.f);
+      d_lo = nan_max(__fsub_rn(p, a), 0.f);
+      d_up = nan_max(__fsub_rn(c, p), 0.f);
     } else {
       p = a; d_lo = sqrtf(b); d_up = d_lo;                    // correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt; NOT __fsqrt_rn, which maps to the 1-ulp native instruction)
     }
@@ -241,8 +246,8 @@ __global__ __launch_bounds__(256) void rcps_miscoverage_kernel(
       float p, d_lo, d_up;
       SetForm<FORM>::widths(lv[k], pv[k], uv[k], p, d_lo, d_up);
       const float pm = __fsub_rn(p, 1e-6f), pp = __fadd_rn(p, 1e-6f);
-      const float up = fmaxf(__fadd_rn(__fmul_rn(lam, d_up), p), pp);
-      const float lo = fminf(__fsub_rn(p, __fmul_rn(lam, d_lo)), pm);
+      const float up = nan_max(__fadd_rn(__fmul_rn(lam, d_up), p), pp);
+      const float lo = nan_min(__fsub_rn(p, __fmul_rn(lam, d_lo)), pm);
       acc[k] += (int)(yv[k] > up) + (int)(yv[k] < lo);        // calibrate_model.py:47
     }
   }
@@ -267,11 +272,11 @@ __global__ __launch_bounds__(256) void nested_sets_kernel(float* __restrict__ ou
     float p, d_lo, d_up;
     SetForm<FORM>::widths(*a_p, *b_p, *c_p, p, d_lo, d_up);
     const float pm = __fsub_rn(p, 1e-6f), pp = __fadd_rn(p, 1e-6f);
-    if (FORM == 0 && clamp_inplace) { *a_p = fminf(*a_p, pm); *c_p = fmaxf(*c_p, pp); }
+    if (FORM == 0 && clamp_inplace) { *a_p = nan_min(*a_p, pm); *c_p = nan_max(*c_p, pp); }
     float up = __fadd_rn(__fmul_rn(lam, d_up), p);
     // FORM 0: p - lam*d_lo (quantile_layer.py:42); FORM 1/2: (-lam)*d + p (gaussian_layer.py:32) -- the same fp32 value
     float lo = __fsub_rn(p, __fmul_rn(lam, d_lo));
-    if (floor) { up = fmaxf(up, pp); lo = fminf(lo, pm); }
+    if (floor) { up = nan_max(up, pp); lo = nan_min(lo, pm); }
     upper_edge[i] = up;
     lower_edge[i] = lo;
   }
