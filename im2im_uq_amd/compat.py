@@ -21,7 +21,7 @@ _MIRRORED = (
     "core.models.finallayers.residual_magnitude_layer", "core.models.finallayers.residual_magnitude_l1_layer",
     "core.models.finallayers.softmax_layer", "core.models.finallayers.inn_layer", "core.models.losses",
     "core.models.losses.pinball", "core.models.losses.inn", "core.calibration", "core.calibration.calibrate_model",
-    "core.calibration.bounds",
+    "core.calibration.bounds", "core.utils",
 )
 
 
