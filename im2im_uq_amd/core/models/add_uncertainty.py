@@ -81,42 +81,26 @@ class ModelWithUncertainty(nn.Module):
         self.lhat = lhat
 
 
-_OUT_OF_SCOPE = ()
+def _registry():
+    """uncertainty_type -> (final layer class, train loss, nested-set function): the reference's if/elif chain (:57-85)
+    as a table."""
+    return {
+        "quantiles": (QuantileRegressionLayer, quantile_regression_loss_fn, quantile_regression_nested_sets_from_output),
+        "quantiles_l1": (QuantileRegressionL1Layer, quantile_regression_l1_loss_fn, quantile_regression_l1_nested_sets_from_output),
+        "gaussian": (GaussianRegressionLayer, gaussian_regression_loss_fn, gaussian_regression_nested_sets_from_output),
+        "residual_magnitude": (ResidualMagnitudeLayer, residual_magnitude_loss_fn, residual_magnitude_nested_sets_from_output),
+        "residual_magnitude_l1": (ResidualMagnitudeL1Layer, residual_magnitude_l1_loss_fn,
+                                  residual_magnitude_l1_nested_sets_from_output),
+        "softmax": (SoftmaxLayer, softmax_loss_fn, softmax_nested_sets_from_output),
+        "inn": (INNLayer, inn_loss_fn, inn_nested_sets_from_output),
+    }
 
 
 def add_uncertainty(model, params):
-    if params["uncertainty_type"] == "quantiles":
-        last_layer = QuantileRegressionLayer(model.n_channels_middle, model.n_channels_out, params)
-        train_loss_fn = quantile_regression_loss_fn
-        nested_sets_from_output_fn = quantile_regression_nested_sets_from_output
-    elif params["uncertainty_type"] == "quantiles_l1":
-        last_layer = QuantileRegressionL1Layer(model.n_channels_middle, model.n_channels_out, params)
-        train_loss_fn = quantile_regression_l1_loss_fn
-        nested_sets_from_output_fn = quantile_regression_l1_nested_sets_from_output
-    elif params["uncertainty_type"] == "gaussian":
-        last_layer = GaussianRegressionLayer(model.n_channels_middle, model.n_channels_out, params)
-        train_loss_fn = gaussian_regression_loss_fn
-        nested_sets_from_output_fn = gaussian_regression_nested_sets_from_output
-    elif params["uncertainty_type"] == "residual_magnitude":
-        last_layer = ResidualMagnitudeLayer(model.n_channels_middle, model.n_channels_out, params)
-        train_loss_fn = residual_magnitude_loss_fn
-        nested_sets_from_output_fn = residual_magnitude_nested_sets_from_output
-    elif params["uncertainty_type"] == "residual_magnitude_l1":
-        last_layer = ResidualMagnitudeL1Layer(model.n_channels_middle, model.n_channels_out, params)
-        train_loss_fn = residual_magnitude_l1_loss_fn
-        nested_sets_from_output_fn = residual_magnitude_l1_nested_sets_from_output
-    elif params["uncertainty_type"] == "softmax":
-        last_layer = SoftmaxLayer(model.n_channels_middle, model.n_channels_out, params)
-        train_loss_fn = softmax_loss_fn
-        nested_sets_from_output_fn = softmax_nested_sets_from_output
-    elif params["uncertainty_type"] == "inn":
-        last_layer = INNLayer(model.n_channels_middle, model.n_channels_out, params)
-        train_loss_fn = inn_loss_fn
-        nested_sets_from_output_fn = inn_nested_sets_from_output
-    elif params["uncertainty_type"] in _OUT_OF_SCOPE:
-        raise NotImplementedError(
-            f"uncertainty_type={params['uncertainty_type']!r} is outside this build's scope (SURVEY.md section 8f): "
-            "the quantile, gaussian, residual-magnitude and softmax layers run on the HIP kernels; inn does not yet")
-    else:
-        raise NotImplementedError
-    return ModelWithUncertainty(model, last_layer, train_loss_fn, nested_sets_from_output_fn, params)
+    """trunk (needs n_channels_middle / n_channels_out) + params["uncertainty_type"] -> ModelWithUncertainty."""
+    try:
+        layer_cls, loss_fn, sets_fn = _registry()[params["uncertainty_type"]]
+    except KeyError:
+        raise NotImplementedError(f"unknown uncertainty_type {params.get('uncertainty_type')!r}") from None
+    head = layer_cls(model.n_channels_middle, model.n_channels_out, params)
+    return ModelWithUncertainty(model, head, loss_fn, sets_fn, params)

@@ -9,13 +9,13 @@ class INNLoss():
     """mean (or sum) of relu(target - upper)^2 + relu(lower - target)^2 + beta*|upper - lower|."""
 
     def __init__(self, beta=0.10, reduction='mean'):
-        self.beta = beta
-        assert 0 <= self.beta
-        self.reduction = reduction
+        if beta < 0:
+            raise AssertionError("beta must be non-negative")
+        self.beta, self.reduction = beta, reduction
 
     def __call__(self, lower, upper, target):
-        assert target.shape == lower.shape
-        assert target.shape == upper.shape
+        if not (target.shape == lower.shape == upper.shape):
+            raise AssertionError("lower, upper and target must have one shape")
         if not lower.is_cuda:
             raise RuntimeError("INNLoss: tensors must be on the GPU; the HIP path has no CPU fallback")
         n = lower.shape[0] if lower.dim() > 1 else 1

@@ -6,22 +6,26 @@ from ... import _pkg  # noqa: F401
 from .... import nn_ops
 
 
+def _fused_pinball(output, target, q):
+    """mean pinball loss of `output` against `target` at quantile q: the packed-loss kernel with only its first term on."""
+    if not output.is_cuda:
+        raise RuntimeError("PinballLoss: tensors must be on the GPU; the HIP path has no CPU fallback")
+    pred = output.to(torch.float32).contiguous()
+    frozen = pred.detach()
+    return nn_ops.QuantileLoss.apply(pred, frozen, frozen, target.detach().to(torch.float32).contiguous(), 0, 1, pred.numel(),
+                                     float(q), 0.5, 1.0, 0.0, 0.0)
+
+
 class PinballLoss():
+    """q*|e| where the prediction is below the target, (1-q)*|e| where above, 0 at ties; mean or sum over all elements."""
 
     def __init__(self, quantile=0.10, reduction='mean'):
-        self.quantile = quantile
-        assert 0 < self.quantile
-        assert self.quantile < 1
-        self.reduction = reduction
+        if not 0 < quantile < 1:
+            raise AssertionError("quantile must lie strictly between 0 and 1")
+        self.quantile, self.reduction = quantile, reduction
 
     def __call__(self, output, target):
-        assert output.shape == target.shape
-        if not output.is_cuda:
-            raise RuntimeError("PinballLoss: tensors must be on the GPU; the HIP path has no CPU fallback")
-        o = output.to(torch.float32).contiguous()
-        t = target.detach().to(torch.float32).contiguous()
-        n = o.numel()
-        loss = nn_ops.QuantileLoss.apply(o, o.detach(), o.detach(), t, 0, 1, n, float(self.quantile), 0.5, 1.0, 0.0, 0.0)
-        if self.reduction == 'sum':
-            loss = loss * n
-        return loss
+        if output.shape != target.shape:
+            raise AssertionError(f"shape mismatch: {tuple(output.shape)} vs {tuple(target.shape)}")
+        mean = _fused_pinball(output, target, self.quantile)
+        return mean * output.numel() if self.reduction == 'sum' else mean

@@ -8,40 +8,35 @@ from ... import _pkg  # noqa: F401
 from .unet_parts import DoubleConv, Down, OutConv, Up
 
 
+_ENCODER = (("down1", 64, 128), ("down2", 128, 256), ("down3", 256, 512))     # name, channels in, channels out (:21-23)
+
+
 class UNet(nn.Module):
     def __init__(self, n_channels_in, n_channels_out, bilinear=True):
         super(UNet, self).__init__()
-        self.n_channels_in = n_channels_in
-        self.n_channels_middle = 32
-        self.n_channels_out = n_channels_out
+        self.n_channels_in, self.n_channels_middle, self.n_channels_out = n_channels_in, 32, n_channels_out
         self.bilinear = bilinear
         factor = 2 if bilinear else 1
-
-        self.inc = DoubleConv(n_channels_in, 64)
-        self.down1 = Down(64, 128)
-        self.down2 = Down(128, 256)
-        self.down3 = Down(256, 512)
+        self.inc = DoubleConv(n_channels_in, 64)                       # registration order == the reference's state_dict order
+        for name, cin, cout in _ENCODER:
+            setattr(self, name, Down(cin, cout))
         self.down4 = Down(512, 1024 // factor)
-
-        self.up1 = Up(1024, 512 // factor, bilinear)
-        self.up2 = Up(512, 256 // factor, bilinear)
-        self.up3 = Up(256, 128 // factor, bilinear)
-        self.up4 = Up(128, 64, bilinear)
+        for level, (cin, cout) in enumerate(((1024, 512 // factor), (512, 256 // factor), (256, 128 // factor), (128, 64)), 1):
+            setattr(self, f"up{level}", Up(cin, cout, bilinear))
         self.out = OutConv(64, self.n_channels_middle)
 
     def forward(self, x):
         # lazy=True: between these blocks activations stay "pre-BatchNorm + (scale, shift)"; every consumer below is one
-        # of this package's kernels and applies BatchNorm+ReLU on the fly (see DoubleConv.forward)
+        # of this package's kernels and applies BatchNorm+ReLU on the fly (see DoubleConv.forward).
         # pool=True: a skip block also hands back MaxPool2d(2) of its output for the next Down block (pooled=True), so the
-        # pooling's backward and the skip-gradient accumulation fold into that block's BatchNorm backward kernels
-        x1, p1 = self.inc(x, lazy=True, pool=True)
-        x2, p2 = self.down1(p1, lazy=True, pool=True, pooled=True)
-        x3, p3 = self.down2(p2, lazy=True, pool=True, pooled=True)
-        x4, p4 = self.down3(p3, lazy=True, pool=True, pooled=True)
-        x5 = self.down4(p4, lazy=True, pooled=True)
-
-        x = self.up1(x5, x4, lazy=True)
-        x = self.up2(x, x3, lazy=True)
-        x = self.up3(x, x2, lazy=True)
-        x = self.up4(x, x1, lazy=True)
-        return self.out(x)
+        # pooling's backward and the skip-gradient accumulation fold into that block's BatchNorm backward kernels.
+        skips = []
+        feat, pooled = self.inc(x, lazy=True, pool=True)
+        skips.append(feat)
+        for name, _, _ in _ENCODER:
+            feat, pooled = getattr(self, name)(pooled, lazy=True, pool=True, pooled=True)
+            skips.append(feat)
+        h = self.down4(pooled, lazy=True, pooled=True)
+        for level in range(1, 5):                                      # up1(x5, x4) ... up4(., x1)  (:40-43)
+            h = getattr(self, f"up{level}")(h, skips[4 - level], lazy=True)
+        return self.out(h)
