@@ -20,20 +20,20 @@ import torch.nn.functional as F
 BN_EPS = 1e-5       # torch.nn.BatchNorm2d default, core/models/trunks/unet_parts.py:17
 BN_MOMENTUM = 0.1   # idem
 
-# (prefix, Cin, Cmid, Cout) for the nine DoubleConv blocks of the fixed
-# 4-level UNet, core/models/trunks/unet.py:20-30 with bilinear=True.
-def unet_blocks(n_in: int) -> List[Tuple[str, int, int, int]]:
-    return [
-        ("inc", n_in, 64, 64),
-        ("down1.maxpool_conv.1", 64, 128, 128),
-        ("down2.maxpool_conv.1", 128, 256, 256),
-        ("down3.maxpool_conv.1", 256, 512, 512),
-        ("down4.maxpool_conv.1", 512, 512, 512),
-        ("up1.conv", 1024, 512, 256),
-        ("up2.conv", 512, 256, 128),
-        ("up3.conv", 256, 128, 64),
-        ("up4.conv", 128, 64, 64),
-    ]
+# (prefix, Cin, Cmid, Cout) for the DoubleConv blocks of the UNet, core/models/trunks/unet.py:20-30 with
+# bilinear=True.  The reference fixes depth=4, base=64 (nine blocks: inc, down1-4, up1-4); the same recipe
+# written for any depth (level i has base*2**i channels, the deepest Down and every Up but the last halve
+# theirs) is what BASELINE configs[0] ("2-level") and configs[3] ("deeper UNet") are assembled from.
+def unet_blocks(n_in: int, depth: int = 4, base: int = 64) -> List[Tuple[str, int, int, int]]:
+    width = [base * 2 ** i for i in range(depth + 1)]
+    blocks = [("inc", n_in, base, base)]
+    for i in range(1, depth + 1):
+        co = width[i] // 2 if i == depth else width[i]
+        blocks.append((f"down{i}.maxpool_conv.1", width[i - 1], co, co))
+    for k in range(1, depth + 1):
+        cin = width[depth - k + 1]
+        blocks.append((f"up{k}.conv", cin, cin // 2, width[depth - k] // 2 if k < depth else base))
+    return blocks
 
 
 NUM_SOFTMAX = 50     # experiments/fastmri_test/config.yml num_softmax
@@ -49,11 +49,12 @@ HEADS = {
 }
 
 
-def state_spec(n_in: int = 1, n_out: int = 1, n_mid: int = 32, utype: str = "quantiles") -> List[Tuple[str, Tuple[int, ...]]]:
+def state_spec(n_in: int = 1, n_out: int = 1, n_mid: int = 32, utype: str = "quantiles", depth: int = 4,
+               base: int = 64) -> List[Tuple[str, Tuple[int, ...]]]:
     """(key, shape) list in the reference's state_dict order
     (unet.py:20-31, unet_parts.py:15-22,90, quantile_layer.py:15-17)."""
     spec: List[Tuple[str, Tuple[int, ...]]] = []
-    for prefix, cin, cmid, cout in unet_blocks(n_in):
+    for prefix, cin, cmid, cout in unet_blocks(n_in, depth, base):
         p = f"baseModel.{prefix}.double_conv"
         for idx, (ci, co) in ((0, (cin, cmid)), (3, (cmid, cout))):
             spec.append((f"{p}.{idx}.weight", (co, ci, 3, 3)))
@@ -63,7 +64,7 @@ def state_spec(n_in: int = 1, n_out: int = 1, n_mid: int = 32, utype: str = "qua
             spec.append((f"{p}.{idx + 1}.running_mean", (co,)))
             spec.append((f"{p}.{idx + 1}.running_var", (co,)))
             spec.append((f"{p}.{idx + 1}.num_batches_tracked", ()))
-    spec.append(("baseModel.out.conv.weight", (n_mid, 64, 1, 1)))
+    spec.append(("baseModel.out.conv.weight", (n_mid, base, 1, 1)))
     spec.append(("baseModel.out.conv.bias", (n_mid,)))
     if utype == "softmax":                                             # softmax_layer.py:11 (one conv to num_softmax classes)
         spec.append(("last_layer.output_layers.0.weight", (NUM_SOFTMAX, n_mid, 3, 3)))
@@ -139,16 +140,25 @@ def up_block(x_deep, x_skip, state, prefix, training, emulate_bf16=False):
     return double_conv(cat, state, prefix, training, emulate_bf16)
 
 
+def unet_depth(state) -> int:
+    """number of Down blocks the state describes (4 for the reference's UNet)."""
+    d = 0
+    while f"baseModel.down{d + 1}.maxpool_conv.1.double_conv.0.weight" in state:
+        d += 1
+    return d
+
+
 def unet_forward(x, state, training: bool, emulate_bf16=False):
-    """core/models/trunks/unet.py:33-46."""
+    """core/models/trunks/unet.py:33-46 (for the depth the state describes)."""
+    depth = unet_depth(state)
     x1 = double_conv(x, state, "inc", training, emulate_bf16)
     skips = [x1]
     h = x1
-    for i in range(1, 5):
+    for i in range(1, depth + 1):
         h = double_conv(F.max_pool2d(h, 2), state, f"down{i}.maxpool_conv.1", training, emulate_bf16)  # unet_parts.py:33-40
         skips.append(h)
-    for i in range(1, 5):
-        h = up_block(h, skips[4 - i], state, f"up{i}.conv", training, emulate_bf16)
+    for i in range(1, depth + 1):
+        h = up_block(h, skips[depth - i], state, f"up{i}.conv", training, emulate_bf16)
     out = F.conv2d(h, _operand(state["baseModel.out.conv.weight"], emulate_bf16), state["baseModel.out.conv.bias"])  # unet_parts.py:90-94
     return _store(out, emulate_bf16)
 
@@ -259,8 +269,8 @@ def det_fill(key: str, shape: Tuple[int, ...]) -> torch.Tensor:
     return v.to(torch.float32).reshape(shape)
 
 
-def det_state(n_in: int = 1, n_out: int = 1, utype: str = "quantiles") -> Dict[str, torch.Tensor]:
-    return {k: det_fill(k, shp) for k, shp in state_spec(n_in, n_out, utype=utype)}
+def det_state(n_in: int = 1, n_out: int = 1, utype: str = "quantiles", depth: int = 4, base: int = 64) -> Dict[str, torch.Tensor]:
+    return {k: det_fill(k, shp) for k, shp in state_spec(n_in, n_out, utype=utype, depth=depth, base=base)}
 
 
 def det_images(n: int, c: int, h: int, w: int, salt: int = 0):

@@ -498,11 +498,91 @@ def g14(only_parts=()):
         save("g14_" + name, **rec)
 
 
+# ---------------------------------------------------------------- G17 UNets of other depths, from the reference's own parts
+class RefUNetDepth(nn.Module):
+    """the reference's DoubleConv / Down / Up / OutConv assembled by the recipe of core/models/trunks/unet.py:20-46 for
+    a given depth (the reference hard-codes depth 4; SURVEY D3: this assembly is the oracle for BASELINE configs[0]
+    "2-level" and configs[3] "deeper UNet").  depth=4 reproduces the reference's UNet state_dict exactly (asserted)."""
+
+    def __init__(self, n_channels_in, n_channels_out, depth, base=64, bilinear=True):
+        super().__init__()
+        self.n_channels_in, self.n_channels_middle, self.n_channels_out = n_channels_in, 32, n_channels_out
+        self.depth = depth
+        factor = 2 if bilinear else 1
+        width = [base * 2 ** i for i in range(depth + 1)]
+        self.inc = DoubleConv(n_channels_in, base)
+        for i in range(1, depth + 1):
+            setattr(self, f"down{i}", Down(width[i - 1], width[i] // factor if i == depth else width[i]))
+        for k in range(1, depth + 1):
+            setattr(self, f"up{k}", Up(width[depth - k + 1], width[depth - k] // factor if k < depth else base, bilinear))
+        self.out = OutConv(base, self.n_channels_middle)
+
+    def forward(self, x):
+        feats = [self.inc(x)]
+        for i in range(1, self.depth + 1):
+            feats.append(getattr(self, f"down{i}")(feats[-1]))
+        h = feats[-1]
+        for k in range(1, self.depth + 1):
+            h = getattr(self, f"up{k}")(h, feats[self.depth - k])
+        return self.out(h)
+
+
+def g17():
+    ref4 = UNet(1, 1).state_dict()
+    mine4 = RefUNetDepth(1, 1, 4).state_dict()
+    assert list(ref4.keys()) == list(mine4.keys()) and all(ref4[k].shape == mine4[k].shape for k in ref4)
+    for depth, hw, nb in ((2, 32, 4), (5, 64, 2)):
+        model = add_uncertainty(RefUNetDepth(1, 1, depth), dict(PARAMS))
+        st = om.det_state(1, 1, depth=depth)
+        model.load_state_dict(st, strict=True)
+        if depth == 2:                     # configs[0]: synthetic Gaussian-denoise, y ~ U[0,1], x = y + 0.1 N(0,1)
+            fix_randomness(0)
+            y = torch.rand(nb, 1, hw, hw)
+            x = y + 0.1 * torch.randn(nb, 1, hw, hw)
+        else:
+            x, y = om.det_images(nb, 1, hw, hw, salt=2)
+        model.eval()
+        with torch.no_grad():
+            out_eval = model(x)
+        model.train()
+        out_train = model(x)
+        loss = model.loss_fn(out_train, y)
+        loss.backward()
+        sd = model.state_dict()
+        rec = dict(x=x, y=y, out_eval=out_eval, out_train=out_train.detach(), loss=loss.detach(), depth=np.array(depth))
+        for k, prm in model.named_parameters():           # float64 norm + a strided sample of every parameter gradient
+            g = prm.grad.flatten()
+            rec["gnorm." + k] = g.double().norm()
+            rec["gsample." + k] = g[::max(1, g.numel() // 256)][:256].clone()
+        for k, v in sd.items():
+            if "running" in k and (".inc." in k or f".up{depth}." in k or f".down{depth}." in k):
+                rec["state." + k] = v.clone()
+        if depth == 2:                     # a short Adam run (train.py:141-165) + calibration on held-out images
+            model.load_state_dict(st, strict=True)
+            model.zero_grad()
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+            losses = []
+            for step in range(5):
+                pred = model(x)
+                l = model.loss_fn(pred, y)
+                losses.append(l.item())
+                opt.zero_grad(); l.backward(); opt.step()
+            rec["adam_losses"] = np.array(losses)
+            fix_randomness(1)
+            yc = torch.rand(16, 1, hw, hw)
+            xc = yc + 0.1 * torch.randn(16, 1, hw, hw)
+            cfg = dict(PARAMS, batch_size=8, num_lambdas=50)
+            with quiet(), contextlib.redirect_stderr(io.StringIO()):
+                model, table = calibrate_model(model, TensorDataset(xc, yc), cfg)
+            rec.update(cal_x=xc, cal_y=yc, cal_table=table, lhat=model.lhat)
+        save(f"g17_unet_depth{depth}", **rec)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
     for name, fn in (("g1_g2", g1_g2), ("g3", g3), ("g4", g4), ("g5", g5), ("g6", g6), ("g7", g7), ("g8", g8),
-                     ("g9_g10", g9_g10), ("g11", g11), ("g12", g12), ("g13", g13), ("g14", g14)):
+                     ("g9_g10", g9_g10), ("g11", g11), ("g12", g12), ("g13", g13), ("g14", g14), ("g17", g17)):
         if not only or name in only:
             fn()
     if "g12_inn" in only:

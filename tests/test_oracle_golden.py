@@ -251,3 +251,35 @@ def test_g14_blocks_at_kernel_channel_counts(name):
         else:
             y = om.up_block(x0, T(g[f"{mode}.x1"]), work, "blk", mode == "train")
         np.testing.assert_allclose(y.numpy(), g[f"{mode}.y"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("depth", [2, 5])
+def test_g17_unet_of_other_depths(depth):
+    """the oracle's depth-generic UNet against the reference's own DoubleConv/Down/Up/OutConv assembled to that depth
+    (make_golden.py RefUNetDepth; BASELINE configs[0] is depth 2, configs[3] "deeper UNet" depth 5)."""
+    g = load_golden(f"g17_unet_depth{depth}")
+    st = om.det_state(1, 1, depth=depth)
+    assert om.unet_depth(st) == depth
+    x, y = T(g["x"]), T(g["y"])
+    with torch.no_grad():
+        out = om.model_forward(x, st, training=False)
+    np.testing.assert_allclose(out.numpy(), g["out_eval"], rtol=1e-4, atol=1e-5)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in st.items() if om.is_param(k)}
+    work = dict(st); work.update(leaves)
+    pred = om.model_forward(x, work, training=True)
+    np.testing.assert_allclose(pred.detach().numpy(), g["out_train"], rtol=1e-4, atol=2e-5)
+    loss = om.quantile_loss(pred, y, PARAMS)
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-5)
+    loss.backward()
+    for k in ("last_layer.prediction.weight", "baseModel.out.conv.weight", f"baseModel.up{depth}.conv.double_conv.3.weight",
+              "baseModel.inc.double_conv.0.weight"):
+        gr = leaves[k].grad.flatten()
+        np.testing.assert_allclose(gr[::max(1, gr.numel() // 256)][:256].numpy(), g["gsample." + k], rtol=2e-3,
+                                   atol=2e-3 * float(g["gnorm." + k]) / np.sqrt(gr.numel()))
+    for k in g:
+        if k.startswith("state."):
+            np.testing.assert_allclose(work[k[len("state."):]].numpy(), g[k], rtol=1e-4, atol=1e-6)
+    if depth == 2:
+        st2 = om.det_state(1, 1, depth=2)
+        losses = om.train_steps(st2, [(x, y)] * 5, PARAMS, lr=1e-3)
+        np.testing.assert_allclose(losses, g["adam_losses"], rtol=2e-4)

@@ -1,0 +1,140 @@
+"""Depth-parametrised UNet on the HIP kernels (BASELINE configs[0] "2-level UNet", configs[3] "deeper UNet") against
+fixtures G17: the reference's own DoubleConv / Down / Up / OutConv assembled to depth 2 and 5 by the recipe of
+core/models/trunks/unet.py:20-46 (tests/golden/make_golden.py RefUNetDepth), plus the default depth's state_dict keys."""
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import TensorDataset
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = torch.from_numpy
+PARAMS = dict(uncertainty_type="quantiles", q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1,
+              alpha=0.1, delta=0.1, num_lambdas=50, rcps_loss="fraction_missed", minimum_lambda=0, maximum_lambda=6,
+              device=DEV, dataset="synthetic", batch_size=8, lr=1e-3, input_normalization="standard",
+              output_normalization="min-max", num_validation_images=2)
+
+
+@pytest.fixture(autouse=True)
+def _restore_dtype():
+    from im2im_uq_amd import nn_ops
+    yield
+    nn_ops.set_compute_dtype("bf16")
+
+
+def build(depth, dt):
+    from im2im_uq_amd import nn_ops
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from im2im_uq_amd.core.models.trunks.unet import UNet
+    from oracle import model as om
+    nn_ops.set_compute_dtype(dt)
+    model = add_uncertainty(UNet(1, 1, depth=depth), dict(PARAMS))
+    model.load_state_dict(om.det_state(1, 1, depth=depth))          # strict: keys are the reference recipe's
+    return model.to(DEV)
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).double().flatten(), torch.as_tensor(b).double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("depth", [2, 5])
+def test_g17_forward_loss_gradients_fp32(depth):
+    """fp32 parity mode vs the reference parts: outputs atol 5e-4, loss 5e-5 relative, running statistics 1e-3, and the
+    sampled parameter gradients within 2 % of the tensor's RMS (re-association noise of an fp32 network whose
+    BatchNorm sees as few as 8 samples per channel at the bottom level)."""
+    g = load_golden(f"g17_unet_depth{depth}")
+    model = build(depth, "fp32")
+    x, y = T(g["x"]).to(DEV), T(g["y"]).to(DEV)
+    model.eval()
+    with torch.no_grad():
+        out = model(x)
+    np.testing.assert_allclose(out.cpu().numpy(), g["out_eval"], rtol=0, atol=3e-4)
+    model.train()
+    pred = model(x)
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g["out_train"], rtol=0, atol=5e-4)
+    loss = model.loss_fn(pred, y)
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=5e-5)
+    loss.backward()
+    sd = model.state_dict()
+    for k in g:
+        if k.startswith("state."):
+            np.testing.assert_allclose(sd[k[len("state."):]].cpu().numpy(), g[k], rtol=1e-3, atol=1e-5)
+    worst = 0.0
+    for name, p in model.named_parameters():
+        if ".double_conv.0.bias" in name or ".double_conv.3.bias" in name:
+            continue                                      # conv bias before train-mode BatchNorm: analytically zero
+        gr = p.grad.flatten().cpu()
+        sample = gr[::max(1, gr.numel() // 256)][:256].numpy()
+        rms = float(g["gnorm." + name]) / np.sqrt(gr.numel())
+        err = np.abs(sample - g["gsample." + name]).max() / (rms + 1e-30)
+        worst = max(worst, err)
+        assert float(gr.double().norm()) == pytest.approx(float(g["gnorm." + name]), rel=2e-2), name
+    assert worst < 0.05, worst
+
+
+def test_g17_depth2_adam_and_calibration_fp32():
+    """configs[0] (32x32 Gaussian-denoise, 2-level UNet): five Adam steps track the reference's losses within 0.5 %, and
+    calibrating the trained net lands on the reference's lambda-hat within one grid step (the table is compared where
+    both visited it)."""
+    from im2im_uq_amd import nn_ops
+    from im2im_uq_amd.core.calibration.calibrate_model import calibrate_model
+    g = load_golden("g17_unet_depth2")
+    model = build(2, "fp32")
+    x, y = T(g["x"]).to(DEV), T(g["y"]).to(DEV)
+    opt = nn_ops.FusedAdam(model.parameters(), lr=1e-3)
+    model.train()
+    losses = []
+    for _ in range(5):
+        loss = model.loss_fn(model(x), y)
+        losses.append(loss.item())
+        opt.zero_grad(); loss.backward(); opt.step()
+    np.testing.assert_allclose(losses, g["adam_losses"], rtol=5e-3)
+    cfg = dict(PARAMS, batch_size=8, num_lambdas=50)
+    model, table = calibrate_model(model, TensorDataset(T(g["cal_x"]), T(g["cal_y"])), cfg)
+    dl = 6.0 / 49
+    assert abs(float(model.lhat) - float(g["lhat"])) <= dl * 1.001
+    both = (table.numpy() != 0).any(axis=0) & (g["cal_table"] != 0).any(axis=0)
+    assert both.any()
+    assert np.abs(table.numpy()[:, both] - g["cal_table"][:, both]).mean() < 5e-3
+
+
+@pytest.mark.parametrize("depth", [2, 5])
+def test_g17_bf16_tolerance(depth):
+    """throughput mode vs the reference's fp32: eval outputs 3 % relative L2, train-mode loss 3 %."""
+    g = load_golden(f"g17_unet_depth{depth}")
+    model = build(depth, "bf16")
+    x, y = T(g["x"]).to(DEV), T(g["y"]).to(DEV)
+    model.eval()
+    with torch.no_grad():
+        out = model(x)
+    assert rel_l2(out.cpu(), g["out_eval"]) < 3e-2
+    model.train()
+    loss = model.loss_fn(model(x), y)
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=3e-2)
+
+
+def test_default_depth_is_the_reference_network():
+    from im2im_uq_amd.core.models.trunks.unet import UNet, unet_plan
+    from oracle import model as om
+    keys = [k for k, _ in om.state_spec(1, 1) if k.startswith("baseModel.")]
+    mine = ["baseModel." + k for k in UNet(1, 1).state_dict().keys()]
+    assert mine == keys                                   # G4 pins these keys against the reference's UNet
+    assert [(n, ci, co) for n, _, ci, co in unet_plan(1)] == [
+        ("inc", 1, 64), ("down1", 64, 128), ("down2", 128, 256), ("down3", 256, 512), ("down4", 512, 512),
+        ("up1", 1024, 256), ("up2", 512, 128), ("up3", 256, 64), ("up4", 128, 64)]
+
+
+def test_configs3_deeper_unet_1024_tile_row_vs_cpu_fp32():
+    """configs[3] shape check with parity: a depth-5 UNet on a 1024-wide strip (B=1, 64 x 1024 -- one row of 16x16
+    tiles at full width, small enough for the CPU oracle) in fp32 mode, eval forward, vs the oracle: atol 5e-4."""
+    from oracle import model as om
+    model = build(5, "fp32")
+    x, _ = om.det_images(1, 1, 64, 1024, salt=4)
+    model.eval()
+    with torch.no_grad():
+        out = model(x.to(DEV))
+        ref = om.model_forward(x, om.det_state(1, 1, depth=5), training=False)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=5e-4)
