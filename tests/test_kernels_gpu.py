@@ -403,3 +403,58 @@ def test_inn_loss_class_matches_formula():
         ref.backward()
         assert got.item() == pytest.approx(ref.item(), rel=2e-5)
         assert rel_l2(l_d.grad.cpu(), l_r.grad) < 2e-5 and rel_l2(u_d.grad.cpu(), u_r.grad) < 2e-5
+
+
+# BASELINE configs[1] layer shapes: B >= 8 so the 1x16x16 tile path sees several images, the split
+# cases are the Up blocks' first conv reading [skip, upsampled] from two tensors.  (B, H, W, Ci, Co, split)
+BASELINE_LAYER_CASES = [
+    (8, 320, 320, 64, 64, False),      # inc / up4 second conv: the 1x16x16, BN=64 variant (40 % of the FLOPs)
+    (8, 320, 320, 128, 64, True),      # up4 first conv: 64 skip + 64 upsampled channels
+    (8, 160, 160, 64, 128, False),     # down1 first conv: 1x16x16, BN=128
+    (8, 40, 40, 1024, 512, True),      # up1 first conv: 4x8x8 tiles, 512 + 512 channels, K = 9216
+]
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("case", BASELINE_LAYER_CASES)
+def test_conv_fwd_dgrad_wgrad_at_baseline_layer_shapes(case, dt):
+    """forward (+ BatchNorm partial statistics), data-gradient and weight-gradient at the benchmarked layer shapes
+    against F.conv2d / its autograd in fp32 on the CPU, operands quantised the way the kernel sees them.
+    Tolerance (relative L2): fp32 2e-5, bf16 1.5e-2 (bf16 rounding of the stored result; K up to 9216)."""
+    from im2im_uq_amd import nn_ops
+    b, h, w, ci, co, split = case
+    x = rnd(b, ci, h, w, seed=11)
+    wt = rnd(co, ci, 3, 3, seed=12, scale=(ci * 9) ** -0.5)
+    bias = rnd(co, seed=13, scale=0.1)
+    gy = rnd(b, co, h, w, seed=16)
+    xq, wq = q(x, dt).requires_grad_(True), q(wt, dt).requires_grad_(True)
+    torch.set_num_threads(min(32, torch.get_num_threads() or 1))
+    ref = F.conv2d(xq, wq, bias, padding=1)
+    ref.backward(q(gy, dt))
+    x_d = x.to(DEV).permute(0, 2, 3, 1).contiguous().to(dt)
+    gy_d = gy.to(DEV).permute(0, 2, 3, 1).contiguous().to(dt)
+    wf, wd = nn_ops.pack_weight(wt.to(DEV), dt)
+    if split:
+        lo, hi = x_d[..., : ci // 2].contiguous(), x_d[..., ci // 2:].contiguous()
+        y, stats = nn_ops.conv_fwd(lo, wf, bias.to(DEV), want_stats=True, x_hi=hi)
+        dw = nn_ops.conv_wgrad(lo, gy_d, 9, x_hi=hi)
+        dx_lo, dx_hi = nn_ops.conv_fwd(gy_d, wd, split_out=ci // 2)
+        dx = torch.cat([dx_lo, dx_hi], dim=3)
+    else:
+        y, stats = nn_ops.conv_fwd(x_d, wf, bias.to(DEV), want_stats=True)
+        dw = nn_ops.conv_wgrad(x_d, gy_d, 9)
+        dx = nn_ops.conv_fwd(gy_d, wd)
+    torch.cuda.synchronize()
+    assert rel_l2(y.float().cpu().permute(0, 3, 1, 2), ref.detach()) < tol(dt)
+    assert rel_l2(dx.float().cpu().permute(0, 3, 1, 2), xq.grad) < tol(dt)
+    assert rel_l2(dw.cpu().view(co, ci, 3, 3), wq.grad) < tol(dt)
+    # worst single element, against the tensor's RMS (a dropped tile or a wrong halo shows here, not in the L2)
+    for got, want in ((y.float().cpu().permute(0, 3, 1, 2), ref.detach()), (dx.float().cpu().permute(0, 3, 1, 2), xq.grad),
+                      (dw.cpu().view(co, ci, 3, 3), wq.grad)):
+        rms = float(want.double().pow(2).mean().sqrt())
+        assert float((got - want).abs().max()) < (2e-4 if dt == F32 else 6e-2) * rms
+    n, mean, m2 = merged_moments(stats)
+    yst = y.double().cpu().reshape(-1, co)
+    assert float((n - yst.shape[0]).abs().max()) == 0.0
+    np.testing.assert_allclose(mean.numpy(), yst.mean(0).numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(m2.numpy(), ((yst - yst.mean(0)) ** 2).sum(0).numpy(), rtol=2e-5)
