@@ -43,22 +43,26 @@ def shard_bounds(n: int, rank: int, world: int):
     return lo, min(lo + per, n)
 
 
-def gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
-    """all-gather [n_local, ...] row blocks (contiguous shards, possibly ragged) -> [n_total, ...]."""
+def gather_rows(local: torch.Tensor, n_total=None) -> torch.Tensor:
+    """all-gather [n_local, ...] row blocks -> [sum n_local, ...] in rank order.  The ranks first exchange their row
+    counts, so any partition works (contiguous `shard_bounds` shards, caller-provided local shards of unequal size,
+    empty shards); `n_total`, when given, is checked against the gathered count."""
     dist = _dist()
     if dist is None:
         return local
     world = dist.get_world_size()
-    per = (n_total + world - 1) // world
+    cnt = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt)
+    counts = [int(c.item()) for c in counts]
+    if n_total is not None and sum(counts) != n_total:
+        raise ValueError(f"gather_rows: ranks hold {counts} rows, expected {n_total} in total")
+    per = max(max(counts), 1)
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
-    rows = []
-    for r in range(world):
-        lo, hi = shard_bounds(n_total, r, world)
-        rows.append(parts[r][: hi - lo])
-    return torch.cat(rows, dim=0)
+    return torch.cat([parts[r][: counts[r]] for r in range(world)], dim=0)
 
 
 # ------------------------------------------------------------------ losses
@@ -107,31 +111,71 @@ def get_rcps_losses(model, dataset, rcps_loss_fn, lam, device):
     return get_rcps_losses_from_outputs(model, TensorDataset(outputs, labels), rcps_loss_fn, lam, device)
 
 
-def get_rcps_metrics_from_outputs(model, out_dataset, rcps_loss_fn, device):
+def shard_offset(n_local: int, device):
+    """(first global row of this rank's block, total rows) for row blocks held in rank order."""
+    dist = _dist()
+    if dist is None:
+        return 0, n_local
+    cnt = torch.tensor([n_local], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(cnt) for _ in range(dist.get_world_size())]
+    dist.all_gather(counts, cnt)
+    counts = [int(c.item()) for c in counts]
+    return sum(counts[: dist.get_rank()]), sum(counts)
+
+
+def get_rcps_metrics_from_outputs(model, out_dataset, rcps_loss_fn, device, sharded=False):
     """Metrics at the model's calibrated lhat (reference :31-60).  Returns
     (losses[N], sizes[N], spearman, stratified_risks[4], mse, spatial_miscoverage[H,W]).
     numpy/torch RNG is consumed in the reference's order (one np.random.choice per batch of 64, then one
-    torch.rand), so with the same seed the sampled-pixel statistics are the reference's."""
-    outputs, labels = _as_device_pair(out_dataset, device, model)
+    torch.rand), so with the same seed the sampled-pixel statistics are the reference's.
+
+    sharded=True (torch.distributed active): `out_dataset` holds only this rank's contiguous block of the evaluated set
+    (or None for an empty block).  Each rank scores its own images; the per-image rows are all-gathered in rank order
+    and the int32 per-pixel miss counts [C,H*W] are all-reduced, after which every rank evaluates the
+    same scalars.  The random pixels are drawn for the WHOLE set on every rank (same seed => same draws as one GPU)."""
+    dist = _dist() if sharded else None
     model = model.to(device)
     if model.lhat is None:
         raise Exception("You have to specify lambda unless your model is already calibrated.")
     lhat = float(model.lhat)
-    n = outputs.shape[0]
     form = sets_form(model)
     if form is None:
         raise NotImplementedError("get_rcps_metrics_from_outputs needs one of this package's nested-set functions")
-    k = outputs.shape[1]
-    losses = hip_ops.rcps_loss_table(outputs, labels, torch.tensor([lhat], dtype=torch.float32), form=form)[:, 0]
+    if out_dataset is not None:
+        outputs, labels = _as_device_pair(out_dataset, device, model)
+        n_loc = outputs.shape[0]
+        k, c = outputs.shape[1], outputs.shape[2]
+        p = outputs[0, 0].numel()
+        hw_shape = tuple(outputs.shape[3:])
+    else:
+        outputs = labels = None
+        n_loc = k = c = p = 0
+        hw_shape = ()
+    lo_row, n = shard_offset(n_loc, device) if dist is not None else (0, n_loc)
+    if dist is not None:                                      # an empty rank learns the image geometry from the others
+        geo = torch.tensor([c, p] + list(hw_shape) + [0] * (4 - len(hw_shape)), dtype=torch.int64, device=device)
+        dist.all_reduce(geo, op=dist.ReduceOp.MAX)
+        c, p = int(geo[0]), int(geo[1])
+        hw_shape = tuple(int(v) for v in geo[2:] if int(v) > 0)
     # one random pixel per image: interval size and |residual| (reference :43-46)
-    p = outputs[0, 0].numel()
     idx = np.concatenate([np.random.choice(p, size=min(64, n - s)) for s in range(0, n, 64)]) if n else np.zeros(0, int)
-    idx_t = torch.from_numpy(idx).to(device)
-    rows = torch.arange(n, device=device)
-    picked = outputs.flatten(start_dim=2)[rows, :, idx_t].reshape(n, k, 1).contiguous()        # [N,K,1]
-    lo, mid, up = hip_ops.nested_sets(picked, lhat, form=form)
-    sizes = (up - lo).reshape(n).cpu()
-    residuals = (labels.flatten(start_dim=1)[rows, idx_t] - mid.reshape(n)).abs()
+    if n_loc:
+        losses = hip_ops.rcps_loss_table(outputs, labels, torch.tensor([lhat], dtype=torch.float32), form=form)[:, 0]
+        idx_t = torch.from_numpy(idx[lo_row:lo_row + n_loc]).to(device)
+        rows = torch.arange(n_loc, device=device)
+        picked = outputs.flatten(start_dim=2)[rows, :, idx_t].reshape(n_loc, k, 1).contiguous()        # [N,K,1]
+        lo, mid, up = hip_ops.nested_sets(picked, lhat, form=form)
+        sizes = (up - lo).reshape(n_loc)
+        residuals = (labels.flatten(start_dim=1)[rows, idx_t] - mid.reshape(n_loc)).abs()
+        counts = hip_ops.rcps_miscoverage(outputs, labels, lhat, form=form)
+    else:
+        losses = sizes = residuals = torch.zeros((0,), dtype=torch.float32, device=device)
+        counts = torch.zeros((c, p), dtype=torch.int32, device=device)
+    if dist is not None:
+        rows3 = gather_rows(torch.stack([losses, sizes, residuals], dim=1), n)
+        losses, sizes, residuals = rows3[:, 0], rows3[:, 1], rows3[:, 2]
+        dist.all_reduce(counts)                               # integer per-pixel miss counts: exact in any order
+    sizes = sizes.cpu()
     # the reference iterates one DataLoader here, whose iterator draws its base seed from torch's default
     # generator (one int64 random_()); consume the same draw so the jitter below is the reference's.
     torch.empty((), dtype=torch.int64).random_()
@@ -139,8 +183,7 @@ def get_rcps_metrics_from_outputs(model, out_dataset, rcps_loss_fn, device):
     residuals = residuals.detach().cpu().numpy()
     spearman = spearmanr(residuals, sizes)[0]
     mse = (residuals * residuals).mean().item()
-    c = outputs.shape[2]
-    counts = hip_ops.rcps_miscoverage(outputs, labels, lhat, form=form).reshape((c,) + tuple(outputs.shape[3:]))
+    counts = counts.reshape((c,) + hw_shape)
     # reference: float32 mean over images, then float32 mean over the channel axis (:55)
     spatial_miscoverage = (counts.cpu().numpy().astype(np.float32) / np.float32(n)).mean(axis=0)
     size_bins = torch.tensor([0, torch.quantile(sizes, 0.25), torch.quantile(sizes, 0.5), torch.quantile(sizes, 0.75)])
@@ -247,9 +290,6 @@ def calibrate_model(model, dataset, config):
         lambdas = lambda_grid(config)
         rcps_loss_fn = get_rcps_loss_fn(config)
         model = model.to(device)
-        n_total = len(dataset) if config.get('dataset') != 'temca' else None
-        if getattr(dataset, "im2im_local_shard", False):      # caller already holds only this rank's shard
-            n_total = None
         outputs, labels = collect_outputs(model, dataset, config, device)
         dlambda = lambdas[1] - lambdas[0]
         model.set_lhat(lambdas[-1] + dlambda - 1e-9)
@@ -262,10 +302,7 @@ def calibrate_model(model, dataset, config):
             ds = TensorDataset(outputs, labels)
             table = torch.stack([get_rcps_losses_from_outputs(model, ds, rcps_loss_fn, lam - dlambda, device)
                                  for lam in lambdas], dim=1).to(device)
-        if _dist() is not None:
-            if n_total is None:                               # equal-size local shards
-                n_total = table.shape[0] * _dist().get_world_size()
-            table = gather_rows(table, n_total)
+        table = gather_rows(table)                            # row order = rank order = dataset order for contiguous shards
         lhat, calib_loss_table, trace = scan_loss_table(table.cpu(), lambdas, alpha, delta)
         model.set_lhat(lhat)
         j, rhat, rhat_plus = trace[-1]

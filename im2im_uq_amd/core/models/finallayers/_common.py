@@ -53,4 +53,7 @@ class TwoHeadLayer(nn.Module):
         if x.dtype in (torch.float32, torch.bfloat16) and x.permute(0, 2, 3, 1).is_contiguous():
             cdt = x.dtype                      # consume the trunk's channels-last feature map zero-copy
         a, b = (getattr(self, n) for n in self._names)
-        return nn_ops.Heads.apply(x, cdt, self._act, a.weight, a.bias, b.weight, b.bias)
+        out = nn_ops.Heads.apply(x, cdt, self._act, a.weight, a.bias, b.weight, b.bias)
+        if self._act == "relu":
+            out._im2im_var_nonneg = True       # lets gaussian_regression_loss_fn skip its per-step host sync
+        return out

@@ -14,8 +14,10 @@ class GaussianRegressionLayer(TwoHeadLayer):
 def gaussian_regression_loss_fn(pred, target, params):
     """nn.GaussianNLLLoss()(pred[:,0], target, pred[:,1])  (reference :19-23): mean(0.5*(log v + (mean-y)^2/v)),
     v = max(var, 1e-6), one fused reduction kernel forward, one elementwise kernel backward."""
-    if pred.is_cuda and bool((pred[:, 1] < 0).any()):
-        raise ValueError("var has negative entry/entries")          # torch.nn.functional.gaussian_nll_loss
+    # torch.nn.functional.gaussian_nll_loss rejects negative variances.  This package's own layer output is ReLU'd (tagged
+    # by TwoHeadLayer.forward), so the check -- a host sync -- only runs for tensors that come from somewhere else.
+    if pred.is_cuda and not getattr(pred, "_im2im_var_nonneg", False) and bool((pred[:, 1] < 0).any()):
+        raise ValueError("var has negative entry/entries")
     return packed_loss(pred, target, 2, nn_ops.LOSS_GAUSSIAN, who="gaussian_regression_loss_fn")
 
 

@@ -59,10 +59,14 @@ class DoubleConv(nn.Module):
                                               pool=(pool and ci == 3))
                 bn.num_batches_tracked += 1
             else:
-                if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad and False):
-                    raise NotImplementedError("eval-mode backward through the fused conv+BN kernel is not implemented")
+                needs_graph = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad or bn.weight.requires_grad)
                 x = nn_ops.conv_bn_relu_eval(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                                              bn.running_var, bn.eps, cdt, x_hi=x_hi)
+                if needs_graph:
+                    # the fused eval kernel has no backward: the forward works as in the reference, but the result is tied
+                    # to its inputs by a node that raises if anyone back-propagates through it (instead of silently
+                    # returning activations detached from the conv / BatchNorm weights)
+                    x = nn_ops.EvalModeBarrier.apply(x, conv.weight, bn.weight)
             x_hi = None
         if pool and not isinstance(x, tuple):
             x = (x, nn_ops.MaxPool2.apply(x))

@@ -16,53 +16,56 @@ from ._wandb import wandb
 
 
 def transform_output(x, self_normalize=True):
+    """tensor -> uint8 image (channels last when it has several): optional min-max stretch to [0,1], then 255*x clipped
+    to [0,255] and truncated (reference :14-22)."""
+    img = x.detach().to("cpu", torch.float32)
     if self_normalize:
-        x = x - x.min()
-        x = x / x.max()
-    x = np.maximum(0, np.minimum(255 * x.cpu().squeeze(), 255))
-    if len(x.shape) == 3:
-        x = x.permute(1, 2, 0)
-    return x.numpy().astype(np.uint8)
+        img = img - img.min()
+        img = img / img.max()
+    img = (255 * img.squeeze()).clamp(0, 255)
+    if img.dim() == 3:
+        img = img.permute(1, 2, 0)
+    return img.numpy().astype(np.uint8)
 
 
 def get_images(model, val_dataset, device, idx_iterator, config):
+    """Example panels of a few validation images (reference :24-84): the calibrated (or lam = 1 / 0.99) nested sets of
+    the selected images, as wandb images and, last, as the raw tensors that results_*.pkl stores (keys inputs / gt /
+    predictions / lower_edge / upper_edge).  The selected images go through the network as ONE batch (eval-mode outputs
+    do not depend on the batch composition); every returned list still has one [1,C,H,W] entry per image."""
+    picks = list(idx_iterator)
     with torch.no_grad():
         model = model.to(device)
         lam = None
-        if model.lhat == None:
-            lam = 1.0 if config["uncertainty_type"] != "softmax" else 0.99
-        try:
-            my_iter = iter(val_dataset)
-            val_dataset = [next(my_iter) for img_idx in idx_iterator]
-        except Exception:  # noqa: BLE001
-            pass
-        examples_output = [tuple(t.float() for t in model.nested_sets((val_dataset[img_idx][0].unsqueeze(0).to(device, torch.float32),), lam=lam))
-                           for img_idx in idx_iterator]
-        examples_gt = [val_dataset[img_idx][1] for img_idx in idx_iterator]
-        if val_dataset[0][0].shape[0] > 1:
-            inputs = [val_dataset[img_idx][0][0] for img_idx in idx_iterator]
-        else:
-            inputs = [val_dataset[img_idx][0] for img_idx in idx_iterator]
-        raw_images_dict = {'inputs': inputs, 'gt': examples_gt,
-                           'predictions': [example[1] for example in examples_output],
-                           'lower_edge': [example[0] for example in examples_output],
-                           'upper_edge': [example[2] for example in examples_output]}
-        examples_input = [wandb.Image(transform_output(i)) for i in inputs]
-        examples_lower_edge = [wandb.Image(transform_output(example[0])) for example in examples_output]
-        examples_prediction = [wandb.Image(transform_output(example[1])) for example in examples_output]
-        examples_upper_edge = [wandb.Image(transform_output(example[2])) for example in examples_output]
-        examples_ground_truth = [wandb.Image(transform_output(val_dataset[img_idx][1])) for img_idx in idx_iterator]
-        spans = [(e[1].max() - e[1].min()) for e in examples_output]
-        lower_lengths = [transform_output((e[1] - e[0]) / s, self_normalize=False) for e, s in zip(examples_output, spans)]
-        upper_lengths = [transform_output((e[2] - e[1]) / s, self_normalize=False) for e, s in zip(examples_output, spans)]
-        examples_lower_length = [wandb.Image(ll) for ll in lower_lengths]
-        examples_upper_length = [wandb.Image(ul) for ul in upper_lengths]
-        try:
-            val_dataset.reset()
-        except Exception:  # noqa: BLE001
-            pass
-        return (examples_input, examples_lower_edge, examples_prediction, examples_upper_edge, examples_ground_truth,
-                examples_lower_length, examples_upper_length, raw_images_dict)
+        if model.lhat is None:
+            lam = 0.99 if config["uncertainty_type"] == "softmax" else 1.0
+        if hasattr(val_dataset, "__getitem__"):
+            samples = {i: val_dataset[i] for i in picks}
+        else:                                                  # iterable dataset: the first len(picks) samples of the stream
+            stream = iter(val_dataset)
+            drawn = [next(stream) for _ in picks]
+            samples = {i: drawn[i] for i in picks}
+        x = torch.stack([samples[i][0] for i in picks]).to(device, torch.float32)
+        lower, pred, upper = (t.float() for t in model.nested_sets((x,), lam=lam))
+        per_image = [(lower[j:j + 1], pred[j:j + 1], upper[j:j + 1]) for j in range(len(picks))]
+        gt = [samples[i][1] for i in picks]
+        inputs = [samples[i][0][0] if samples[i][0].shape[0] > 1 else samples[i][0] for i in picks]
+        raw_images_dict = {'inputs': inputs, 'gt': gt, 'predictions': [e[1] for e in per_image],
+                           'lower_edge': [e[0] for e in per_image], 'upper_edge': [e[2] for e in per_image]}
+
+        def panel(tensors, **kw):
+            return [wandb.Image(transform_output(t, **kw)) for t in tensors]
+
+        span = [e[1].max() - e[1].min() for e in per_image]   # interval lengths are shown on the prediction's own scale
+        lower_len = panel([(e[1] - e[0]) / s for e, s in zip(per_image, span)], self_normalize=False)
+        upper_len = panel([(e[2] - e[1]) / s for e, s in zip(per_image, span)], self_normalize=False)
+        if hasattr(val_dataset, "reset"):
+            try:
+                val_dataset.reset()
+            except Exception:  # noqa: BLE001
+                pass
+        return (panel(inputs), panel(raw_images_dict['lower_edge']), panel(raw_images_dict['predictions']),
+                panel(raw_images_dict['upper_edge']), panel(gt), lower_len, upper_len, raw_images_dict)
 
 
 def _outputs_for(model, dataset, config, device):
@@ -85,16 +88,14 @@ def get_loss_table(model, dataset, config):
         model = model.to(device)
         outputs, labels = _outputs_for(model, dataset, config, device)
         form = sets_form(model)
-        if rcps_loss_fn is fraction_missed_loss and form is not None:
+        if outputs is None:                                   # empty shard of a multi-rank run (fewer images than ranks)
+            table = torch.zeros((0, lambdas.numel()), dtype=torch.float32, device=device)
+        elif rcps_loss_fn is fraction_missed_loss and form is not None:
             table = hip_ops.rcps_loss_table(outputs, labels, lambdas, form=form)
         else:
             ds = TensorDataset(outputs, labels)
             table = torch.stack([get_rcps_losses_from_outputs(model, ds, rcps_loss_fn, lam, device) for lam in lambdas], dim=1).to(device)
-        if _dist() is not None:
-            cnt = torch.tensor([table.shape[0]], device=table.device)
-            _dist().all_reduce(cnt)
-            table = gather_rows(table, int(cnt.item()))
-        return table.cpu()
+        return gather_rows(table).cpu()
 
 
 def eval_set_metrics(model, dataset, config):
@@ -110,9 +111,11 @@ def eval_set_metrics(model, dataset, config):
             dataset.reset()
         except Exception:  # noqa: BLE001
             pass
-        outputs, labels = collect_outputs(model, dataset, cfg, device, shard=False)
+        # with torch.distributed active every rank runs the forward over its own contiguous block of the set only; the
+        # per-image rows are gathered and the [H,W] miss counts all-reduced inside get_rcps_metrics_from_outputs
+        outputs, labels = collect_outputs(model, dataset, cfg, device, shard=True)
         losses, sizes, spearman, stratified_risks, mse, spatial_miscoverage = get_rcps_metrics_from_outputs(
-            model, TensorDataset(outputs, labels), rcps_loss_fn, device)
+            model, TensorDataset(outputs, labels) if outputs is not None else None, rcps_loss_fn, device, sharded=True)
         return losses.mean(), sizes, spearman, stratified_risks, mse, spatial_miscoverage
 
 

@@ -48,21 +48,160 @@ class DataParallelPassthrough(nn.Module):
             return getattr(self.module, name)
 
 
+class GradSync:
+    """Gradient exchange of data-parallel training (replaces nn.DataParallel's reduce-to-GPU0, reference :112-115).
+
+    All parameter gradients live in ONE pre-allocated flat fp32 buffer; every `p.grad` is a permanent view into it, so
+    autograd accumulates straight into the buffer and nothing is concatenated or copied per step.  The buffer is cut
+    into buckets in reverse registration order (the order backward produces gradients); a post-accumulate hook counts a
+    bucket's parameters down and launches its all-reduce (RCCL, asynchronous, on the communicator's own stream) the
+    moment the last one is written, so the exchange of the decoder's gradients runs under the encoder's backward.
+    `finish()` launches whatever is left, waits, and the optimizer reads the reduced views.
+
+    Sum, not mean: the caller scales its loss by (local images / global images), so the summed gradients are the
+    gradient of the global-batch mean loss even when the global batch does not divide evenly over the ranks.
+    With one rank the class only provides the flat buffer (zero_grad = one memset)."""
+
+    def __init__(self, params, bucket_bytes=8 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.dist = _dist()
+        dev = self.params[0].device
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        off = 0
+        self.buckets = []                       # [lo, hi) element ranges, first bucket = last parameters
+        self.bucket_of = {}
+        spans = []
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            spans.append((off, off + p.numel()))
+            off += p.numel()
+        hi = off
+        members = []
+        for i in range(len(self.params) - 1, -1, -1):
+            members.append(i)
+            if (hi - spans[i][0]) * 4 >= bucket_bytes or i == 0:
+                b = len(self.buckets)
+                self.buckets.append((spans[i][0], hi))
+                for m in members:
+                    self.bucket_of[m] = b
+                members, hi = [], spans[i][0]
+        self.expected = None                    # per bucket: how many parameters receive a gradient (learnt on step 1)
+        self.seen = [0] * len(self.buckets)
+        self.fired = set()
+        self.launched = [None] * len(self.buckets)
+        self.handles = []
+        if self.dist is not None:
+            for i, p in enumerate(self.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(_p):
+            b = self.bucket_of[i]
+            self.fired.add(i)
+            self.seen[b] += 1
+            if self.expected is not None and self.seen[b] == self.expected[b] and self.launched[b] is None:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        lo, hi = self.buckets[b]
+        self.launched[b] = self.dist.all_reduce(self.flat[lo:hi], async_op=True)
+
+    def zero_grad(self):
+        self.flat.zero_()
+        for p, (lo, hi) in zip(self.params, self._spans()):
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * lo:      # someone re-pointed it (zero_grad(set_to_none))
+                p.grad = self.flat[lo:hi].view_as(p)
+
+    def _spans(self):
+        off = 0
+        for p in self.params:
+            yield off, off + p.numel()
+            off += p.numel()
+
+    def finish(self):
+        """call after backward(): every bucket reduced and visible to the current stream."""
+        if self.dist is None:
+            return
+        for b in range(len(self.buckets)):      # buckets no hook completed (first step, unused parameters, no local images)
+            if self.launched[b] is None:
+                self._launch(b)
+        for h in self.launched:
+            h.wait()
+        if self.expected is None:
+            exp = [0] * len(self.buckets)
+            for i in self.fired:
+                exp[self.bucket_of[i]] += 1
+            self.expected = [e if e > 0 else -1 for e in exp]
+        self.seen = [0] * len(self.buckets)
+        self.fired = set()
+        self.launched = [None] * len(self.buckets)
+
+
 def allreduce_gradients(params):
-    """average gradients over ranks with one flat all-reduce (17.27 M fp32 = 69 MB for the reference model);
-    afterwards each p.grad is a view into the flat buffer."""
+    """one-shot form of GradSync for callers that keep torch's own .grad tensors: average the gradients over ranks
+    in place, bucket by bucket (no flat copy)."""
     dist = _dist()
     if dist is None:
         return
-    params = [p for p in params if p.grad is not None]
-    flat = torch.cat([p.grad.reshape(-1).to(torch.float32) for p in params])
-    dist.all_reduce(flat)
-    flat /= dist.get_world_size()
-    off = 0
+    world = dist.get_world_size()
+    handles = []
     for p in params:
-        n = p.numel()
-        p.grad = flat[off:off + n].view_as(p)
-        off += n
+        if p.grad is not None:
+            handles.append(dist.all_reduce(p.grad, async_op=True))
+    for h in handles:
+        h.wait()
+    for p in params:
+        if p.grad is not None:
+            p.grad /= world
+
+
+def broadcast_module_state(net, src=0):
+    """rank `src`'s parameters and buffers to every rank (what DistributedDataParallel does at construction; the
+    reference's DataParallel re-broadcasts them every step, :22-27): training starts from ONE model even when the
+    caller did not seed the ranks identically."""
+    dist = _dist()
+    if dist is None:
+        return
+    with torch.no_grad():
+        for t in list(net.parameters()) + list(net.buffers()):
+            if t.numel():
+                dist.broadcast(t.data, src=src)
+
+
+class GlobalBatchSampler(torch.utils.data.Sampler):
+    """batch sampler of one rank: every rank walks the SAME (seeded) order of the dataset in global batches of
+    `batch_size` (the reference's DataLoader batches, train.py:104) and takes its contiguous slice of each; slices
+    differ by at most one image, so a global batch of 78 on 8 ranks is 10+10+10+10+10+10+9+9, never 72.
+    Yields (possibly empty) index lists; `global_sizes` has the size of each global batch."""
+
+    def __init__(self, n, batch_size, rank, world, shuffle=True, seed=0):
+        self.n, self.batch_size, self.rank, self.world, self.shuffle, self.seed = n, batch_size, rank, world, shuffle, seed
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        return (self.n + self.batch_size - 1) // self.batch_size
+
+    @staticmethod
+    def share(count, rank, world):
+        base, rem = divmod(count, world)
+        lo = rank * base + min(rank, rem)
+        return lo, lo + base + (1 if rank < rem else 0)
+
+    def __iter__(self):
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed + self.epoch)
+            order = torch.randperm(self.n, generator=g).tolist()
+        else:
+            order = list(range(self.n))
+        for s in range(0, self.n, self.batch_size):
+            batch = order[s:s + self.batch_size]
+            lo, hi = self.share(len(batch), self.rank, self.world)
+            yield batch[lo:hi]
 
 
 def _ckpt_name(checkpoint_dir, epoch, config):
@@ -122,20 +261,24 @@ def train_net(net, train_dataset, val_dataset, device, epochs, batch_size, lr, l
     dist = _dist()
     world = dist.get_world_size() if dist else 1
     rank = dist.get_rank() if dist else 0
-    local_bs = max(1, batch_size // world)                   # the global batch is split over ranks, as DataParallel does
     sampler = None
+    iterable = False
     try:
         if dist:
-            from torch.utils.data.distributed import DistributedSampler
-            sampler = DistributedSampler(train_dataset, num_replicas=world, rank=rank, shuffle=True, seed=0)
-            train_loader = DataLoader(train_dataset, batch_size=local_bs, sampler=sampler, num_workers=0)
+            # the global batch is split over ranks, as DataParallel's scatter does (remainder images go to the first ranks)
+            sampler = GlobalBatchSampler(len(train_dataset), batch_size, rank, world, shuffle=True, seed=0)
+            train_loader = None
         else:
             train_loader = DataLoader(train_dataset, batch_size=batch_size, shuffle=True, num_workers=0)
     except Exception:  # noqa: BLE001  (iterable datasets cannot be shuffled, reference :105-106)
-        train_loader = DataLoader(train_dataset, batch_size=local_bs, shuffle=False, num_workers=0)
+        # with several ranks every rank reads the same global batches from the stream and keeps its slice of each
+        iterable = True
+        sampler = None
+        train_loader = DataLoader(train_dataset, batch_size=batch_size, shuffle=False, num_workers=0)
     val_loader = DataLoader(val_dataset, batch_size=batch_size, shuffle=False, num_workers=0)
 
     net = net.to(device=device)
+    broadcast_module_state(net)                              # every rank starts from rank 0's weights and BatchNorm buffers
     optimizer = nn_ops.FusedAdam(net.parameters(), lr=lr)    # torch.optim.Adam defaults, reference :120
     if starting_epoch == 0:
         try:
@@ -144,7 +287,7 @@ def train_net(net, train_dataset, val_dataset, device, epochs, batch_size, lr, l
             wandb.init(config=config)
             wandb.watch(net, log_freq=100)
 
-    params = [p for p in net.parameters() if p.requires_grad]
+    sync = GradSync(net.parameters()) if dist else None
     print("Start Training!")
     for epoch in range(starting_epoch, epochs):
         net = net.to(device)
@@ -154,22 +297,50 @@ def train_net(net, train_dataset, val_dataset, device, epochs, batch_size, lr, l
         print('epoch ' + str(epoch + 1) + '\n')
         epoch_loss = torch.zeros((), dtype=torch.float64, device=device)
         num_examples = 0
-        for batch in train_loader:
+        if sampler is not None:
+            collate = torch.utils.data.default_collate
+            batches = ((collate([train_dataset[i] for i in idx]) if idx else None, min(batch_size, len(train_dataset) - k * batch_size))
+                       for k, idx in enumerate(sampler))
+        elif dist and iterable:
+            def _sliced():
+                for b in train_loader:
+                    n_glob = b[-1].shape[0]
+                    lo, hi = GlobalBatchSampler.share(n_glob, rank, world)
+                    yield ([t[lo:hi] for t in b] if hi > lo else None), n_glob
+            batches = _sliced()
+        else:
+            batches = ((b, None) for b in train_loader)
+        for batch, global_n in batches:
+            if batch is None:                                # this rank's share of a short last batch is empty: it still joins the exchange
+                sync.zero_grad(); sync.finish(); optimizer.step()
+                global_step += 1
+                continue
             labels = batch[-1].to(device=device)
             x = tuple([batch[i].to(device=device, dtype=torch.float32) for i in range(len(batch) - 1)])
 
             labels_pred = net(*x)
             loss = net.loss_fn(labels_pred, labels)
-            epoch_loss += loss.detach()
 
-            optimizer.zero_grad()
-            loss.backward()
-            allreduce_gradients(params)
+            if sync is None:
+                epoch_loss += loss.detach()
+                optimizer.zero_grad()
+                loss.backward()
+            else:
+                # summed over ranks, (n_local / n_global) * local mean == the global batch mean DataParallel's GPU-0 loss is
+                weight = labels.shape[0] / global_n if global_n else 1.0 / world
+                epoch_loss += loss.detach() * weight
+                sync.zero_grad()
+                (loss * weight).backward()
+                sync.finish()
             optimizer.step()
 
             global_step += 1
             num_examples += labels.shape[0]
 
+        if dist:                                             # the logged quantity is the global one (sum of batch-mean losses / #examples)
+            tot = torch.stack([epoch_loss, torch.tensor(float(num_examples), dtype=torch.float64, device=device)])
+            dist.all_reduce(tot)
+            epoch_loss, num_examples = tot[0], int(tot[1].item())
         wandb.log({"iter": global_step, "train_loss": epoch_loss.item() / max(num_examples, 1)})
 
         with torch.no_grad():

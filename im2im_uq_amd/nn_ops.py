@@ -515,6 +515,20 @@ def conv_bn_relu_eval(x, weight, bias, gamma, beta, running_mean, running_var, e
                          x_hi=nhwc(x_hi.detach(), cdt) if x_hi is not None else None))
 
 
+class EvalModeBarrier(torch.autograd.Function):
+    """identity in the forward; its backward raises: marks the output of a fused eval-mode conv+BatchNorm (which records no
+    autograd graph) so that back-propagating through it fails loudly instead of yielding no / partial gradients."""
+
+    @staticmethod
+    def forward(ctx, y, *deps):
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError("eval-mode backward through the fused conv+BatchNorm kernel is not implemented: "
+                                  "run inference under torch.no_grad(), or put the block in train() mode to fine-tune")
+
+
 class MaxPool2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -955,8 +969,7 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         for group in self.param_groups:
-            ps, gs, ms, vs = [], [], [], []
-            step = None
+            by_step = {}                      # bias correction is per parameter (torch.optim.Adam): one launch per distinct step count
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -968,21 +981,19 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
-                step = st["step"]
                 g = p.grad
                 if g.dtype != F32 or not g.is_contiguous():
                     g = g.to(F32).contiguous()
                 if not p.is_contiguous():
                     raise _lib.Im2ImError("FusedAdam: non-contiguous parameter")
-                ps.append(p); gs.append(g); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"])
-            if not ps:
-                continue
-            n = len(ps)
-            arr = ctypes.c_void_p * n
-            sizes = (ctypes.c_int64 * n)(*[p.numel() for p in ps])
+                by_step.setdefault(int(st["step"]), []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
             b1, b2 = group["betas"]
-            check(lib.im2im_adam_step(n, arr(*[p.data_ptr() for p in ps]), arr(*[g.data_ptr() for g in gs]),
-                                      arr(*[m.data_ptr() for m in ms]), arr(*[v.data_ptr() for v in vs]), sizes,
-                                      float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(step),
-                                      stream_ptr(ps[0].device)), "im2im_adam_step")
+            for step, items in by_step.items():
+                n = len(items)
+                arr = ctypes.c_void_p * n
+                sizes = (ctypes.c_int64 * n)(*[it[0].numel() for it in items])
+                check(lib.im2im_adam_step(n, arr(*[it[0].data_ptr() for it in items]), arr(*[it[1].data_ptr() for it in items]),
+                                          arr(*[it[2].data_ptr() for it in items]), arr(*[it[3].data_ptr() for it in items]), sizes,
+                                          float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(step),
+                                          stream_ptr(items[0][0].device)), "im2im_adam_step")
         return loss

@@ -1,0 +1,149 @@
+"""Numerics of the N > 1 path on real GPU tensors: two ranks (gloo, sharing the test box's one GPU -- RCCL refuses
+duplicate devices; the collectives' call sites are the same ones the nccl backend runs) against an oracle that emulates
+what the reference's nn.DataParallel computes (train.py:112-115,152-160): per-replica BatchNorm batch statistics, the loss
+of the gathered batch, gradients summed onto one set of weights.  Also: the sharded eval_set_metrics (per-rank forward +
+row all-gather + int miss-map all-reduce) equals the single-process result bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+PARAMS = dict(uncertainty_type="quantiles", q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1,
+              alpha=0.1, delta=0.1, num_lambdas=50, rcps_loss="fraction_missed", minimum_lambda=0, maximum_lambda=6,
+              device=DEV, dataset="synthetic", batch_size=5, lr=1e-3, input_normalization="standard",
+              output_normalization="min-max", num_validation_images=2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _data():
+    g = torch.Generator().manual_seed(21)
+    return torch.randn(5, 1, 64, 64, generator=g), torch.rand(5, 1, 64, 64, generator=g)
+
+
+def _build():
+    from im2im_uq_amd import nn_ops
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from im2im_uq_amd.core.models.trunks.unet import UNet
+    from oracle import model as om
+    nn_ops.set_compute_dtype("fp32")
+    model = add_uncertainty(UNet(1, 1), dict(PARAMS))
+    model.load_state_dict(om.det_state(1, 1))
+    return model.to(DEV)
+
+
+def _worker(rank, world, port, tmpdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from im2im_uq_amd import nn_ops
+        from im2im_uq_amd.core.calibration.calibrate_model import calibrate_model
+        from im2im_uq_amd.core.scripts.eval import eval_set_metrics
+        from im2im_uq_amd.core.scripts.train import GlobalBatchSampler, GradSync, broadcast_module_state, train_net
+        from torch.utils.data import TensorDataset
+        x, y = _data()
+        model = _build().train()
+        if rank == 1:                                         # a rank that was not seeded like rank 0 ...
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.add_(0.01)
+        broadcast_module_state(model)                         # ... is overwritten with rank 0's weights
+        sync = GradSync(model.parameters())
+        lo, hi = GlobalBatchSampler.share(5, rank, world)     # 3 + 2 images
+        sync.zero_grad()
+        loss = model.loss_fn(model(x[lo:hi].to(DEV)), y[lo:hi].to(DEV))
+        (loss * ((hi - lo) / 5)).backward()
+        sync.finish()
+        grads = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}
+        torch.save({"grads": grads, "loss": float(loss)}, os.path.join(tmpdir, f"step_{rank}.pt"))
+        # train_net end to end under two ranks: both ranks must hold the same weights afterwards
+        net = _build()
+        ds = TensorDataset(x, y)
+        cfg = dict(PARAMS)
+        net = train_net(net, ds, ds, DEV, 2, 5, 1e-3, False, None, 100, 100, cfg)
+        flat = torch.cat([p.detach().flatten() for p in net.parameters()])
+        both = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1])
+        # sharded calibration + metrics
+        net, table = calibrate_model(net, ds, dict(cfg, batch_size=2))
+        torch.manual_seed(0); np.random.seed(0)
+        risk, sizes, spearman, strat, mse, spatial = eval_set_metrics(net, ds, cfg)
+        torch.save({"state": {k: v.cpu() for k, v in net.state_dict().items()}, "table": table, "lhat": float(net.lhat),
+                    "risk": float(risk), "sizes": sizes, "spatial": spatial, "mse": mse}, os.path.join(tmpdir, f"eval_{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_step_matches_dataparallel_oracle_and_sharded_metrics_match_single_process(tmp_path):
+    from oracle import model as om
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "step_0.pt")
+    r1 = torch.load(tmp_path / "step_1.pt")
+    for k in r0["grads"]:
+        assert torch.equal(r0["grads"][k], r1["grads"][k])                    # both ranks hold the reduced gradient
+    # oracle: replicas with their own BatchNorm statistics, loss of the gathered batch = sum_r (n_r / N) * mean_r
+    x, y = _data()
+
+    def oracle(dtype):
+        st = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in om.det_state(1, 1).items()}
+        leaves = {k: v.clone().requires_grad_(True) for k, v in st.items() if om.is_param(k)}
+        total = 0.0
+        for lo, hi in ((0, 3), (3, 5)):
+            work = dict(st); work.update(leaves)              # replicas share the weights, not the batch statistics
+            pred = om.model_forward(x[lo:hi].to(dtype), work, training=True)
+            total = total + om.quantile_loss(pred, y[lo:hi].to(dtype), PARAMS) * ((hi - lo) / 5)
+        total.backward()
+        return float(total), {k: v.grad for k, v in leaves.items()}
+
+    l32, g32 = oracle(torch.float32)
+    _, g64 = oracle(torch.float64)
+    assert r0["loss"] * 3 / 5 + r1["loss"] * 2 / 5 == pytest.approx(l32, rel=2e-5)
+    bad = {}
+    for k, g in r0["grads"].items():
+        if ".double_conv.0.bias" in k or ".double_conv.3.bias" in k:
+            assert float(g.abs().max()) == 0.0
+            continue
+        e_hip, e_ref = rel_l2(g, g64[k]), rel_l2(g32[k], g64[k])
+        if e_hip > 3.0 * e_ref + 5e-4:                        # same yardstick as test_backward_gradients_vs_oracle_fp32
+            bad[k] = (e_hip, e_ref)
+    assert not bad, bad
+    # sharded evaluation == the same model evaluated by ONE process
+    e0, e1 = torch.load(tmp_path / "eval_0.pt", weights_only=False), torch.load(tmp_path / "eval_1.pt", weights_only=False)
+    assert e0["lhat"] == e1["lhat"] and torch.equal(e0["table"], e1["table"])
+    assert e0["risk"] == e1["risk"] and np.array_equal(e0["spatial"], e1["spatial"])
+    from im2im_uq_amd import nn_ops
+    from im2im_uq_amd.core.calibration.calibrate_model import calibrate_model
+    from im2im_uq_amd.core.scripts.eval import eval_set_metrics
+    from torch.utils.data import TensorDataset
+    try:
+        single = _build()
+        single.load_state_dict(e0["state"])
+        cfg = dict(PARAMS)
+        ds = TensorDataset(x, y)
+        single, table = calibrate_model(single, ds, dict(cfg, batch_size=2))
+        torch.manual_seed(0); np.random.seed(0)
+        risk, sizes, spearman, strat, mse, spatial = eval_set_metrics(single, ds, cfg)
+    finally:
+        nn_ops.set_compute_dtype("bf16")
+    assert float(single.lhat) == e0["lhat"] and torch.equal(table, e0["table"])
+    assert float(risk) == e0["risk"] and np.array_equal(spatial, e0["spatial"]) and torch.equal(sizes, e0["sizes"])

@@ -389,6 +389,26 @@ def test_fused_adam_matches_torch_adam():
         np.testing.assert_allclose(p.detach().cpu().numpy(), pr.detach().numpy(), rtol=2e-6, atol=2e-7)
 
 
+def test_fused_adam_bias_correction_is_per_parameter():
+    """a parameter that starts receiving gradients later (unfrozen, or unused at first) has its own step count in
+    torch.optim.Adam; FusedAdam launches once per distinct step count so its bias correction matches."""
+    from im2im_uq_amd import nn_ops
+    ps_ref = [rnd(40, 3, seed=1).requires_grad_(True), rnd(17, seed=2).requires_grad_(True)]
+    ps = [p.detach().clone().to(DEV).requires_grad_(True) for p in ps_ref]
+    o_ref, o = torch.optim.Adam(ps_ref, lr=1e-2), nn_ops.FusedAdam(ps, lr=1e-2)
+    for step in range(5):
+        for i, (pr, p) in enumerate(zip(ps_ref, ps)):
+            if i == 1 and step < 3:
+                pr.grad, p.grad = None, None             # no gradient during the first three steps
+                continue
+            g = rnd(*pr.shape, seed=10 * step + i)
+            pr.grad, p.grad = g.clone(), g.to(DEV)
+        o_ref.step(); o.step()
+    assert int(o.state[ps[0]]["step"]) == 5 and int(o.state[ps[1]]["step"]) == 2
+    for pr, p in zip(ps_ref, ps):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), pr.detach().numpy(), rtol=2e-6, atol=2e-7)
+
+
 def test_inn_loss_class_matches_formula():
     """losses/inn.py mirror: INNLoss(beta)(lower, upper, target), mean and sum reductions, value and gradients."""
     from im2im_uq_amd.core.models.losses.inn import INNLoss

@@ -680,3 +680,18 @@ def test_wnet_trunk_trains_bf16():
     with torch.no_grad():
         out = model(x.to(DEV))
     assert out.shape == (2, 3, 1, 64, 48) and bool(torch.isfinite(out).all())
+
+
+def test_eval_mode_forward_works_with_grad_enabled_and_backward_raises():
+    """model.eval(); model(x) outside torch.no_grad() works as in the reference; back-propagating through the fused
+    eval-mode conv+BatchNorm (which has no backward) raises instead of silently dropping the weight gradients."""
+    model = build(1, "fp32")
+    model.eval()
+    from oracle import model as om
+    x, _ = om.det_images(2, 1, 32, 32, salt=1)
+    out = model(x.to(DEV))
+    with torch.no_grad():
+        ref = model(x.to(DEV))
+    assert torch.equal(out.detach(), ref)
+    with pytest.raises(NotImplementedError):
+        out.sum().backward()
