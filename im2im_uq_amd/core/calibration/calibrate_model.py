@@ -194,18 +194,23 @@ def get_rcps_metrics_from_outputs(model, out_dataset, rcps_loss_fn, device, shar
 
 
 def evaluate_from_loss_table(loss_table, n, alpha, delta):
-    """Monte-Carlo re-split of a saved loss table (reference :62-74; note it compares against `delta`)."""
+    """Monte-Carlo re-split of a saved loss table (reference :62-74): shuffle the rows, calibrate on the first n, return
+    the mean validation loss at the first lambda whose Hoeffding-Bentkus bound is <= `delta` (sic: the reference compares
+    against delta, not alpha -- kept).  The num_lambdas bounds are solved in one multi-threaded C++ call
+    (im2im_hb_mu_plus_batch) instead of one scipy root-find per lambda; like the reference's list of Python floats they
+    are compared as float32."""
     with torch.no_grad():
         perm = torch.randperm(loss_table.shape[0])
         loss_table = loss_table[perm]
         calib_table, val_table = loss_table[:n], loss_table[n:]
         Rhats = calib_table.mean(dim=0)
-        RhatPlus = torch.tensor([HB_mu_plus(Rhat, n, delta) for Rhat in Rhats])
-        try:
-            idx_lambda = (RhatPlus <= delta).nonzero()[0]
-        except Exception:
+        RhatPlus = hip_ops.hb_mu_plus_batch(Rhats, n, delta).to(torch.float32)
+        hits = (RhatPlus <= delta).nonzero()
+        if hits.numel() == 0:
             print("No rejections made!")
             idx_lambda = 0
+        else:
+            idx_lambda = hits[0]
         return val_table[:, idx_lambda].mean()
 
 

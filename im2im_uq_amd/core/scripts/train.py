@@ -156,15 +156,17 @@ def allreduce_gradients(params):
             p.grad /= world
 
 
-def broadcast_module_state(net, src=0):
+def broadcast_module_state(net, src=0, buffers_only=False):
     """rank `src`'s parameters and buffers to every rank (what DistributedDataParallel does at construction; the
     reference's DataParallel re-broadcasts them every step, :22-27): training starts from ONE model even when the
-    caller did not seed the ranks identically."""
+    caller did not seed the ranks identically.  buffers_only: just the BatchNorm running statistics -- every rank
+    updates them from its own share of the batch during an epoch; DataParallel keeps only device 0's, so before anything
+    evaluates or saves the model the ranks adopt rank 0's."""
     dist = _dist()
     if dist is None:
         return
     with torch.no_grad():
-        for t in list(net.parameters()) + list(net.buffers()):
+        for t in ([] if buffers_only else list(net.parameters())) + list(net.buffers()):
             if t.numel():
                 dist.broadcast(t.data, src=src)
 
@@ -343,6 +345,7 @@ def train_net(net, train_dataset, val_dataset, device, epochs, batch_size, lr, l
             epoch_loss, num_examples = tot[0], int(tot[1].item())
         wandb.log({"iter": global_step, "train_loss": epoch_loss.item() / max(num_examples, 1)})
 
+        broadcast_module_state(net, buffers_only=True)      # BatchNorm running statistics: rank 0's, as DataParallel keeps device 0's
         with torch.no_grad():
             if (epoch) % validate_every == 0:
                 run_validation(net, val_loader, val_dataset, device, global_step, epoch, config)

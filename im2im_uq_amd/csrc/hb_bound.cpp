@@ -9,9 +9,12 @@
 //     bisection) with scipy's default xtol = 2e-12, rtol = 4*eps.
 // Python-level semantics that matter are kept: builtin min/max NaN behaviour, and "any solver
 // exception -> 1.0" (NaN function value, same-sign bracket, no convergence).
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <limits>
+#include <thread>
+#include <vector>
 #include "../../include/im2im_uq.h"
 
 namespace {
@@ -66,13 +69,15 @@ inline double py_max(double a, double b) { return (b > a) ? b : a; }  // builtin
 
 struct Tail {
   double muhat, n, log_delta;
+  double k = 0.0;            // floor(n * muhat) supplied by the caller (batch form: the reference's fp32 product)
+  bool has_k = false;
   // _tailprob, bounds.py:18-21
   double operator()(double mu) const {
     double y = std::fmin(mu, muhat);                       // np.minimum(mu, x)  (bounds.py:11)
     if (std::isnan(mu) || std::isnan(muhat)) y = std::numeric_limits<double>::quiet_NaN();
     double h1 = y * std::log(y / mu) + (1.0 - y) * std::log((1.0 - y) / (1.0 - mu));   // bounds.py:7
     double hoeffding = -n * h1;
-    double bentkus = std::log(py_max(binom_cdf(std::floor(n * muhat), n, mu), 1e-10)) + 1.0;  // bounds.py:14
+    double bentkus = std::log(py_max(binom_cdf(has_k ? k : std::floor(n * muhat), n, mu), 1e-10)) + 1.0;  // bounds.py:14
     return py_min(hoeffding, bentkus) - log_delta;
   }
 };
@@ -133,4 +138,35 @@ extern "C" double im2im_hb_mu_plus(double muhat, int64_t n, double delta, int32_
   bool ok = false;
   double root = brentq(f, muhat, hi, 2e-12, 4.0 * std::numeric_limits<double>::epsilon(), maxiters, ok);
   return ok ? root : 1.0;                                    // bounds.py:25-29
+}
+
+// A whole row of bounds at once (evaluate_from_loss_table, core/calibration/calibrate_model.py:62-74, solves one per lambda,
+// and experiments/fastmri_test/plot.py:126-139 repeats that 100 times): muhat[i] are float32 empirical risks as the reference
+// holds them (0-dim fp32 tensors), so floor(n * muhat) is taken on the fp32 product like `np.floor(n * muhat)` there; the
+// solves are independent and are spread over host threads.
+extern "C" int im2im_hb_mu_plus_batch(const float* muhat, int64_t count, int64_t n, double delta, int32_t maxiters,
+                                      double* out) {
+  if (!muhat || !out || count < 0 || n <= 0) return -1;
+  auto solve = [&](int64_t i) {
+    const float m32 = muhat[i];
+    Tail f{(double)m32, (double)n, std::log(delta)};
+    f.k = std::floor((double)((float)n * m32));
+    f.has_k = true;
+    const double hi = 1.0 - 1e-10;
+    if (f(hi) > 0.0) { out[i] = 1.0; return; }
+    bool ok = false;
+    const double root = brentq(f, (double)m32, hi, 2e-12, 4.0 * std::numeric_limits<double>::epsilon(), maxiters, ok);
+    out[i] = ok ? root : 1.0;
+  };
+  unsigned hw = std::thread::hardware_concurrency();
+  const int64_t nthreads = std::max<int64_t>(1, std::min<int64_t>({(int64_t)(hw ? hw : 1), (int64_t)16, count / 8}));
+  if (nthreads == 1) {
+    for (int64_t i = 0; i < count; ++i) solve(i);
+    return 0;
+  }
+  std::vector<std::thread> pool;
+  for (int64_t t = 0; t < nthreads; ++t)
+    pool.emplace_back([&, t]() { for (int64_t i = t; i < count; i += nthreads) solve(i); });
+  for (auto& th : pool) th.join();
+  return 0;
 }

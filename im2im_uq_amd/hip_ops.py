@@ -124,3 +124,12 @@ def fraction_missed(lower: torch.Tensor, upper: torch.Tensor, label: torch.Tenso
 
 def hb_mu_plus(muhat: float, n: int, delta: float, maxiters: int = 1000) -> float:
     return float(lib.im2im_hb_mu_plus(float(muhat), int(n), float(delta), int(maxiters)))
+
+
+def hb_mu_plus_batch(muhat: torch.Tensor, n: int, delta: float, maxiters: int = 1000) -> torch.Tensor:
+    """float64 [count] Hoeffding-Bentkus bounds of a vector of float32 empirical risks (host, multi-threaded)."""
+    m = muhat.detach().to("cpu", F32).contiguous().reshape(-1)
+    out = torch.empty((m.numel(),), dtype=torch.float64)
+    check(lib.im2im_hb_mu_plus_batch(m.data_ptr(), m.numel(), int(n), float(delta), int(maxiters), out.data_ptr()),
+          "im2im_hb_mu_plus_batch")
+    return out

@@ -100,6 +100,12 @@ int im2im_fraction_missed(const float* lower_edge, const float* upper_edge, cons
  * solver exception" path (muhat == 0 -> NaN, Q3). */
 double im2im_hb_mu_plus(double muhat, int64_t n, double delta, int32_t maxiters);
 
+/* `count` bounds at once, spread over host threads; replaces the per-lambda list comprehension of
+ * evaluate_from_loss_table, core/calibration/calibrate_model.py:69 (driven 100 x num_lambdas times by
+ * experiments/fastmri_test/plot.py:126-139).  muhat are the float32 empirical risks as the reference holds them:
+ * floor(n * muhat) is taken on the fp32 product like np.floor(n * muhat) on a 0-dim fp32 tensor.  out [count] float64. */
+int im2im_hb_mu_plus_batch(const float* muhat, int64_t count, int64_t n, double delta, int32_t maxiters, double* out);
+
 /* ---------------------------------------------------------------------------------------------
  * Convolution by MFMA implicit GEMM.  Activations are NHWC, element type `dtype`.
  * Replaces nn.Conv2d 3x3 pad 1 (core/models/trunks/unet_parts.py:16,19) and 1x1 (:90) and their

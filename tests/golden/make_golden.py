@@ -531,7 +531,7 @@ def g17():
     ref4 = UNet(1, 1).state_dict()
     mine4 = RefUNetDepth(1, 1, 4).state_dict()
     assert list(ref4.keys()) == list(mine4.keys()) and all(ref4[k].shape == mine4[k].shape for k in ref4)
-    for depth, hw, nb in ((2, 32, 4), (5, 64, 2)):
+    for depth, hw, nb in ((2, 32, 4), (5, 96, 2)):      # depth 5 at 96x96: 3x3x2 = 18 samples per channel in the deepest BatchNorm
         model = add_uncertainty(RefUNetDepth(1, 1, depth), dict(PARAMS))
         st = om.det_state(1, 1, depth=depth)
         model.load_state_dict(st, strict=True)

@@ -74,7 +74,7 @@ def _worker(rank, world, port, tmpdir):
         (loss * ((hi - lo) / 5)).backward()
         sync.finish()
         grads = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}
-        torch.save({"grads": grads, "loss": float(loss)}, os.path.join(tmpdir, f"step_{rank}.pt"))
+        torch.save({"grads": grads, "loss": float(loss.detach())}, os.path.join(tmpdir, f"step_{rank}.pt"))
         # train_net end to end under two ranks: both ranks must hold the same weights afterwards
         net = _build()
         ds = TensorDataset(x, y)
@@ -113,7 +113,7 @@ def test_two_rank_step_matches_dataparallel_oracle_and_sharded_metrics_match_sin
             pred = om.model_forward(x[lo:hi].to(dtype), work, training=True)
             total = total + om.quantile_loss(pred, y[lo:hi].to(dtype), PARAMS) * ((hi - lo) / 5)
         total.backward()
-        return float(total), {k: v.grad for k, v in leaves.items()}
+        return float(total.detach()), {k: v.grad for k, v in leaves.items()}
 
     l32, g32 = oracle(torch.float32)
     _, g64 = oracle(torch.float64)
@@ -123,10 +123,29 @@ def test_two_rank_step_matches_dataparallel_oracle_and_sharded_metrics_match_sin
         if ".double_conv.0.bias" in k or ".double_conv.3.bias" in k:
             assert float(g.abs().max()) == 0.0
             continue
+        # yardstick as in test_backward_gradients_vs_oracle_fp32 (distance to the float64 truth vs the fp32 oracle's own),
+        # plus a budget of 1e-2: on this data the fp32 oracle happens to take every ReLU / max-pool decision like float64
+        # does (e_ref ~ 6e-6), while ONE decision taken the other way by a different fp32 summation order moves a deep
+        # layer's gradient by ~4e-3 (tools/debug_grad.py).  A wrong replica weight or a lost replica is a >= 10 % error.
         e_hip, e_ref = rel_l2(g, g64[k]), rel_l2(g32[k], g64[k])
-        if e_hip > 3.0 * e_ref + 5e-4:                        # same yardstick as test_backward_gradients_vs_oracle_fp32
+        if e_hip > 3.0 * e_ref + 1e-2:
             bad[k] = (e_hip, e_ref)
     assert not bad, bad
+    # the exchange itself, exactly: the same two replicas run one after the other by ONE process, gradients accumulated with
+    # the same weights, must give the same bits as the two ranks' all-reduced sum (deterministic kernels, a + b == b + a)
+    from im2im_uq_amd import nn_ops as _nn
+    try:
+        seq = _build().train()
+        for lo, hi in ((0, 3), (3, 5)):
+            l = seq.loss_fn(seq(x[lo:hi].to(DEV)), y[lo:hi].to(DEV))
+            (l * ((hi - lo) / 5)).backward()
+        for k, p in seq.named_parameters():
+            if p.grad is None:
+                assert float(r0["grads"][k].abs().max()) == 0.0
+            else:
+                assert torch.equal(p.grad.cpu(), r0["grads"][k]), k
+    finally:
+        _nn.set_compute_dtype("bf16")
     # sharded evaluation == the same model evaluated by ONE process
     e0, e1 = torch.load(tmp_path / "eval_0.pt", weights_only=False), torch.load(tmp_path / "eval_1.pt", weights_only=False)
     assert e0["lhat"] == e1["lhat"] and torch.equal(e0["table"], e1["table"])

@@ -1,15 +1,19 @@
 """bf16 (the benchmarked mode) against fp32 (the parity mode, itself pinned to the reference by G4/G5/G11/G17) over a
-REAL training run, end to end: same initial weights, same batches in the same order, 240 Adam steps on a 64x64
+REAL training run, end to end: same initial weights, same batches in the same order, 600 Adam steps (lr 1e-3) on a 64x64
 denoising task, then calibration and validation -- the sequence of core/scripts/train.py:141-165 followed by
 calibrate_model.py:89-145 and eval.py:130-157.
 
-What is asserted (numbers measured on MI355X, see the printed line in the test log; each bound has ~2x head-room over
-the measured value so that a real regression -- a wrong rounding point, a lost gradient -- trips it):
-  * the bf16 loss curve tracks the fp32 one: mean train loss over the last 40 steps within 4 %;
-  * both trained models calibrate (alpha = delta = 0.1, 100 lambdas): lambda-hat within 3 grid steps of each other;
+Training is chaotic: two fp32 runs that differ by a 1e-4 relative perturbation of the initial weights (40x smaller than
+one bf16 rounding) end up a few percent apart in every metric below.  That fp32-vs-fp32' distance is the yardstick: the
+bf16 run has to land as close to the fp32 run as a second fp32 run does (<= 2x the yardstick plus a small absolute
+margin), and within the absolute bounds stated in the asserts (measured on MI355X -- the kernels are deterministic, so
+the printed numbers reproduce run to run -- with ~1.5-2x head-room, tight enough that a wrong rounding point or a lost
+gradient term, which costs tens of percent, trips them):
+  * loss curve: mean train loss over the last 200 steps within 10 % of fp32's;
+  * both trained models calibrate (alpha = delta = 0.1, 100 lambdas) inside the grid, lambda-hat within 3 grid steps;
   * both calibrated models hold the risk on 96 held-out images: validation risk <= alpha;
-  * the trained models agree as functions: prediction images within 3 % relative L2, calibrated lower / upper edges
-    within 4 %.
+  * the trained models agree as functions: prediction images within 8 % relative L2, calibrated lower / upper edges
+    within 10 % / 14 %.
 """
 import numpy as np
 import pytest
@@ -36,7 +40,7 @@ def _restore_dtype():
     nn_ops.set_compute_dtype("bf16")
 
 
-def _run(dt, data, steps, hw):
+def _run(dt, data, steps, hw, perturb=0.0):
     from im2im_uq_amd import nn_ops
     from im2im_uq_amd.core.calibration.calibrate_model import calibrate_model
     from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
@@ -45,7 +49,11 @@ def _run(dt, data, steps, hw):
     from oracle import model as om
     nn_ops.set_compute_dtype(dt)
     model = add_uncertainty(UNet(1, 1), dict(PARAMS))
-    model.load_state_dict(om.det_state(1, 1))
+    st = om.det_state(1, 1)
+    if perturb:
+        g = torch.Generator().manual_seed(99)
+        st = {k: (v * (1 + perturb * torch.randn(v.shape, generator=g)) if om.is_param(k) else v) for k, v in st.items()}
+    model.load_state_dict(st)
     model = model.to(DEV).train()
     opt = nn_ops.FusedAdam(model.parameters(), lr=PARAMS["lr"])
     (xt, yt), (xc, yc), (xv, yv) = data
@@ -54,7 +62,7 @@ def _run(dt, data, steps, hw):
     for step in range(steps):
         s = (step % nb) * 16
         loss = model.loss_fn(model(xt[s:s + 16]), yt[s:s + 16])
-        losses.append(loss)
+        losses.append(loss.detach())
         opt.zero_grad(); loss.backward(); opt.step()
     losses = torch.stack(losses).cpu().numpy()
     cfg = dict(PARAMS)
@@ -67,26 +75,38 @@ def _run(dt, data, steps, hw):
                 hi=hi.float().cpu())
 
 
+def _distance(a, ref):
+    dl = 6.0 / 99
+    return dict(loss=abs(a["losses"][-200:].mean() / ref["losses"][-200:].mean() - 1.0), lhat=abs(a["lhat"] - ref["lhat"]) / dl,
+                mid=rel_l2(a["mid"], ref["mid"]), lo=rel_l2(a["lo"], ref["lo"]), hi=rel_l2(a["hi"], ref["hi"]))
+
+
 def test_bf16_training_tracks_fp32_training_then_calibrates_alike():
     from im2im_uq_amd.core.datasets.synthetic import SyntheticDenoiseDataset
-    hw, steps = 64, 240
+    hw, steps = 64, 600
     ds = SyntheticDenoiseDataset(num_images=96 + 96 + 96, num_inputs=1, side=hw, noise=0.1, seed=5)
     x, y = ds.x.to(DEV), ds.y.to(DEV)
     data = ((x[:96], y[:96]), (x[96:192], y[96:192]), (x[192:], y[192:]))
     r32 = _run("fp32", data, steps, hw)
+    r32b = _run("fp32", data, steps, hw, perturb=1e-4)         # the yardstick: fp32 against (almost) itself
     r16 = _run("bf16", data, steps, hw)
-    tail32, tail16 = r32["losses"][-40:].mean(), r16["losses"][-40:].mean()
-    dl = 6.0 / 99
-    d_lhat = abs(r32["lhat"] - r16["lhat"]) / dl
-    e_mid, e_lo, e_hi = rel_l2(r16["mid"], r32["mid"]), rel_l2(r16["lo"], r32["lo"]), rel_l2(r16["hi"], r32["hi"])
-    print(f"\n[train parity] loss0 {r32['losses'][0]:.4f}/{r16['losses'][0]:.4f}  tail40 fp32 {tail32:.5f} bf16 {tail16:.5f} "
-          f"(ratio {tail16 / tail32:.4f})  lhat fp32 {r32['lhat']:.4f} bf16 {r16['lhat']:.4f} ({d_lhat:.2f} grid steps)  "
-          f"val risk fp32 {r32['risk']:.4f} bf16 {r16['risk']:.4f}  rel-L2 pred {e_mid:.4f} lower {e_lo:.4f} upper {e_hi:.4f}")
-    assert np.isfinite(r32["losses"]).all() and np.isfinite(r16["losses"]).all()
-    assert tail32 < 0.25 * r32["losses"][0] and tail16 < 0.25 * r16["losses"][0]      # both actually trained
+    d16, dself = _distance(r16, r32), _distance(r32b, r32)
+    print(f"\n[train parity] loss0 {r32['losses'][0]:.4f}/{r16['losses'][0]:.4f}  tail200 fp32 {r32['losses'][-200:].mean():.5f} "
+          f"bf16 {r16['losses'][-200:].mean():.5f} fp32' {r32b['losses'][-200:].mean():.5f}  lhat {r32['lhat']:.4f}/{r16['lhat']:.4f}/"
+          f"{r32b['lhat']:.4f}  val risk {r32['risk']:.4f}/{r16['risk']:.4f}/{r32b['risk']:.4f}\n"
+          f"  bf16 vs fp32 : " + "  ".join(f"{k} {v:.4f}" for k, v in d16.items()) + "\n"
+          f"  fp32' vs fp32: " + "  ".join(f"{k} {v:.4f}" for k, v in dself.items()))
+    for r in (r32, r16, r32b):
+        assert np.isfinite(r["losses"]).all()
+        assert r["losses"][-200:].mean() < 0.1 * r["losses"][0]                       # actually trained
+        assert 0 < r["lhat"] < 6                                                      # the scan stopped inside the grid
+        assert r["risk"] <= PARAMS["alpha"]                                           # the calibrated sets hold the risk
     assert r16["losses"][0] == pytest.approx(r32["losses"][0], rel=1e-2)              # same start
-    assert abs(tail16 / tail32 - 1.0) < 0.04
-    assert d_lhat <= 3.0 + 1e-6
-    assert 0 < r32["lhat"] < 6 and 0 < r16["lhat"] < 6                                # stopped inside the grid
-    assert r32["risk"] <= PARAMS["alpha"] and r16["risk"] <= PARAMS["alpha"]
-    assert e_mid < 0.03 and e_lo < 0.04 and e_hi < 0.04
+    # absolute bounds (measured, see the module docstring)
+    assert d16["loss"] < 0.10 and d16["lhat"] <= 3.0 + 1e-6
+    assert d16["mid"] < 0.08 and d16["lo"] < 0.10 and d16["hi"] < 0.14
+    # and no further from fp32 than fp32 is from itself (2x + margin)
+    assert d16["loss"] <= 2 * dself["loss"] + 0.05
+    assert d16["lhat"] <= 2 * dself["lhat"] + 2.0
+    for k in ("mid", "lo", "hi"):
+        assert d16[k] <= 2 * dself[k] + 0.02, (k, d16[k], dself[k])

@@ -43,8 +43,9 @@ def rel_l2(a, b):
 @pytest.mark.parametrize("depth", [2, 5])
 def test_g17_forward_loss_gradients_fp32(depth):
     """fp32 parity mode vs the reference parts: outputs atol 5e-4, loss 5e-5 relative, running statistics 1e-3, and the
-    sampled parameter gradients within 2 % of the tensor's RMS (re-association noise of an fp32 network whose
-    BatchNorm sees as few as 8 samples per channel at the bottom level)."""
+    sampled parameter gradients (256 strided entries per tensor) within 3 % relative L2 for the worst tensor, 0.5 % for the
+    median one, norms within 2 % (re-association noise of an fp32 network whose deepest BatchNorm sees 18-32 samples
+    per channel; see test_backward_gradients_vs_oracle_fp32 for the float64 yardstick on the default depth)."""
     g = load_golden(f"g17_unet_depth{depth}")
     model = build(depth, "fp32")
     x, y = T(g["x"]).to(DEV), T(g["y"]).to(DEV)
@@ -62,17 +63,16 @@ def test_g17_forward_loss_gradients_fp32(depth):
     for k in g:
         if k.startswith("state."):
             np.testing.assert_allclose(sd[k[len("state."):]].cpu().numpy(), g[k], rtol=1e-3, atol=1e-5)
-    worst = 0.0
+    errs = {}
     for name, p in model.named_parameters():
         if ".double_conv.0.bias" in name or ".double_conv.3.bias" in name:
             continue                                      # conv bias before train-mode BatchNorm: analytically zero
         gr = p.grad.flatten().cpu()
-        sample = gr[::max(1, gr.numel() // 256)][:256].numpy()
-        rms = float(g["gnorm." + name]) / np.sqrt(gr.numel())
-        err = np.abs(sample - g["gsample." + name]).max() / (rms + 1e-30)
-        worst = max(worst, err)
+        sample = gr[::max(1, gr.numel() // 256)][:256]
+        errs[name] = rel_l2(sample, g["gsample." + name])
         assert float(gr.double().norm()) == pytest.approx(float(g["gnorm." + name]), rel=2e-2), name
-    assert worst < 0.05, worst
+    assert max(errs.values()) < 3e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    assert float(np.median(list(errs.values()))) < 5e-3
 
 
 def test_g17_depth2_adam_and_calibration_fp32():
