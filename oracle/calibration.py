@@ -41,6 +41,20 @@ def hb_mu_plus(muhat, n, delta, maxiters=1000):
         return 1.0
 
 
+def evaluate_from_loss_table(loss_table, n, alpha, delta):
+    """core/calibration/calibrate_model.py:62-74: shuffle the rows (torch RNG), calibrate on the first n, return the mean
+    validation loss at the first lambda whose bound is <= delta (sic).  The reference hands HB_mu_plus 0-dim fp32 tensors
+    and builds `torch.tensor([...])` (float32) from the results; both kept."""
+    perm = torch.randperm(loss_table.shape[0])
+    loss_table = loss_table[perm]
+    calib_table, val_table = loss_table[:n], loss_table[n:]
+    rhats = calib_table.mean(dim=0)
+    rhat_plus = torch.tensor([hb_mu_plus(np.float32(r.item()), n, delta) for r in rhats])
+    hits = (rhat_plus <= delta).nonzero()
+    idx = hits[0] if hits.numel() else 0
+    return val_table[:, idx].mean()
+
+
 # ------------------------------------------------------- nested sets / loss
 def lambda_grid(cfg, utype="quantiles"):
     """calibrate_model.py:97-100 / eval.py:92-95: fp32 linspace (softmax has its own lambda range keys)."""

@@ -163,6 +163,24 @@ def unet_forward(x, state, training: bool, emulate_bf16=False):
     return _store(out, emulate_bf16)
 
 
+def wnet_forward(x, state, training: bool, emulate_bf16=False):
+    """core/models/trunks/wnet.py:40-66: two half-width encoders, one per input channel, concatenated level by level and
+    decoded by the UNet's Up blocks."""
+    feats = {}
+    for path, ch in (("p1", 0), ("p2", 1)):
+        h = double_conv(x[:, ch:ch + 1], state, path + "inc", training, emulate_bf16)
+        feats[path] = [h]
+        for i in range(1, 5):
+            h = double_conv(F.max_pool2d(h, 2), state, f"{path}down{i}.maxpool_conv.1", training, emulate_bf16)
+            feats[path].append(h)
+    join = [torch.cat((a, b), dim=1) for a, b in zip(feats["p1"], feats["p2"])]
+    h = join[4]
+    for i in range(1, 5):
+        h = up_block(h, join[4 - i], state, f"up{i}.conv", training, emulate_bf16)
+    out = F.conv2d(h, _operand(state["baseModel.out.conv.weight"], emulate_bf16), state["baseModel.out.conv.bias"])
+    return _store(out, emulate_bf16)
+
+
 def quantile_heads(feat, state):
     """three 3x3 heads stacked on a new dim 1 -> [B,3,C,H,W], quantile_layer.py:19-21."""
     outs = [F.conv2d(feat, state[f"last_layer.{h}.weight"], state[f"last_layer.{h}.bias"], padding=1)

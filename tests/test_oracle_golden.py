@@ -283,3 +283,87 @@ def test_g17_unet_of_other_depths(depth):
         st2 = om.det_state(1, 1, depth=2)
         losses = om.train_steps(st2, [(x, y)] * 5, PARAMS, lr=1e-3)
         np.testing.assert_allclose(losses, g["adam_losses"], rtol=2e-4)
+
+
+def test_g15_evaluate_from_loss_table():
+    """oracle and the C-ABI batch bound against the reference's evaluate_from_loss_table (4 re-splits incl. 'no lambda
+    qualifies') and its per-lambda HB_mu_plus values on 0-dim fp32 risks."""
+    g = load_golden("g15_evaluate_from_loss_table")
+    table = T(g["table"])
+    for (n, alpha, delta), want, hb in zip(g["cases"], g["values"], g["hb"]):
+        n = int(n)
+        torch.manual_seed(n)
+        got = oc.evaluate_from_loss_table(table, n, alpha, delta)
+        assert float(got) == pytest.approx(float(want), rel=1e-6, abs=1e-9)
+        torch.manual_seed(n)
+        rh = table[torch.randperm(table.shape[0])][:n].mean(dim=0)
+        mine = np.array([oc.hb_mu_plus(np.float32(r.item()), n, delta) for r in rh], dtype=np.float64)
+        np.testing.assert_allclose(mine, hb, rtol=0, atol=2e-7)        # the reference evaluates h1 on fp32 operands
+
+
+def test_g15_batch_bound_through_the_c_abi():
+    """im2im_hb_mu_plus_batch (host C++, no GPU needed) and the drop-in evaluate_from_loss_table built on it."""
+    from im2im_uq_amd import hip_ops
+    from im2im_uq_amd.core.calibration.calibrate_model import evaluate_from_loss_table
+    g = load_golden("g15_evaluate_from_loss_table")
+    table = T(g["table"])
+    for (n, alpha, delta), want, hb in zip(g["cases"], g["values"], g["hb"]):
+        n = int(n)
+        torch.manual_seed(n)
+        rh = table[torch.randperm(table.shape[0])][:n].mean(dim=0)
+        got = hip_ops.hb_mu_plus_batch(rh, n, delta).numpy()
+        np.testing.assert_allclose(got, hb, rtol=0, atol=2e-7)
+        torch.manual_seed(n)
+        val = evaluate_from_loss_table(table, n, alpha, delta)
+        assert float(val) == pytest.approx(float(want), rel=1e-6, abs=1e-9)
+
+
+def test_g16_wnet():
+    g = load_golden("g16_wnet")
+    keys = [str(k) for k in g["keys"]]
+    from oracle.model import det_fill
+    shapes = _wnet_shapes()
+    assert [k for k in keys if k != "lhat"] == list(shapes)
+    st = {k: det_fill(k, shp) for k, shp in shapes.items()}
+    x, y = T(g["x"]), T(g["y"])
+    with torch.no_grad():
+        out = om.final_layer(om.wnet_forward(x, st, training=False), st)
+    np.testing.assert_allclose(out.numpy(), g["out_eval"], rtol=1e-4, atol=1e-5)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in st.items() if om.is_param(k)}
+    work = dict(st); work.update(leaves)
+    pred = om.final_layer(om.wnet_forward(x, work, training=True), work)
+    np.testing.assert_allclose(pred.detach().numpy(), g["out_train"], rtol=1e-4, atol=2e-5)
+    loss = om.quantile_loss(pred, y, PARAMS)
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-5)
+    loss.backward()
+    for k in ("baseModel.p1inc.double_conv.0.weight", "baseModel.p2down4.maxpool_conv.1.double_conv.3.weight", "baseModel.up1.conv.double_conv.0.weight"):
+        gr = leaves[k].grad.flatten()
+        np.testing.assert_allclose(gr[::max(1, gr.numel() // 256)][:256].numpy(), g["gsample." + k], rtol=2e-3,
+                                   atol=2e-3 * float(g["gnorm." + k]) / np.sqrt(gr.numel()))
+
+
+def _wnet_shapes():
+    """state_dict (key -> shape) of add_uncertainty(WNet(1, 1), quantiles) in the reference's registration order
+    (wnet.py:19-38; pinned against the fixture's recorded keys)."""
+    shapes = {}
+
+    def dc(prefix, cin, cmid, cout):
+        p = f"baseModel.{prefix}.double_conv"
+        for idx, (ci, co) in ((0, (cin, cmid)), (3, (cmid, cout))):
+            shapes[f"{p}.{idx}.weight"] = (co, ci, 3, 3)
+            shapes[f"{p}.{idx}.bias"] = (co,)
+            for nm in ("weight", "bias", "running_mean", "running_var"):
+                shapes[f"{p}.{idx + 1}.{nm}"] = (co,)
+            shapes[f"{p}.{idx + 1}.num_batches_tracked"] = ()
+    for path in ("p1", "p2"):
+        dc(path + "inc", 1, 32, 32)
+        for i, (ci, co) in enumerate(((32, 64), (64, 128), (128, 256), (256, 256)), 1):
+            dc(f"{path}down{i}.maxpool_conv.1", ci, co, co)
+    for i, (ci, co) in enumerate(((1024, 256), (512, 128), (256, 64), (128, 64)), 1):
+        dc(f"up{i}.conv", ci, ci // 2, co)
+    shapes["baseModel.out.conv.weight"] = (32, 64, 1, 1)
+    shapes["baseModel.out.conv.bias"] = (32,)
+    for h in ("lower", "prediction", "upper"):
+        shapes[f"last_layer.{h}.weight"] = (1, 32, 3, 3)
+        shapes[f"last_layer.{h}.bias"] = (1,)
+    return shapes

@@ -138,3 +138,42 @@ def test_configs3_deeper_unet_1024_tile_row_vs_cpu_fp32():
         out = model(x.to(DEV))
         ref = om.model_forward(x, om.det_state(1, 1, depth=5), training=False)
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=5e-4)
+
+
+def test_g16_wnet_forward_loss_gradients_fp32():
+    """WNet (core/models/trunks/wnet.py:9-59) on the HIP kernels vs the reference's WNet (fixture G16: 2-channel 64x64
+    input, eval + train forward, loss, every parameter gradient, running statistics).  Same tolerances as G17."""
+    from im2im_uq_amd import nn_ops
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from im2im_uq_amd.core.models.trunks.wnet import WNet
+    from oracle import model as om
+    g = load_golden("g16_wnet")
+    nn_ops.set_compute_dtype("fp32")
+    model = add_uncertainty(WNet(1, 1), dict(PARAMS))
+    assert list(model.state_dict().keys()) == [str(k) for k in g["keys"] if str(k) != "lhat"]
+    model.load_state_dict({k: om.det_fill(k, tuple(v.shape)) for k, v in model.state_dict().items()})
+    model = model.to(DEV)
+    x, y = T(g["x"]).to(DEV), T(g["y"]).to(DEV)
+    model.eval()
+    with torch.no_grad():
+        out = model(x)
+    np.testing.assert_allclose(out.cpu().numpy(), g["out_eval"], rtol=0, atol=3e-4)
+    model.train()
+    pred = model(x)
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g["out_train"], rtol=0, atol=5e-4)
+    loss = model.loss_fn(pred, y)
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=5e-5)
+    loss.backward()
+    sd = model.state_dict()
+    for k in g:
+        if k.startswith("state."):
+            np.testing.assert_allclose(sd[k[len("state."):]].cpu().numpy(), g[k], rtol=1e-3, atol=1e-5)
+    errs = {}
+    for name, p in model.named_parameters():
+        if ".double_conv.0.bias" in name or ".double_conv.3.bias" in name:
+            continue
+        gr = p.grad.flatten().cpu()
+        errs[name] = rel_l2(gr[::max(1, gr.numel() // 256)][:256], g["gsample." + name])
+        assert float(gr.double().norm()) == pytest.approx(float(g["gnorm." + name]), rel=2e-2), name
+    assert max(errs.values()) < 3e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    assert float(np.median(list(errs.values()))) < 5e-3
