@@ -28,18 +28,18 @@ def unet_plan(n_channels_in, depth=4, base=64, bilinear=True):
 
 
 class UNet(nn.Module):
-    def __init__(self, n_channels_in, n_channels_out, bilinear=True, depth=4, base=64):
+    def __init__(self, n_channels_in, n_channels_out, bilinear=True, depth=4, base=64, norm="batch"):
         super(UNet, self).__init__()
         self.n_channels_in, self.n_channels_middle, self.n_channels_out = n_channels_in, 32, n_channels_out
         self.bilinear = bilinear
-        self.depth, self.base = depth, base
+        self.depth, self.base, self.norm = depth, base, norm      # norm="group": GroupNorm instead of BatchNorm2d (extra)
         for name, kind, cin, cout in unet_plan(n_channels_in, depth, base, bilinear):   # registration order == state_dict order
             if kind == "inc":
-                setattr(self, name, DoubleConv(cin, cout))
+                setattr(self, name, DoubleConv(cin, cout, norm=norm))
             elif kind == "down":
-                setattr(self, name, Down(cin, cout))
+                setattr(self, name, Down(cin, cout, norm=norm))
             else:
-                setattr(self, name, Up(cin, cout, bilinear))
+                setattr(self, name, Up(cin, cout, bilinear, norm=norm))
         self.out = OutConv(base, self.n_channels_middle)
 
     def forward(self, x):

@@ -27,16 +27,24 @@ def _cdt(module):
 class DoubleConv(nn.Module):
     """(convolution => [BN] => ReLU) * 2   (reference :8-25)"""
 
-    def __init__(self, in_channels, out_channels, mid_channels=None):
+    def __init__(self, in_channels, out_channels, mid_channels=None, norm="batch", groups=32):
+        """norm="batch" is the reference's block.  norm="group" (a build-side extra named by the north star)
+        puts nn.GroupNorm(min(groups, channels), channels) where the reference has BatchNorm2d."""
         super().__init__()
         if not mid_channels:
             mid_channels = out_channels
+        if norm not in ("batch", "group"):
+            raise ValueError(f"norm must be 'batch' or 'group', got {norm!r}")
+        self.norm = norm
+
+        def make_norm(ch):
+            return nn.BatchNorm2d(ch) if norm == "batch" else nn.GroupNorm(min(groups, ch), ch)
         self.double_conv = nn.Sequential(
             nn.Conv2d(in_channels, mid_channels, kernel_size=3, padding=1),
-            nn.BatchNorm2d(mid_channels),
+            make_norm(mid_channels),
             nn.ReLU(inplace=True),
             nn.Conv2d(mid_channels, out_channels, kernel_size=3, padding=1),
-            nn.BatchNorm2d(out_channels),
+            make_norm(out_channels),
             nn.ReLU(inplace=True)
         )
         self.compute_dtype = None
@@ -52,7 +60,14 @@ class DoubleConv(nn.Module):
         cdt = _cdt(self)
         for ci, bi in ((0, 1), (3, 4)):
             conv, bn = self.double_conv[ci], self.double_conv[bi]
-            if self.training:
+            if getattr(self, "norm", "batch") == "group":
+                # GroupNorm: per-image statistics from the conv epilogue, applied lazily by the block's second conv; the
+                # block's own result is materialised (the pooling / upsampling / skip consumers take plain tensors)
+                if x_hi is not None:
+                    x = torch.cat([nn_ops.materialize(x), nn_ops.materialize(x_hi)], dim=1)
+                x = nn_ops.conv_gn_relu(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.num_groups, bn.eps, cdt,
+                                        lazy_out=(ci == 0))
+            elif self.training:
                 momentum = bn.momentum if bn.momentum is not None else 0.1
                 x = nn_ops.conv_bn_relu_train(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                                               bn.running_var, momentum, bn.eps, cdt, lazy_out=(lazy or ci == 0), x_hi=x_hi,
@@ -81,11 +96,11 @@ class _MaxPool2(nn.Module):
 class Down(nn.Module):
     """Downscaling with maxpool then double conv   (reference :28-40)"""
 
-    def __init__(self, in_channels, out_channels):
+    def __init__(self, in_channels, out_channels, norm="batch"):
         super().__init__()
         self.maxpool_conv = nn.Sequential(
             _MaxPool2(),
-            DoubleConv(in_channels, out_channels)
+            DoubleConv(in_channels, out_channels, norm=norm)
         )
 
     def forward(self, x, lazy=False, pool=False, pooled=False):
@@ -106,14 +121,14 @@ class _BilinearUp(nn.Module):
 class Up(nn.Module):
     """Upscaling then double conv   (reference :42-69)"""
 
-    def __init__(self, in_channels, out_channels, bilinear=True):
+    def __init__(self, in_channels, out_channels, bilinear=True, norm="batch"):
         super().__init__()
         if bilinear:
             self.up = _BilinearUp()
-            self.conv = DoubleConv(in_channels, out_channels, in_channels // 2)
+            self.conv = DoubleConv(in_channels, out_channels, in_channels // 2, norm=norm)
         else:
             self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)   # parameter container
-            self.conv = DoubleConv(in_channels, out_channels)
+            self.conv = DoubleConv(in_channels, out_channels, norm=norm)
         self.compute_dtype = None
 
     def forward(self, x1, x2, lazy=False):

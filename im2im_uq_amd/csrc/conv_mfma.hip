@@ -54,6 +54,9 @@ struct ConvArgs {
   const float* bn_ss;   // [2][Co] scale, shift
   const float* bn_mi;   // [2][Co] mean, invstd
   float* bn_partial;
+  // GroupNorm producers have one (scale, shift) pair per IMAGE and channel: in_ss then points at [B][2][Ci] and this is the
+  // stride between images (2*Ci); 0 = one pair per channel for the whole batch (BatchNorm).  Needs one image per tile.
+  int in_ss_img;
 };
 
 template <typename T> struct Frag;
@@ -199,7 +202,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   if (lazy_lo || lazy_hi) {
     // ldsSS = [scale over the Ci logical channels][shift ...]; a source without coefficients is never looked up
     const int clo = split_in ? a.Ci_lo : a.Ci, chi = a.Ci - clo;
-    if (lazy_lo) for (int i = tid; i < clo; i += 256) { ldsSS[i] = a.in_ss[i]; ldsSS[a.Ci + i] = a.in_ss[clo + i]; }
+    const float* __restrict__ ss_lo = a.in_ss + (size_t)b0 * a.in_ss_img;      // per-image coefficients (GroupNorm): TB == 1
+    if (lazy_lo) for (int i = tid; i < clo; i += 256) { ldsSS[i] = ss_lo[i]; ldsSS[a.Ci + i] = ss_lo[clo + i]; }
     if (lazy_hi) for (int i = tid; i < chi; i += 256) { ldsSS[clo + i] = a.in_ss_hi[i]; ldsSS[a.Ci + clo + i] = a.in_ss_hi[chi + i]; }
     __syncthreads();
   }
@@ -895,8 +899,8 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
 // pixel-tile shape per problem: 16x16 for the large-extent levels, 8x8 (8x16 when Cout == 32) for the
 // deep, small-extent ones (40x40, 20x20) so that little of a tile hangs over the image edge.
 struct TileChoice { int tb, th, tw, bn; };
-inline TileChoice pick_tile(int H, int W, int Co) {
-  const bool small = (H < 64 || W < 64);
+inline TileChoice pick_tile(int H, int W, int Co, bool per_image = false) {
+  const bool small = (H < 64 || W < 64) && !per_image;       // per_image: every tile (and its statistics row) lies in ONE image
   const int bn = (Co % 128 == 0) ? 128 : (Co % 64 == 0) ? 64 : 32;
   if (!small) return {1, 16, 16, bn};
   // small extents: an 8x8 patch of FOUR consecutive images per tile, so a weight tile is still amortised over
@@ -905,8 +909,8 @@ inline TileChoice pick_tile(int H, int W, int Co) {
 }
 
 template <typename T, int TAPS>
-int dispatch_conv(const ConvArgs& a, hipStream_t stream) {
-  const TileChoice t = pick_tile(a.H, a.W, a.Co);
+int dispatch_conv(const ConvArgs& a, hipStream_t stream, bool per_image = false) {
+  const TileChoice t = pick_tile(a.H, a.W, a.Co, per_image);
   if (t.tb == 1) {
     if (t.bn == 128) return launch_conv<T, 1, 16, 16, 128, 2, 2, TAPS>(a, stream);
     if (t.bn == 64) return launch_conv<T, 1, 16, 16, 64, 4, 1, TAPS>(a, stream);
@@ -924,6 +928,8 @@ extern "C" int64_t im2im_conv_stats_rows(int32_t B, int32_t H, int32_t W, int32_
   return im2im::cdiv(B, t.tb) * im2im::cdiv(H, t.th) * im2im::cdiv(W, t.tw);
 }
 
+extern "C" int64_t im2im_conv_tiles_per_image(int32_t H, int32_t W) { return im2im::cdiv(H, 16) * im2im::cdiv(W, 16); }
+
 extern "C" int im2im_conv_fwd(const void* x, const float* in_scale_shift, const void* w, const float* bias, const float* center,
                               const float* scale, const float* shift, void* y, float* stats, int32_t B, int32_t H, int32_t W,
                               int32_t Ci, int32_t Co, int32_t taps, int32_t relu, int32_t dtype, im2im_stream_t stream_) {
@@ -931,11 +937,34 @@ extern "C" int im2im_conv_fwd(const void* x, const float* in_scale_shift, const 
                               Ci, Co, taps, relu, dtype, stream_);
 }
 
+namespace {
+int conv_fwd_impl(const void* x, const float* in_scale_shift, int in_ss_img, bool per_image, const void* x_hi,
+                  const float* in_scale_shift_hi, int32_t Ci_lo, const void* w, const float* bias, const float* center,
+                  const float* scale, const float* shift, void* y, void* y_hi, int32_t Co_lo, float* stats, int32_t B, int32_t H,
+                  int32_t W, int32_t Ci, int32_t Co, int32_t taps, int32_t relu, int32_t dtype, im2im_stream_t stream_);
+}
+
+extern "C" int im2im_conv_fwd_per_image(const void* x, const float* in_scale_shift_per_image, const void* w, const float* bias,
+                                        void* y, float* stats, int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                                        int32_t taps, int32_t dtype, im2im_stream_t stream_) {
+  return conv_fwd_impl(x, in_scale_shift_per_image, in_scale_shift_per_image ? 2 * Ci : 0, true, nullptr, nullptr, Ci, w, bias,
+                       nullptr, nullptr, nullptr, y, nullptr, Co, stats, B, H, W, Ci, Co, taps, 0, dtype, stream_);
+}
+
 extern "C" int im2im_conv_fwd_split(const void* x, const float* in_scale_shift, const void* x_hi, const float* in_scale_shift_hi,
                                     int32_t Ci_lo, const void* w, const float* bias, const float* center, const float* scale,
                                     const float* shift, void* y, void* y_hi, int32_t Co_lo, float* stats, int32_t B, int32_t H,
                                     int32_t W, int32_t Ci, int32_t Co, int32_t taps, int32_t relu, int32_t dtype,
                                     im2im_stream_t stream_) {
+  return conv_fwd_impl(x, in_scale_shift, 0, false, x_hi, in_scale_shift_hi, Ci_lo, w, bias, center, scale, shift, y, y_hi, Co_lo,
+                       stats, B, H, W, Ci, Co, taps, relu, dtype, stream_);
+}
+
+namespace {
+int conv_fwd_impl(const void* x, const float* in_scale_shift, int in_ss_img, bool per_image, const void* x_hi,
+                  const float* in_scale_shift_hi, int32_t Ci_lo, const void* w, const float* bias, const float* center,
+                  const float* scale, const float* shift, void* y, void* y_hi, int32_t Co_lo, float* stats, int32_t B, int32_t H,
+                  int32_t W, int32_t Ci, int32_t Co, int32_t taps, int32_t relu, int32_t dtype, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(x && w && y);
   if (x_hi) {
@@ -958,11 +987,13 @@ extern "C" int im2im_conv_fwd_split(const void* x, const float* in_scale_shift, 
   IM2IM_REQUIRE((scale == nullptr) == (shift == nullptr));
   IM2IM_REQUIRE(!(stats && scale));                              // statistics describe the raw conv output
   IM2IM_REQUIRE(Ci <= 2048);
+  IM2IM_REQUIRE(in_ss_img == 0 || (per_image && x_hi == nullptr));   // per-image coefficients need one image per tile
   ConvArgs a{x, w, bias, scale, shift, y, stats, B, H, W, Ci, Co, 0, 0, relu, center, in_scale_shift,
-             x_hi, in_scale_shift_hi, Ci_lo, y_hi, Co_lo, nullptr, nullptr, nullptr, nullptr};
-  if (dtype == IM2IM_BF16) return taps == 9 ? dispatch_conv<bf16_t, 9>(a, stream) : dispatch_conv<bf16_t, 1>(a, stream);
-  return taps == 9 ? dispatch_conv<float, 9>(a, stream) : dispatch_conv<float, 1>(a, stream);
+             x_hi, in_scale_shift_hi, Ci_lo, y_hi, Co_lo, nullptr, nullptr, nullptr, nullptr, in_ss_img};
+  if (dtype == IM2IM_BF16) return taps == 9 ? dispatch_conv<bf16_t, 9>(a, stream, per_image) : dispatch_conv<bf16_t, 1>(a, stream, per_image);
+  return taps == 9 ? dispatch_conv<float, 9>(a, stream, per_image) : dispatch_conv<float, 1>(a, stream, per_image);
 }
+}  // namespace
 
 extern "C" int im2im_conv_dgrad_bn(const void* dz, const void* wd, void* dx, const void* bn_z, const float* bn_scale_shift,
                                    const float* bn_mean_invstd, float* bn_partial, int32_t B, int32_t H, int32_t W, int32_t Ci,
@@ -975,7 +1006,7 @@ extern "C" int im2im_conv_dgrad_bn(const void* dz, const void* wd, void* dx, con
   IM2IM_REQUIRE(taps == 9 || taps == 1);
   IM2IM_REQUIRE(dtype == IM2IM_F32 || dtype == IM2IM_BF16);
   ConvArgs a{dz, wd, nullptr, nullptr, nullptr, dx, nullptr, B, H, W, Ci, Co, 0, 0, 0, nullptr, nullptr,
-             nullptr, nullptr, Ci, nullptr, Co, bn_z, bn_scale_shift, bn_mean_invstd, bn_partial};
+             nullptr, nullptr, Ci, nullptr, Co, bn_z, bn_scale_shift, bn_mean_invstd, bn_partial, 0};
   if (dtype == IM2IM_BF16) return taps == 9 ? dispatch_conv<bf16_t, 9>(a, stream) : dispatch_conv<bf16_t, 1>(a, stream);
   return taps == 9 ? dispatch_conv<float, 9>(a, stream) : dispatch_conv<float, 1>(a, stream);
 }

@@ -151,6 +151,10 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
   constexpr int N = Vec16<T>::N;
   __shared__ float s_part[256][2 * N + 1];
   const int vpr = C / N;                                   // vectors per row (divides 256)
+  // grid.y > 1 (GroupNorm backward): one grid row per image, M = rows of ONE image, coefficients per image
+  da += (size_t)blockIdx.y * M * C; z += (size_t)blockIdx.y * M * C;
+  scale_shift += (size_t)blockIdx.y * 2 * C; mean_invstd += (size_t)blockIdx.y * 2 * C;
+  partial += (size_t)blockIdx.y * gridDim.x * 2 * C;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
   const int64_t v0 = r0 * vpr, v1 = r1 * vpr;
@@ -238,6 +242,220 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restr
       o[k] = sc[k] * (gg - k1[k] - xhat * k2[k]);
     }
     Vec16<T>::store(dz + i * N, o);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm(+ReLU).  Not in the reference (its DoubleConv uses BatchNorm2d, unet_parts.py:17,20): the
+// north-star-named, selectable extra (DoubleConv(norm="group")); oracle = torch.nn.GroupNorm on the CPU.
+// Same shape as the BatchNorm path above, with the statistics taken per IMAGE and channel group:
+//   * the producing conv's epilogue already emits per-tile per-channel (mean, M2, n) rows, and with one image per tile
+//     (im2im_conv_fwd_per_image) the rows of image b are [b*tpi, (b+1)*tpi): gn_finalize merges them (and the group's
+//     channels) in fp64 and emits per-(image, channel) scale = gamma*rstd, shift = beta - mean*scale, so consumers apply
+//     max(z*scale+shift, 0) exactly like lazy BatchNorm, with coefficients indexed by image;
+//   * backward: per-image partial sums of g and g*xhat per channel (the BatchNorm reduce kernel, one grid row per image),
+//     a per-(image, group) finalize, and one apply pass  dz = rstd*(gamma*g - mean_g(gamma*g) - xhat*mean_g(gamma*g*xhat)).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int tpi, int C, int G,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float eps, float* __restrict__ mean_rstd,
+                                                           float* __restrict__ scale_shift) {
+  __shared__ double sh[3][256];
+  const int g = blockIdx.x, b = blockIdx.y, cpg = C / G;
+  Moments m{0.0, 0.0, 0.0};
+  for (int e = threadIdx.x; e < tpi * cpg; e += 256) {
+    const int r = e / cpg, c = g * cpg + e % cpg;
+    const float* row = partial + ((size_t)b * tpi + r) * 3 * C;
+    m = merge_moments(m, Moments{(double)row[2 * C + c], (double)row[c], (double)row[C + c]});
+  }
+  sh[0][threadIdx.x] = m.n; sh[1][threadIdx.x] = m.mean; sh[2][threadIdx.x] = m.m2;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {                   // fixed-order tree: deterministic
+    if ((int)threadIdx.x < off) {
+      const Moments a{sh[0][threadIdx.x], sh[1][threadIdx.x], sh[2][threadIdx.x]};
+      const Moments o{sh[0][threadIdx.x + off], sh[1][threadIdx.x + off], sh[2][threadIdx.x + off]};
+      const Moments r = merge_moments(a, o);
+      sh[0][threadIdx.x] = r.n; sh[1][threadIdx.x] = r.mean; sh[2][threadIdx.x] = r.m2;
+    }
+    __syncthreads();
+  }
+  const double mean = sh[1][0];
+  const double var = sh[0][0] > 0.0 ? sh[2][0] / sh[0][0] : 0.0;            // biased, as torch.nn.GroupNorm
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  for (int j = threadIdx.x; j < cpg; j += 256) {
+    const int c = g * cpg + j;
+    float* mr = mean_rstd + (size_t)b * 2 * C;
+    float* ss = scale_shift + (size_t)b * 2 * C;
+    mr[c] = (float)mean; mr[C + c] = rstd;
+    const float sc = gamma[c] * rstd;
+    ss[c] = sc; ss[C + c] = beta[c] - (float)mean * sc;
+  }
+}
+
+// per-channel (mean, M2, n) partial rows of an arbitrary [B][HW][C] tensor, in the conv epilogue's format, for a
+// GroupNorm over a tensor this library's conv did not produce.  grid (blocks per image, B); partial[b*nblk + blk][3][C].
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ z, int64_t HW, int C, int64_t rows_per_block,
+                                                        float* __restrict__ partial) {
+  constexpr int N = Vec16<T>::N;
+  __shared__ float s_part[256][3 * N + 1];
+  const int vpr = C / N;
+  const int b = blockIdx.y;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < HW) ? r0 + rows_per_block : HW;
+  const T* zb = z + (size_t)b * HW * C;
+  const int active = (256 / vpr) * vpr;
+  float K[N], s[N], q[N], cnt = 0.f;
+#pragma unroll
+  for (int k = 0; k < N; ++k) { K[k] = 0.f; s[k] = 0.f; q[k] = 0.f; }
+  if ((int)threadIdx.x < active) {
+    bool first = true;
+    for (int64_t i = r0 * vpr + threadIdx.x; i < r1 * vpr; i += active) {
+      float v[N];
+      Vec16<T>::load(zb + i * N, v);
+      if (first) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) K[k] = v[k];              // shift by a sample: no E[z^2]-E[z]^2 cancellation
+        first = false;
+      }
+#pragma unroll
+      for (int k = 0; k < N; ++k) { const float d = v[k] - K[k]; s[k] += d; q[k] += d * d; }
+      cnt += 1.f;
+    }
+  }
+  const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    s_part[threadIdx.x][k] = K[k] + s[k] * inv;               // mean
+    s_part[threadIdx.x][N + k] = fmaxf(q[k] - s[k] * s[k] * inv, 0.f);   // M2
+    s_part[threadIdx.x][2 * N + k] = cnt;
+  }
+  __syncthreads();
+  const int groups = 256 / vpr;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float n = 0.f, m = 0.f, qq = 0.f;
+    for (int gidx = 0; gidx < groups; ++gidx) {
+      const float* pr = s_part[gidx * vpr + c / N];
+      const float n2 = pr[2 * N + c % N], m2 = pr[c % N], q2 = pr[N + c % N];
+      const float nn = n + n2;
+      const float iv = nn > 0.f ? 1.f / nn : 0.f;
+      const float d = m2 - m;
+      qq = qq + q2 + d * d * (n * n2 * iv);
+      m = (n * m + n2 * m2) * iv;
+      n = nn;
+    }
+    float* row = partial + ((size_t)b * gridDim.x + blockIdx.x) * 3 * C;
+    row[c] = m; row[C + c] = qq; row[2 * C + c] = n;
+  }
+}
+
+// a = relu(z*scale + shift) with per-image coefficients ss[B][2][C]; grid.y = image
+template <typename T>
+__global__ __launch_bounds__(256) void affine_relu_apply_img_kernel(const T* __restrict__ z, const float* __restrict__ ss,
+                                                                     T* __restrict__ a, int64_t nvec_img, int C) {
+  constexpr int N = Vec16<T>::N;
+  const int vpr = C / N;
+  const int b = blockIdx.y;
+  const float* ssb = ss + (size_t)b * 2 * C;
+  const T* zb = z + (size_t)b * nvec_img * N;
+  T* ab = a + (size_t)b * nvec_img * N;
+  const bool fixed = (256 % vpr) == 0;
+  int c0 = (int)((blockIdx.x * 256u + threadIdx.x) % (unsigned)vpr) * N;
+  float sc[N], sh[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) { sc[k] = ssb[c0 + k]; sh[k] = ssb[C + c0 + k]; }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec_img; i += (int64_t)gridDim.x * 256) {
+    if (!fixed) {
+      c0 = (int)(i % vpr) * N;
+#pragma unroll
+      for (int k = 0; k < N; ++k) { sc[k] = ssb[c0 + k]; sh[k] = ssb[C + c0 + k]; }
+    }
+    float v[N];
+    Vec16<T>::load(zb + i * N, v);
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = fmaxf(v[k] * sc[k] + sh[k], 0.f);
+    Vec16<T>::store(ab + i * N, v);
+  }
+}
+
+// partial[B][nblk][2][C] (sum g, sum g*xhat per channel) -> per (image, group): k1 = sum_c gamma*S1 / (cpg*HW),
+// k2 = sum_c gamma*S2 / (cpg*HW) written per channel into coef[B][2][C]; per-image channel sums into sums[B][2][C]
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int G,
+                                                               double count, const float* __restrict__ gamma,
+                                                               float* __restrict__ coef, float* __restrict__ sums) {
+  __shared__ double sh[2][256];
+  const int g = blockIdx.x, b = blockIdx.y, cpg = C / G;
+  double a1 = 0.0, a2 = 0.0;
+  for (int j = threadIdx.x; j < cpg; j += 256) {
+    const int c = g * cpg + j;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+      const float* row = partial + ((size_t)b * nblk + k) * 2 * C;
+      s1 += (double)row[c]; s2 += (double)row[C + c];
+    }
+    sums[(size_t)b * 2 * C + c] = (float)s1;
+    sums[(size_t)b * 2 * C + C + c] = (float)s2;
+    a1 += (double)gamma[c] * s1; a2 += (double)gamma[c] * s2;
+  }
+  sh[0][threadIdx.x] = a1; sh[1][threadIdx.x] = a2;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) { sh[0][threadIdx.x] += sh[0][threadIdx.x + off]; sh[1][threadIdx.x] += sh[1][threadIdx.x + off]; }
+    __syncthreads();
+  }
+  const float k1 = (float)(sh[0][0] / count), k2 = (float)(sh[1][0] / count);
+  for (int j = threadIdx.x; j < cpg; j += 256) {
+    const int c = g * cpg + j;
+    coef[(size_t)b * 2 * C + c] = k1;
+    coef[(size_t)b * 2 * C + C + c] = k2;
+  }
+}
+
+// dgamma[c] = sum_b S2[b][c], dbeta[c] = sum_b S1[b][c]
+__global__ __launch_bounds__(256) void gn_param_grad_kernel(const float* __restrict__ sums, int B, int C,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < B; ++b) { s1 += (double)sums[(size_t)b * 2 * C + c]; s2 += (double)sums[(size_t)b * 2 * C + C + c]; }
+  dbeta[c] = (float)s1; dgamma[c] = (float)s2;
+}
+
+// dz = rstd * (gamma*g - k1 - xhat*k2), g = da*[z*scale+shift > 0]; per-image coefficients, grid.y = image
+template <typename T>
+__global__ __launch_bounds__(256) void gn_relu_bwd_apply_kernel(const T* __restrict__ da, const T* __restrict__ z,
+                                                                 const float* __restrict__ ss, const float* __restrict__ mr,
+                                                                 const float* __restrict__ coef, const float* __restrict__ gamma,
+                                                                 T* __restrict__ dz, int64_t nvec_img, int C) {
+  constexpr int N = Vec16<T>::N;
+  const int vpr = C / N;
+  const int b = blockIdx.y;
+  const size_t boff = (size_t)b * 2 * C, toff = (size_t)b * nvec_img * N;
+  const bool fixed = (256 % vpr) == 0;
+  int c0 = (int)((blockIdx.x * 256u + threadIdx.x) % (unsigned)vpr) * N;
+  float sc[N], sh[N], mu[N], is[N], k1[N], k2[N], gm[N];
+  auto load_coef = [&]() {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      sc[k] = ss[boff + c0 + k]; sh[k] = ss[boff + C + c0 + k];
+      mu[k] = mr[boff + c0 + k]; is[k] = mr[boff + C + c0 + k];
+      k1[k] = coef[boff + c0 + k]; k2[k] = coef[boff + C + c0 + k];
+      gm[k] = gamma[c0 + k];
+    }
+  };
+  load_coef();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec_img; i += (int64_t)gridDim.x * 256) {
+    if (!fixed) { c0 = (int)(i % vpr) * N; load_coef(); }
+    float g[N], zz[N], o[N];
+    Vec16<T>::load(da + toff + i * N, g);
+    Vec16<T>::load(z + toff + i * N, zz);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const float gg = (zz[k] * sc[k] + sh[k] > 0.f) ? g[k] : 0.f;
+      const float xhat = (zz[k] - mu[k]) * is[k];
+      o[k] = is[k] * (gm[k] * gg - k1[k] - xhat * k2[k]);
+    }
+    Vec16<T>::store(dz + toff + i * N, o);
   }
 }
 
@@ -1115,6 +1333,89 @@ extern "C" int im2im_bn_relu_bwd_from_partial(const void* da, const void* z, con
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, stream, (const T*)da, (const T*)z,
                        scale_shift, mean_invstd, coef, (T*)dz, nvec, (int)C);
     return check_launch("bn_relu_bwd_apply_kernel");
+  });
+}
+
+// ------------------------------------------------------------------------------------------------ GroupNorm (extra)
+extern "C" int im2im_groupnorm_finalize(const float* partial, int32_t B, int32_t tiles_per_image, int32_t C, int32_t G,
+                                        const float* gamma, const float* beta, float eps, float* mean_rstd, float* scale_shift,
+                                        im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(partial && gamma && beta && mean_rstd && scale_shift && B > 0 && tiles_per_image > 0 && C > 0 && G > 0 && C % G == 0);
+  IM2IM_REQUIRE(B <= 65535);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)G, (unsigned)B), dim3(256), 0, stream, partial, (int)tiles_per_image, (int)C,
+                     (int)G, gamma, beta, eps, mean_rstd, scale_shift);
+  return check_launch("gn_finalize_kernel");
+}
+
+namespace {
+inline int gn_blocks_per_image(int64_t B, int64_t HW) {
+  int64_t n = std::min<int64_t>(cdiv(HW, 64), std::max<int64_t>(1, 2048 / B));
+  return (int)std::max<int64_t>(n, 1);
+}
+}  // namespace
+
+extern "C" int64_t im2im_groupnorm_stats_rows(int32_t B, int64_t HW) { return (int64_t)B * gn_blocks_per_image(B, HW); }
+
+extern "C" int im2im_groupnorm_stats(const void* z, int32_t B, int64_t HW, int32_t C, int32_t dtype, float* partial,
+                                     im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(z && partial && B > 0 && B <= 65535 && HW > 0 && C > 0 && C % 8 == 0 && C <= 2048);
+  const int nblk = gn_blocks_per_image(B, HW);
+  return for_dtype(dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    IM2IM_REQUIRE(C / Vec16<T>::N <= 256);
+    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, stream, (const T*)z, HW, (int)C,
+                       cdiv(HW, nblk), partial);
+    return check_launch("gn_stats_kernel");
+  });
+}
+
+extern "C" int im2im_affine_relu_apply_per_image(const void* z, const float* scale_shift, void* a, int32_t B, int64_t HW,
+                                                 int32_t C, int32_t dtype, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(z && scale_shift && a && B > 0 && B <= 65535 && HW > 0 && C > 0 && C % 8 == 0);
+  return for_dtype(dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    const int64_t nvec = HW * C / Vec16<T>::N;
+    const int gx = (int)std::min<int64_t>(cdiv(nvec, 256), std::max<int64_t>(1, 8192 / B));
+    hipLaunchKernelGGL(affine_relu_apply_img_kernel<T>, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, stream, (const T*)z, scale_shift,
+                       (T*)a, nvec, (int)C);
+    return check_launch("affine_relu_apply_img_kernel");
+  });
+}
+
+extern "C" int64_t im2im_groupnorm_relu_bwd_workspace_bytes(int32_t B, int64_t HW, int32_t C) {
+  return ((int64_t)B * gn_blocks_per_image(B, HW) * 2 * C + (int64_t)B * 4 * C) * (int64_t)sizeof(float);
+}
+
+extern "C" int im2im_groupnorm_relu_bwd(const void* da, const void* z, const float* scale_shift, const float* mean_rstd,
+                                        const float* gamma, void* dz, float* dgamma, float* dbeta, int32_t B, int64_t HW,
+                                        int32_t C, int32_t G, int32_t dtype, void* ws, int64_t ws_bytes, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(da && z && scale_shift && mean_rstd && gamma && dz && dgamma && dbeta && ws);
+  IM2IM_REQUIRE(B > 0 && B <= 65535 && HW > 0 && C > 0 && C % 8 == 0 && C <= 1024 && G > 0 && C % G == 0);
+  IM2IM_REQUIRE(ws_bytes >= im2im_groupnorm_relu_bwd_workspace_bytes(B, HW, C));
+  const int nblk = gn_blocks_per_image(B, HW);
+  float* partial = (float*)ws;
+  float* coef = partial + (size_t)B * nblk * 2 * C;
+  float* sums = coef + (size_t)B * 2 * C;
+  return for_dtype(dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    IM2IM_REQUIRE(256 % (C / Vec16<T>::N) == 0);               // the reduce kernel keeps one channel vector per thread
+    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<T>, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, stream, (const T*)da, (const T*)z,
+                       scale_shift, mean_rstd, HW, (int)C, cdiv(HW, nblk), partial);
+    if (int rc = check_launch("bn_relu_bwd_reduce_kernel")) return rc;
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((unsigned)G, (unsigned)B), dim3(256), 0, stream, partial, nblk, (int)C, (int)G,
+                       (double)(C / G) * (double)HW, gamma, coef, sums);
+    if (int rc = check_launch("gn_bwd_finalize_kernel")) return rc;
+    hipLaunchKernelGGL(gn_param_grad_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, stream, sums, (int)B, (int)C, dgamma, dbeta);
+    if (int rc = check_launch("gn_param_grad_kernel")) return rc;
+    const int64_t nvec = HW * C / Vec16<T>::N;
+    const int gx = (int)std::min<int64_t>(cdiv(nvec, 256), std::max<int64_t>(1, 8192 / B));
+    hipLaunchKernelGGL(gn_relu_bwd_apply_kernel<T>, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, stream, (const T*)da, (const T*)z,
+                       scale_shift, mean_rstd, coef, gamma, (T*)dz, nvec, (int)C);
+    return check_launch("gn_relu_bwd_apply_kernel");
   });
 }
 

@@ -472,6 +472,8 @@ class Materialize(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, scale_shift):
+        if scale_shift.dim() == 3:                             # per-image coefficients: a GroupNorm producer
+            return nchw(affine_relu_apply_per_image(nhwc(x.detach()), scale_shift))
         return nchw(bn_relu_apply(nhwc(x.detach()), scale_shift))
 
     @staticmethod
@@ -513,6 +515,170 @@ def conv_bn_relu_eval(x, weight, bias, gamma, beta, running_mean, running_var, e
     wf, _ = pack_weight(weight, cdt, want_wd=False)
     return nchw(conv_fwd(nhwc(x.detach(), cdt), wf, None, fold, relu=True,
                          x_hi=nhwc(x_hi.detach(), cdt) if x_hi is not None else None))
+
+
+# ----------------------------------------------------------------------------------------- GroupNorm (north-star extra)
+def conv_fwd_per_image(x, wf, bias, in_ss_img=None):
+    """conv with one image per tile: y [B,H,W,Co] + per-tile statistics rows grouped by image -> (y, stats, rows_per_image).
+    in_ss_img [B,2,Ci]: x is a GroupNorm producer's pre-norm z, max(z*scale+shift, 0) is applied while staging."""
+    b, h, w_, ci = x.shape
+    co, taps = wf.shape[0], wf.shape[1]
+    rpi = lib.im2im_conv_tiles_per_image(h, w_)
+    y = torch.empty((b, h, w_, co), dtype=x.dtype, device=x.device)
+    stats = torch.empty((b * rpi, 3, co), dtype=F32, device=x.device)
+    ev = TIMER.wrap(f"conv_igemm_kernel<{'bf16' if x.dtype == BF16 else 'f32'},1x16x16,gn,taps={taps}>", 2.0 * b * h * w_ * co * ci * taps,
+                    x.device) if TIMER else None
+    check(lib.im2im_conv_fwd_per_image(dptr(x), dptr(in_ss_img), dptr(wf), dptr(bias), dptr(y), dptr(stats), b, h, w_, ci, co, taps,
+                                       _DT[x.dtype], stream_ptr(x.device)), "im2im_conv_fwd_per_image")
+    if ev is not None:
+        ev.record(torch.cuda.current_stream(x.device))
+    return y, stats, rpi
+
+
+def groupnorm_stats(z):
+    """(mean, M2, n) partial rows of an arbitrary NHWC tensor [B,H,W,C] -> (stats, rows_per_image)."""
+    b, c = z.shape[0], z.shape[-1]
+    hw = z.numel() // (b * c)
+    rows = lib.im2im_groupnorm_stats_rows(b, hw)
+    stats = torch.empty((rows, 3, c), dtype=F32, device=z.device)
+    check(lib.im2im_groupnorm_stats(dptr(z), b, hw, c, _DT[z.dtype], dptr(stats), stream_ptr(z.device)), "im2im_groupnorm_stats")
+    return stats, rows // b
+
+
+def groupnorm_finalize(stats, b, rows_per_image, gamma, beta, groups, eps):
+    c = stats.shape[-1]
+    mean_rstd = torch.empty((b, 2, c), dtype=F32, device=stats.device)
+    scale_shift = torch.empty((b, 2, c), dtype=F32, device=stats.device)
+    check(lib.im2im_groupnorm_finalize(dptr(stats), b, rows_per_image, c, int(groups), dptr(gamma), dptr(beta), float(eps),
+                                       dptr(mean_rstd), dptr(scale_shift), stream_ptr(stats.device)), "im2im_groupnorm_finalize")
+    return mean_rstd, scale_shift
+
+
+def affine_relu_apply_per_image(z, ss):
+    a = torch.empty_like(z)
+    b, c = z.shape[0], z.shape[-1]
+    check(lib.im2im_affine_relu_apply_per_image(dptr(z), dptr(ss), dptr(a), b, z.numel() // (b * c), c, _DT[z.dtype], stream_ptr(z.device)),
+          "im2im_affine_relu_apply_per_image")
+    return a
+
+
+def groupnorm_relu_bwd(da, z, ss, mean_rstd, gamma, groups):
+    b, c = z.shape[0], z.shape[-1]
+    hw = z.numel() // (b * c)
+    dev = z.device
+    dz = torch.empty_like(z)
+    dgamma = torch.empty((c,), dtype=F32, device=dev)
+    dbeta = torch.empty((c,), dtype=F32, device=dev)
+    ws = _Scratch.get(lib.im2im_groupnorm_relu_bwd_workspace_bytes(b, hw, c), dev)
+    check(lib.im2im_groupnorm_relu_bwd(dptr(da), dptr(z), dptr(ss), dptr(mean_rstd), dptr(gamma), dptr(dz), dptr(dgamma), dptr(dbeta),
+                                       b, hw, c, int(groups), _DT[z.dtype], dptr(ws), ws.numel(), stream_ptr(dev)),
+          "im2im_groupnorm_relu_bwd")
+    return dz, dgamma, dbeta
+
+
+class ConvGroupStats(torch.autograd.Function):
+    """conv3x3(pad 1, bias) whose epilogue statistics are finalised per image and channel group (GroupNorm): returns the
+    pre-norm output z and per-(image, channel) coefficients; the normalisation is applied by the consumer (GnReluLazy).
+    The input may itself be a GroupNorm-lazy activation (coefficients [B,2,Ci]) -- the DoubleConv's second conv."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, groups, eps, cdt):
+        _gpu(x, "input")
+        co, ci = weight.shape[0], weight.shape[1]
+        small = ci <= 8
+        b, _, h, w_ = x.shape
+        in_ss = getattr(x, LAZY_ATTR, None)
+        if in_ss is not None and in_ss.dim() != 3:
+            raise _lib.Im2ImError("ConvGroupStats: a BatchNorm-lazy input must be materialised first")
+        if small:
+            xin = x.detach().to(F32).contiguous()
+            _, wd = pack_weight(weight, F32)
+            z, stats = smallconv_s2l(xin, wd, bias.detach(), None, co, cdt, flip=True, want_stats=True)
+            rpi = lib.im2im_smallconv_tiles(1, h, w_)
+            if not x.requires_grad:
+                wd = None
+        else:
+            xin = nhwc(x.detach(), cdt)
+            wf, wd = pack_weight(weight, cdt)
+            z, stats, rpi = conv_fwd_per_image(xin, wf, bias.detach(), in_ss_img=in_ss)
+        mean_rstd, scale_shift = groupnorm_finalize(stats, b, rpi, gamma.detach(), beta.detach(), groups, eps)
+        ctx.small, ctx.lazy_in = small, in_ss is not None
+        ctx.set_materialize_grads(False)
+        none = torch.empty(0)
+        ctx.save_for_backward(xin, wd if wd is not None else none, in_ss if in_ss is not None else none)
+        ctx.mark_non_differentiable(scale_shift, mean_rstd)
+        return nchw(z), scale_shift, mean_rstd
+
+    @staticmethod
+    def backward(ctx, dz, _g1, _g2):
+        xin, wd, in_ss = ctx.saved_tensors
+        dz = nhwc(dz, xin.dtype if not ctx.small else dz.dtype)
+        dx = None
+        if ctx.small:
+            dw, _ = smallconv_wgrad(xin, dz, l_major=True, want_bias=False)
+            dw = dw.view(dz.shape[3], xin.shape[1], 3, 3)
+            db = colsum(dz)
+            if ctx.needs_input_grad[0] and wd.numel():
+                dx = smallconv_l2s(dz, wd, None, xin.shape[1])
+        else:
+            a = affine_relu_apply_per_image(xin, in_ss) if ctx.lazy_in else xin      # recomputed operand of the weight gradient
+            dw = conv_wgrad(a, dz, 9).view(dz.shape[3], xin.shape[3], 3, 3)
+            db = colsum(dz)                                   # the bias does NOT cancel under GroupNorm (the mean is per image/group)
+            if ctx.needs_input_grad[0]:
+                dx = nchw(conv_fwd(dz, wd))
+        return dx, dw, db, None, None, None, None, None
+
+
+class GnReluLazy(torch.autograd.Function):
+    """a = relu(GroupNorm(z)) without materialising a: forward returns an alias of z (the caller tags it with the per-image
+    coefficients); backward is the GroupNorm+ReLU backward (dz, dgamma, dbeta)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, scale_shift, mean_rstd, groups):
+        ctx.save_for_backward(z, gamma, scale_shift, mean_rstd)
+        ctx.groups = groups
+        return z.detach().view_as(z)
+
+    @staticmethod
+    def backward(ctx, da):
+        z, gamma, scale_shift, mean_rstd = ctx.saved_tensors
+        zz = nhwc(z)
+        dz, dgamma, dbeta = groupnorm_relu_bwd(nhwc(da, zz.dtype), zz, scale_shift, mean_rstd, gamma.detach(), ctx.groups)
+        return nchw(dz), dgamma, dbeta, None, None, None
+
+
+def conv_gn_relu(x, weight, bias, gamma, beta, groups, eps, cdt, lazy_out=False):
+    """conv3x3 -> GroupNorm -> ReLU (DoubleConv(norm="group")); GroupNorm has no train/eval distinction."""
+    ss_in = getattr(x, LAZY_ATTR, None)
+    if ss_in is not None and ss_in.dim() != 3:
+        x = materialize(x)
+    z, scale_shift, mean_rstd = ConvGroupStats.apply(x, weight, bias, gamma, beta, groups, eps, cdt)
+    a = GnReluLazy.apply(z, gamma, beta, scale_shift, mean_rstd, groups)
+    setattr(a, LAZY_ATTR, scale_shift)
+    return a if lazy_out else materialize(a)
+
+
+def group_norm_relu(x, gamma, beta, groups, eps=1e-5):
+    """standalone relu(GroupNorm(x)) of an arbitrary [B,C,H,W] GPU tensor (channels-last in its own dtype): statistics pass,
+    finalize, one apply pass; differentiable (same backward kernels)."""
+    return _GroupNormRelu.apply(x, gamma, beta, groups, eps)
+
+
+class _GroupNormRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps):
+        z = nhwc(x.detach(), x.dtype if x.dtype in (F32, BF16) else F32)
+        stats, rpi = groupnorm_stats(z)
+        mean_rstd, scale_shift = groupnorm_finalize(stats, z.shape[0], rpi, gamma.detach(), beta.detach(), groups, eps)
+        ctx.save_for_backward(z, gamma, scale_shift, mean_rstd)
+        ctx.groups = groups
+        return nchw(affine_relu_apply_per_image(z, scale_shift))
+
+    @staticmethod
+    def backward(ctx, da):
+        z, gamma, scale_shift, mean_rstd = ctx.saved_tensors
+        dz, dgamma, dbeta = groupnorm_relu_bwd(nhwc(da, z.dtype), z, scale_shift, mean_rstd, gamma.detach(), ctx.groups)
+        return nchw(dz), dgamma, dbeta, None, None
 
 
 class EvalModeBarrier(torch.autograd.Function):

@@ -228,6 +228,40 @@ int im2im_bn_relu_pool_bwd(const void* da, const void* dpool, const void* z, con
                            int32_t H, int32_t W, int32_t C, int32_t dtype, void* ws, int64_t ws_bytes,
                            im2im_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * GroupNorm(+ReLU) -- named by BASELINE.json:north_star; NOT in the reference (its DoubleConv uses BatchNorm2d,
+ * core/models/trunks/unet_parts.py:17,20).  Selectable extra behind DoubleConv(norm="group"), never the
+ * default; oracle = torch.nn.GroupNorm on the CPU.  Statistics are per image and channel group (biased variance).
+ *
+ *   im2im_conv_fwd_per_image: im2im_conv_fwd with ONE image per tile (16x16 pixel tiles at every extent), so the rows
+ *     of `stats` [B * im2im_conv_tiles_per_image(H,W)][3][Co] belonging to image b are contiguous; the lazy input
+ *     coefficients are per image: in_scale_shift_per_image [B][2][Ci] (or NULL).  +bias epilogue only.
+ *   im2im_groupnorm_stats: the same (mean, M2, n) partial rows for a tensor z [B][HW][C] this library's conv did not
+ *     produce: partial [im2im_groupnorm_stats_rows(B,HW)][3][C], rows of an image contiguous.
+ *   im2im_groupnorm_finalize: rows -> mean_rstd [B][2][C] (the group's mean / rstd replicated per channel) and
+ *     scale_shift [B][2][C] (scale = gamma*rstd, shift = beta - mean*scale): consumers apply max(z*scale+shift, 0).
+ *   im2im_affine_relu_apply_per_image: a = max(z*scale + shift, 0) with those per-image coefficients.
+ *   im2im_groupnorm_relu_bwd: da [B][HW][C] -> dz, dgamma [C], dbeta [C]:
+ *     g = da*[z*scale+shift > 0]; dz = rstd*(gamma*g - mean_g(gamma*g) - xhat*mean_g(gamma*g*xhat)), means over the
+ *     group's channels and the image's pixels.  Deterministic (no atomics).  C % 8 == 0, C <= 1024, C % G == 0. */
+int64_t im2im_conv_tiles_per_image(int32_t H, int32_t W);
+int im2im_conv_fwd_per_image(const void* x, const float* in_scale_shift_per_image, const void* wf, const float* bias,
+                             void* y, float* stats, int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                             int32_t taps, int32_t dtype, im2im_stream_t stream);
+int64_t im2im_groupnorm_stats_rows(int32_t B, int64_t HW);
+int im2im_groupnorm_stats(const void* z, int32_t B, int64_t HW, int32_t C, int32_t dtype, float* partial,
+                          im2im_stream_t stream);
+int im2im_groupnorm_finalize(const float* partial, int32_t B, int32_t rows_per_image, int32_t C, int32_t G,
+                             const float* gamma, const float* beta, float eps, float* mean_rstd,
+                             float* scale_shift, im2im_stream_t stream);
+int im2im_affine_relu_apply_per_image(const void* z, const float* scale_shift, void* a, int32_t B, int64_t HW,
+                                      int32_t C, int32_t dtype, im2im_stream_t stream);
+int64_t im2im_groupnorm_relu_bwd_workspace_bytes(int32_t B, int64_t HW, int32_t C);
+int im2im_groupnorm_relu_bwd(const void* da, const void* z, const float* scale_shift, const float* mean_rstd,
+                             const float* gamma, void* dz, float* dgamma, float* dbeta, int32_t B, int64_t HW,
+                             int32_t C, int32_t G, int32_t dtype, void* ws, int64_t ws_bytes,
+                             im2im_stream_t stream);
+
 /* out[c] = sum_m x[m][c] (bias gradient of the 1x1 out conv, unet_parts.py:90). */
 int64_t im2im_colsum_workspace_bytes(int64_t M, int32_t C);
 int im2im_colsum(const void* x, float* out, int64_t M, int32_t C, int32_t dtype, void* ws,

@@ -19,6 +19,7 @@ import torch.nn.functional as F
 
 BN_EPS = 1e-5       # torch.nn.BatchNorm2d default, core/models/trunks/unet_parts.py:17
 BN_MOMENTUM = 0.1   # idem
+GN_GROUPS = 32      # DoubleConv(norm="group"): nn.GroupNorm(min(32, C), C), torch's eps default 1e-5
 
 # (prefix, Cin, Cmid, Cout) for the DoubleConv blocks of the UNet, core/models/trunks/unet.py:20-30 with
 # bilinear=True.  The reference fixes depth=4, base=64 (nine blocks: inc, down1-4, up1-4); the same recipe
@@ -50,7 +51,7 @@ HEADS = {
 
 
 def state_spec(n_in: int = 1, n_out: int = 1, n_mid: int = 32, utype: str = "quantiles", depth: int = 4,
-               base: int = 64) -> List[Tuple[str, Tuple[int, ...]]]:
+               base: int = 64, norm: str = "batch") -> List[Tuple[str, Tuple[int, ...]]]:
     """(key, shape) list in the reference's state_dict order
     (unet.py:20-31, unet_parts.py:15-22,90, quantile_layer.py:15-17)."""
     spec: List[Tuple[str, Tuple[int, ...]]] = []
@@ -61,6 +62,8 @@ def state_spec(n_in: int = 1, n_out: int = 1, n_mid: int = 32, utype: str = "qua
             spec.append((f"{p}.{idx}.bias", (co,)))
             spec.append((f"{p}.{idx + 1}.weight", (co,)))
             spec.append((f"{p}.{idx + 1}.bias", (co,)))
+            if norm == "group":                 # nn.GroupNorm has no buffers
+                continue
             spec.append((f"{p}.{idx + 1}.running_mean", (co,)))
             spec.append((f"{p}.{idx + 1}.running_var", (co,)))
             spec.append((f"{p}.{idx + 1}.num_batches_tracked", ()))
@@ -114,6 +117,12 @@ def double_conv(x, state, prefix, training, emulate_bf16=False):
         if w.shape[1] > 8:                      # the <=8-channel first conv runs on fp32 weights in the kernels
             w = _operand(w, emulate_bf16)
         x = F.conv2d(x, w, state[f"{p}.{idx}.bias"], padding=1)
+        if f"{p}.{idx + 1}.running_mean" not in state:
+            # the GroupNorm variant of the block (north-star extra, not in the reference: SURVEY D1): nn.GroupNorm(min(32, C), C)
+            x = _store(x, emulate_bf16)
+            x = F.group_norm(x, min(GN_GROUPS, x.shape[1]), state[f"{p}.{idx + 1}.weight"], state[f"{p}.{idx + 1}.bias"], eps=BN_EPS)
+            x = _store(F.relu(x), emulate_bf16)
+            continue
         if training:
             x = _store(x, emulate_bf16)         # train mode stores the pre-BN conv output; eval folds BN into the conv
         x = F.batch_norm(x, state[f"{p}.{idx + 1}.running_mean"], state[f"{p}.{idx + 1}.running_var"],
@@ -287,8 +296,9 @@ def det_fill(key: str, shape: Tuple[int, ...]) -> torch.Tensor:
     return v.to(torch.float32).reshape(shape)
 
 
-def det_state(n_in: int = 1, n_out: int = 1, utype: str = "quantiles", depth: int = 4, base: int = 64) -> Dict[str, torch.Tensor]:
-    return {k: det_fill(k, shp) for k, shp in state_spec(n_in, n_out, utype=utype, depth=depth, base=base)}
+def det_state(n_in: int = 1, n_out: int = 1, utype: str = "quantiles", depth: int = 4, base: int = 64,
+              norm: str = "batch") -> Dict[str, torch.Tensor]:
+    return {k: det_fill(k, shp) for k, shp in state_spec(n_in, n_out, utype=utype, depth=depth, base=base, norm=norm)}
 
 
 def det_images(n: int, c: int, h: int, w: int, salt: int = 0):
