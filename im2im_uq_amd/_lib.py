@@ -92,6 +92,10 @@ SIGNATURES = {
     "im2im_uq_loss_fwd": (_i32, [_i32, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _ptr, _ptr, _ptr]),
     # kind, a, b, c, target, N, P, img_stride, q_lo, q_hi, w0, w1, w2, grad_out, d_a, d_b, d_c, d_stride, stream
     "im2im_uq_loss_bwd": (_i32, [_i32, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _ptr, _ptr, _ptr, _ptr, _i64, _ptr]),
+    "im2im_fastmri_mask_pack": (_i32, [_ptr, _ptr, _i64, _ptr, _i64, _i32, _i32, _i64, _i32, _ptr]),
+    "im2im_complex_transpose": (_i32, [_ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr]),
+    "im2im_fastmri_abs_normalize": (_i32, [_ptr, _ptr, _i32, _i32, _i32, _i32, _f32, _f32, _ptr]),
+    "im2im_center_crop_affine": (_i32, [_ptr, _ptr, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _ptr]),
     "im2im_adam_step": (_i32, [_i32, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _f32, _f32, _i64, _ptr]),
 }
 for _name, (_res, _args) in SIGNATURES.items():

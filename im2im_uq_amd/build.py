@@ -28,6 +28,7 @@ SOURCES = {
     "conv_mfma.hip": ["-ffp-contract=off"],     # lazy BatchNorm+ReLU in the operand staging must round exactly like bn_relu_apply
     "elementwise.hip": ["-ffp-contract=off"],
     "smallconv.hip": ["-ffp-contract=off"],
+    "fastmri.hip": ["-ffp-contract=off"],
 }
 
 

@@ -367,6 +367,28 @@ int im2im_softmax_ce_bwd(const void* logits, const float* target, const float* b
 int im2im_softmax_sets_summary(const void* logits, int64_t N, int64_t P, int32_t K, int32_t stride, int32_t dtype,
                                float* out3, im2im_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * fastMRI input pipeline: glue kernels around two exact-fp32 MFMA GEMMs (im2im_conv_fwd, taps = 1,
+ * dtype IM2IM_F32) that evaluate the centred orthonormal inverse 2-D DFT restricted to the cropped output.  Replaces, on
+ * the device, apply_mask core/datasets/fastmri/transforms.py:53-85, ifft2c_new fftc.py:87-110, complex_center_crop
+ * transforms.py:130-152, complex_abs math_util.py:56-70, center_crop transforms.py:108-127 and the normalisation of
+ * FastMRIDataset.__getitem__ FastMRIDataset.py:147-160.  All tensors fp32.
+ *   im2im_fastmri_mask_pack: kspace [B][R][C][2], mask [B][C] (mask_stride = C) or one shared [C] (mask_stride = 0)
+ *     -> out [rows_out][Kp]: row (b, r) = the slice's k-space row * mask + 0.0, columns >= 2C and rows >= B*R zero
+ *     (GEMM padding: Kp % 32 == 0, rows_out % 16 == 0 are the caller's business).
+ *   im2im_complex_transpose: in [B][R][ld_in floats] (X complex used) -> out [B][X][ld_out floats] (R complex, rest 0).
+ *   im2im_fastmri_abs_normalize: in [B][X][ld_in floats] (Y complex used, x-major) -> out [B][Y][X] =
+ *     (sqrt(re^2 + im^2) - sub) / div with the reference's rounding (no fma, true division).
+ *   im2im_center_crop_affine: out [B][H][W] = (centre crop of in [B][Hin][Win] - sub) / div. */
+int im2im_fastmri_mask_pack(const float* kspace, const float* mask, int64_t mask_stride, float* out, int64_t B,
+                            int32_t R, int32_t C, int64_t rows_out, int32_t Kp, im2im_stream_t stream);
+int im2im_complex_transpose(const float* in, float* out, int32_t B, int32_t R, int32_t X, int32_t ld_in,
+                            int32_t ld_out, im2im_stream_t stream);
+int im2im_fastmri_abs_normalize(const float* in, float* out, int32_t B, int32_t X, int32_t Y, int32_t ld_in,
+                                float sub, float div, im2im_stream_t stream);
+int im2im_center_crop_affine(const float* in, float* out, int64_t B, int32_t Hin, int32_t Win, int32_t H,
+                             int32_t W, float sub, float div, im2im_stream_t stream);
+
 /* Multi-tensor Adam: optim.Adam(net.parameters(), lr) at core/scripts/train.py:120 with torch
  * defaults (betas, eps, no weight decay, no amsgrad).  Host arrays of n_tensors device pointers / sizes;
  * `step` is the 1-based step count used for bias correction. */

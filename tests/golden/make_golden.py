@@ -32,6 +32,7 @@ wandb.watch = lambda *a, **k: None
 wandb.Image = lambda x: x
 wandb.config = {}
 sys.modules["wandb"] = wandb
+sys.modules.setdefault("h5py", types.ModuleType("h5py"))    # only FastMRIDataset's file reading needs it; the transforms do not
 
 import numpy as np
 import torch
@@ -627,11 +628,54 @@ def g16():
     save("g16_wnet", **rec)
 
 
+# ---------------------------------------------------------------- G18 fastMRI input pipeline
+def g18():
+    """the reference's own mask functions, apply_mask, ifft2c, complex_center_crop, complex_abs and UnetDataTransform
+    (core/datasets/fastmri/{subsample,transforms,fftc,math_util}.py) on synthetic k-space: masks for several widths and
+    seeds; a small slice stored in full; two full-size singlecoil-knee shapes (640x368 and 640x372 -> 320x320) whose
+    closed-form k-space (oracle.fastmri.det_kspace) needs no storing, results kept as a 4x-strided sample + checksums."""
+    from core.datasets.fastmri import subsample as ref_sub
+    from core.datasets.fastmri import transforms as ref_tr
+    from oracle import fastmri as ofm
+    rec = {}
+    # masks: called with a seed (tuple of ords of a file name, transforms.py:289) and un-seeded after rng.seed(k)
+    cases = []
+    for kind, cls in (("equispaced", ref_sub.EquispacedMaskFunc), ("random", ref_sub.RandomMaskFunc)):
+        for cols in (368, 372, 320, 96):
+            for fname in ("file1000001.h5", "file1000277.h5", "x"):
+                seed = tuple(map(ord, fname))
+                m = cls([0.08], [4])((1, cols, 2), seed).reshape(-1).numpy()
+                cases.append((kind, cols, fname))
+                rec[f"mask.{kind}.{cols}.{fname}"] = m.astype(np.uint8)
+    m2 = ref_sub.EquispacedMaskFunc([0.08, 0.04], [4, 8])
+    rec["mask.two_rates"] = np.stack([m2((1, 368, 2), (s,)).reshape(-1).numpy() for s in range(6)]).astype(np.uint8)
+    # transform, small slice in full
+    tr = ref_tr.UnetDataTransform("singlecoil", mask_func=ref_sub.EquispacedMaskFunc([0.08], [4]), use_seed=True)
+    ks = ofm.det_kspace(1, 96, 72, salt=1)[0]
+    kc = (ks[..., 0] + 1j * ks[..., 1]).numpy()
+    target = torch.rand(48, 40).numpy()
+    image, tgt, _, _, _, _, _ = tr(kc, None, target, {"max": 1.0}, "file1000001.h5", 3)
+    rec.update(small_kspace=ks, small_target=target, small_image=image, small_target_out=tgt)
+    # FLAIR-203 rule (image narrower than the target's width)
+    image_f, _, _, _, _, _, _ = tr(kc, None, None, {"recon_size": (64, 80, 1)}, "file1000001.h5", 3)
+    rec["small_image_flair"] = image_f
+    # full-size shapes
+    for cols in (368, 372):
+        ks = ofm.det_kspace(1, 640, cols, salt=cols)[0]
+        kc = (ks[..., 0] + 1j * ks[..., 1]).numpy()
+        image, _, _, _, _, _, _ = tr(kc, None, np.zeros((320, 320), np.float32), {}, "file1000277.h5", 0)
+        rec[f"full{cols}.sample"] = image[::4, ::4].clone()
+        rec[f"full{cols}.sum"] = image.double().sum()
+        rec[f"full{cols}.sumsq"] = (image.double() ** 2).sum()
+        rec[f"full{cols}.max"] = image.max()
+    save("g18_fastmri_pipeline", **rec)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
     for name, fn in (("g1_g2", g1_g2), ("g3", g3), ("g4", g4), ("g5", g5), ("g6", g6), ("g7", g7), ("g8", g8),
-                     ("g9_g10", g9_g10), ("g11", g11), ("g12", g12), ("g13", g13), ("g14", g14), ("g15", g15), ("g16", g16), ("g17", g17)):
+                     ("g9_g10", g9_g10), ("g11", g11), ("g12", g12), ("g13", g13), ("g14", g14), ("g15", g15), ("g16", g16), ("g17", g17), ("g18", g18)):
         if not only or name in only:
             fn()
     if "g12_inn" in only:

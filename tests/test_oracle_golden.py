@@ -367,3 +367,32 @@ def _wnet_shapes():
         shapes[f"last_layer.{h}.weight"] = (1, 32, 3, 3)
         shapes[f"last_layer.{h}.bias"] = (1,)
     return shapes
+
+
+def test_g18_fastmri_pipeline_oracle():
+    """oracle/fastmri.py against the reference's mask functions and UnetDataTransform (fixture G18)."""
+    from oracle import fastmri as ofm
+    g = load_golden("g18_fastmri_pipeline")
+    for k in g:
+        if k.startswith("mask.") and k != "mask.two_rates":
+            _, kind, cols, fname = k.split(".", 3)
+            m = ofm.seeded_mask(kind, int(cols), [0.08], [4], tuple(map(ord, fname)))
+            assert np.array_equal(m.astype(np.uint8), g[k]), k
+    two = np.stack([ofm.seeded_mask("equispaced", 368, [0.08, 0.04], [4, 8], (s,)) for s in range(6)]).astype(np.uint8)
+    assert np.array_equal(two, g["mask.two_rates"])
+    ks = T(g["small_kspace"])
+    mask = T(ofm.seeded_mask("equispaced", 72, [0.08], [4], tuple(map(ord, "file1000001.h5"))))
+    img = ofm.unet_data_transform(ks, mask, (48, 40))
+    np.testing.assert_allclose(img.numpy(), g["small_image"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(ofm.center_crop(T(g["small_target"]), (48, 40)).numpy(), g["small_target_out"], rtol=0, atol=0)
+    img_f = ofm.unet_data_transform(ks, mask, (64, 80))
+    assert img_f.shape == (72, 72)
+    np.testing.assert_allclose(img_f.numpy(), g["small_image_flair"], rtol=1e-5, atol=1e-9)
+    for cols in (368, 372):
+        ks = ofm.det_kspace(1, 640, cols, salt=cols)[0]
+        mask = T(ofm.seeded_mask("equispaced", cols, [0.08], [4], tuple(map(ord, "file1000277.h5"))))
+        img = ofm.unet_data_transform(ks, mask, (320, 320))
+        scale = float(g[f"full{cols}.max"])
+        np.testing.assert_allclose(img[::4, ::4].numpy(), g[f"full{cols}.sample"], rtol=0, atol=2e-6 * scale)
+        assert float(img.double().sum()) == pytest.approx(float(g[f"full{cols}.sum"]), rel=1e-6)
+        assert float((img.double() ** 2).sum()) == pytest.approx(float(g[f"full{cols}.sumsq"]), rel=1e-6)
