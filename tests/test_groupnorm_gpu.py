@@ -40,7 +40,7 @@ def test_group_norm_relu_fwd_bwd_vs_torch(case, dt):
     x = rnd(b, c, h, w, seed=1) + 3.0 * rnd(1, c, 1, 1, seed=2)
     gamma, beta = 1.0 + 0.3 * rnd(c, seed=3), 0.2 * rnd(c, seed=4)
     gy = rnd(b, c, h, w, seed=5)
-    xq = x.to(dt).to(F32).requires_grad_(True)
+    xq = x.to(dt).to(F32).clone().requires_grad_(True)
     gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     ref = F.relu(F.group_norm(xq, groups, gr, br, eps=1e-5))
     ref.backward(gy.to(dt).to(F32))
