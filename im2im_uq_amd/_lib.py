@@ -47,6 +47,11 @@ SIGNATURES = {
     # x, in_ss, x_hi, in_ss_hi, Ci_lo, wf, bias, center, scale, shift, y, y_hi, Co_lo, stats, B, H, W, Ci, Co, taps, relu, dtype, stream
     "im2im_conv_fwd_split": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr,
                                     _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
+    "im2im_conv_fp8_stats_rows": (_i64, [_i32, _i32, _i32]),
+    "im2im_pack_conv_weight_fp8": (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr, _ptr]),
+    # x, in_ss, x_hi, in_ss_hi, Ci_lo, wq, wscale, bias, scale, shift, y, stats, B, H, W, Ci, Co, relu, stream
+    "im2im_conv_fwd_fp8": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32,
+                                  _i32, _ptr]),
     # dz, wd, dx, bn_z, bn_ss, bn_mi, bn_partial, B, H, W, Ci, Co, taps, dtype, stream
     "im2im_conv_dgrad_bn": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_bn_relu_bwd_from_partial": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i64, _ptr]),

@@ -29,6 +29,7 @@ SOURCES = {
     "elementwise.hip": ["-ffp-contract=off"],
     "smallconv.hip": ["-ffp-contract=off"],
     "fastmri.hip": ["-ffp-contract=off"],
+    "conv_fp8.hip": ["-ffp-contract=off"],
 }
 
 
@@ -67,7 +68,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     hdr_t = _deps_mtime()
-    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(lambda kv: _compile(kv[0], kv[1], force, hdr_t), SOURCES.items()))
     if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]

@@ -1,0 +1,465 @@
+// fp8 (OCP e4m3) forward convolution for gfx950 on the block-scaled matrix instruction
+// v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64 per instruction, ~2x the bf16 MFMA rate: 3.7 vs 1.9-2.0 PFLOP/s measured on
+// random operands with tools/hwprobe/fp8probe) -- BASELINE configs[4] "fp8 MFMA conv path".
+//
+// Same implicit-GEMM shape as conv_mfma.hip (3x3 pad-1, NHWC, M = 256 output pixels per workgroup, the halo patch staged
+// once per channel chunk and reused by the 9 taps, weight tiles double-buffered), with these differences:
+//   * activations stay bf16 in HBM (the producer's pre-BatchNorm z, or a plain tensor); the operand STAGING applies the
+//     lazy BatchNorm+ReLU, multiplies by 2^4, clamps to the e4m3 range and converts to fp8 on the way into LDS
+//     (v_cvt_pk_fp8_f32).  The 2^4 pre-scale puts post-BatchNorm activations (O(1)) in the middle of e4m3's exponent
+//     window and is undone for free by the instruction's E8M0 block scale (scale_a = 127 - 4);
+//   * weights are packed once per step to fp8 with one power-of-two scale per output channel (max |w| of the channel
+//     -> (128, 256]), undone in the epilogue;
+//   * a channel chunk is 64 channels = ONE MFMA k-step; an LDS row is still 80 bytes (64 fp8 + 16 pad), so the tile
+//     geometry and the conflict-free ds_read_b128 pattern of the bf16 kernel carry over (halo rows padded by 96 B);
+//   * the halo tile is double-buffered in LDS and the next chunk's halo is trickled in piece by piece across the 9 taps
+//     (global load issued before a tap's MFMAs, converted and written after them): the fp8 MFMAs of a tap take ~512
+//     cycles per wave, which covers the load latency and the ~30 VALU of a piece's BatchNorm + conversion, and only two
+//     16-byte pieces are ever in flight per thread (the bf16 kernel holds a whole halo in registers).
+// fp32 accumulation; bf16 output; the epilogue (bias / BatchNorm partial statistics / folded affine + ReLU) is the
+// bf16 kernel's.  The backward pass stays bf16 (gradients need range more than throughput).
+#include "common.h"
+#include "dtypes.h"
+#include <type_traits>
+
+namespace {
+using namespace im2im;
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+constexpr float XSCALE = 16.f;       // activation pre-scale (2^4), undone by the MFMA's E8M0 scale_a
+constexpr int XSCALE_E8M0 = 127 - 4;
+constexpr float FP8_MAX = 448.f;
+
+struct Fp8ConvArgs {
+  const bf16_t* x;       // [B][H][W][Ci_lo or Ci]
+  const bf16_t* x_hi;    // null, or input channels [Ci_lo, Ci)
+  const float* in_ss;    // [2][Ci_lo or Ci] lazy BatchNorm+ReLU of x (or null)
+  const float* in_ss_hi; // [2][Ci - Ci_lo]
+  const unsigned char* w;  // [Co][9][Ci] e4m3
+  const float* wscale;   // [Co] power-of-two scale of each output channel's weights
+  const float* bias;     // [Co] or null
+  const float* scale;    // [Co] or null (EPI 2)
+  const float* shift;
+  bf16_t* y;             // [B][H][W][Co]
+  float* stats;          // [tiles][3][Co] or null
+  int B, H, W, Ci, Co, Ci_lo, tilesY, tilesX, relu;
+};
+
+__device__ __forceinline__ void merge_moments_f32(float& n, float& m, float& q, float n2, float m2, float q2) {
+  const float nn = n + n2;
+  const float inv = nn > 0.f ? 1.f / nn : 0.f;
+  const float d = m2 - m;
+  q = q + q2 + d * d * (n * n2 * inv);
+  m = (n * m + n2 * m2) * inv;
+  n = nn;
+}
+
+// 8 floats -> 8 e4m3 bytes (saturating: cvt_pk_fp8_f32 turns out-of-range values into NaN, so clamp first)
+__device__ __forceinline__ uint2 to_fp8x8(const float (&v)[8]) {
+  float c[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) c[k] = fminf(fmaxf(v[k], -FP8_MAX), FP8_MAX);
+  int lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
+  int hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], 0, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], hi, true);
+  return make_uint2((unsigned)lo, (unsigned)hi);
+}
+
+// EPI: 0 = (+bias) store; 1 = +bias, store, BatchNorm partial statistics; 2 = folded BatchNorm affine (+ReLU)
+template <int TB, int TH, int TW, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
+  using T = bf16_t;
+  constexpr int HH = TH + 2, HWD = TW + 2, HPI = HH * HWD, HPX = TB * HPI;
+  constexpr int MI = TH * TW;
+  constexpr int KC = 64;                              // channels per chunk = one MFMA k-step
+  constexpr int ROWB = KC + 16;                       // LDS row pitch (bytes): 64 fp8 + pad
+  constexpr int M = TB * TH * TW;
+  constexpr int MT = M / (32 * WM), NT = BN / (32 * WN);
+  static_assert(WM * WN == 4 && MT >= 1 && NT >= 1, "tile split");
+  constexpr int A_PIECES = HPX * 8;                   // 16-byte global pieces (8 bf16 channels) per halo chunk
+  constexpr int A_ROUNDS = (A_PIECES + 255) / 256;
+  constexpr int B_ROUNDS = (BN * 4 + 255) / 256;      // 16-byte pieces (16 fp8 channels) per weight tile
+  constexpr int HROWB = HWD * ROWB + 96;              // halo rows padded: conflict-free ds_read_b128 (enumerated)
+  constexpr int HIMGB = HH * HROWB;
+  constexpr int A_BYTES = TB * HIMGB, B_BYTES = BN * ROWB;
+  static_assert(A_ROUNDS <= 18, "two rounds per tap at most");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsA = smem;                                  // two halo buffers
+  char* ldsB = smem + 2 * A_BYTES;                    // two weight buffers
+  float* ldsS = reinterpret_cast<float*>(smem);       // stats scratch (after the main loop)
+  float* ldsSS = reinterpret_cast<float*>(smem + 2 * A_BYTES + 2 * B_BYTES);   // [2][Ci] lazy coefficients
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tile_id = blockIdx.x, cob = blockIdx.y;
+  int mt_id = tile_id;
+  const int tx_id = mt_id % a.tilesX; mt_id /= a.tilesX;
+  const int ty_id = mt_id % a.tilesY;
+  const int b0 = (mt_id / a.tilesY) * TB;
+  const int y0 = ty_id * TH, x0 = tx_id * TW;
+  const int n0 = cob * BN;
+  const bool split_in = a.x_hi != nullptr;
+  const int xstride = split_in ? a.Ci_lo : a.Ci;
+
+  int aoff[MT], boff[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = (wm * MT + mt) * 32 + l31;
+    aoff[mt] = (m / MI) * HIMGB + ((m % MI) / TW) * HROWB + (m % TW) * ROWB + half * 32;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) boff[nt] = ((wn * NT + nt) * 32 + l31) * ROWB + half * 32;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const bool lazy_lo = a.in_ss != nullptr, lazy_hi = a.in_ss_hi != nullptr;
+  if (lazy_lo || lazy_hi) {
+    const int clo = split_in ? a.Ci_lo : a.Ci, chi = a.Ci - clo;
+    if (lazy_lo) for (int i = tid; i < clo; i += 256) { ldsSS[i] = a.in_ss[i] * XSCALE; ldsSS[a.Ci + i] = a.in_ss[clo + i] * XSCALE; }
+    if (lazy_hi) for (int i = tid; i < chi; i += 256) { ldsSS[clo + i] = a.in_ss_hi[i] * XSCALE; ldsSS[a.Ci + clo + i] = a.in_ss_hi[chi + i] * XSCALE; }
+    __syncthreads();
+  }
+
+  // ---- halo staging, one 16-byte piece (pixel, 8 channels) at a time.  part = tid % 8 is the same for all of a thread's pieces.
+  const int part = tid & 7;
+  const T* __restrict__ xg_tile = a.x + (size_t)b0 * a.H * a.W * xstride;
+  const T* __restrict__ xh_tile = a.x_hi + (size_t)b0 * a.H * a.W * xstride;
+  // `t` is the thread id, passed through an opaque asm once per chunk so that the compiler RE-COMPUTES the ~20 integer
+  // operations of a piece's addresses at its tap (there are hundreds of idle VALU slots under a tap's MFMAs) instead of
+  // keeping the 2 x A_ROUNDS offsets of the whole halo live across the loop, which the 128 accumulators leave no room for
+  auto piece_src = [&](int chunk, int i, int t, int& loff) -> const T* {       // null: padding (zeros); loff < 0: no such piece
+    const int p = i * 256 + t;
+    const int px = p >> 3;
+    loff = -1;
+    if (A_PIECES % 256 != 0 && px >= HPX) return nullptr;
+    const int tb = px / HPI, pi = px % HPI;
+    const int hy = pi / HWD, hx = pi % HWD;
+    loff = tb * HIMGB + hy * HROWB + hx * ROWB + (t & 7) * 8;
+    const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+    if (b0 + tb >= a.B || yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) return nullptr;
+    const int c = chunk * KC;
+    const T* base = (split_in && c >= a.Ci_lo) ? xh_tile + (c - a.Ci_lo) : xg_tile + c;
+    return base + ((size_t)(tb * a.H + yy) * a.W + xx) * xstride + (t & 7) * 8;
+  };
+  // lazy coefficients are read from LDS per piece (4 x ds_read_b128; registers are the scarce resource here), pre-scaled by 2^4
+  auto convert_write = [&](const uint4& raw, bool real, int loff, char* dst, int chunk) {
+    if (loff < 0) return;
+    uint2 q = make_uint2(0u, 0u);
+    if (real) {
+      float v[8];
+      Vec16<T>::load(reinterpret_cast<const T*>(&raw), v);
+      const bool lazy_cur = (split_in && chunk * KC >= a.Ci_lo) ? lazy_hi : lazy_lo;
+      if (lazy_cur) {
+        const int c0 = chunk * KC + part * 8;
+        const float4 s0 = *reinterpret_cast<const float4*>(ldsSS + c0), s1 = *reinterpret_cast<const float4*>(ldsSS + c0 + 4);
+        const float4 h0 = *reinterpret_cast<const float4*>(ldsSS + a.Ci + c0), h1 = *reinterpret_cast<const float4*>(ldsSS + a.Ci + c0 + 4);
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+        // 16 * max(z*scale + shift, 0) == max(z*(16 scale) + 16 shift, 0): ldsSS holds the coefficients times 2^4 (exact)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] * sc[k] + sh[k], 0.f);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= XSCALE;
+      }
+      q = to_fp8x8(v);
+    }
+    *reinterpret_cast<uint2*>(dst + loff) = q;
+  };
+
+  const unsigned char* __restrict__ wg_tile = a.w + (size_t)n0 * 9 * a.Ci;
+  uint4 rb[2][B_ROUNDS];
+  auto gload_B = [&](uint4 (&r)[B_ROUNDS], int chunk, int tap) {
+    const unsigned char* src = wg_tile + (size_t)tap * a.Ci + chunk * KC;
+#pragma unroll
+    for (int i = 0; i < B_ROUNDS; ++i) {
+      const int p = i * 256 + tid;
+      const int n = p >> 2, pt = p & 3;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if ((BN * 4) % 256 == 0 || n < BN) v = *reinterpret_cast<const uint4*>(src + (size_t)n * 9 * a.Ci + pt * 16);
+      r[i] = v;
+    }
+  };
+  auto swrite_B = [&](const uint4 (&r)[B_ROUNDS], int buf) {
+#pragma unroll
+    for (int i = 0; i < B_ROUNDS; ++i) {
+      const int p = i * 256 + tid;
+      const int n = p >> 2, pt = p & 3;
+      if ((BN * 4) % 256 == 0 || n < BN) *reinterpret_cast<uint4*>(ldsB + buf * B_BYTES + n * ROWB + pt * 16) = r[i];
+    }
+  };
+  auto compute = [&](int toff, int bbuf, int abuf) {
+    const char* pa = ldsA + abuf * A_BYTES + toff;
+    const char* pb = ldsB + bbuf * B_BYTES;
+    i32x8 fb[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const uint4 lo = *reinterpret_cast<const uint4*>(pb + boff[nt]);
+      const uint4 hi = *reinterpret_cast<const uint4*>(pb + boff[nt] + 16);
+      fb[nt] = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+    }
+    // one A fragment (8 registers) at a time, reused by the NT weight fragments: the 128 accumulators leave no room for four
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const uint4 lo = *reinterpret_cast<const uint4*>(pa + aoff[mt]);
+      const uint4 hi = *reinterpret_cast<const uint4*>(pa + aoff[mt] + 16);
+      const i32x8 fa = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb[nt], acc[mt][nt], 0, 0, 0, XSCALE_E8M0, 0, 127);
+    }
+  };
+
+  const int nchunks = a.Ci / KC;
+  // prologue: the whole first halo, synchronously
+  for (int i = 0; i < A_ROUNDS; ++i) {
+    int loff;
+    const T* src = piece_src(0, i, tid, loff);
+    uint4 raw = make_uint4(0, 0, 0, 0);
+    if (src) raw = *reinterpret_cast<const uint4*>(src);
+    convert_write(raw, src != nullptr, loff, ldsA, 0);
+  }
+  gload_B(rb[0], 0, 0);
+  gload_B(rb[1], 0, 1);
+  auto chunk_body = [&](auto parity, int chunk) {
+    constexpr int P0 = decltype(parity)::value;
+    const bool more = chunk + 1 < nchunks;
+    const int abuf = chunk & 1;
+    char* nextA = ldsA + (abuf ^ 1) * A_BYTES;
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int set = (P0 + tap) & 1;
+      if (set) swrite_B(rb[1], 1); else swrite_B(rb[0], 0);
+      __syncthreads();                                 // weight tile `set` (and, at tap 0, the halo written during the previous chunk) visible
+      if (tap + 2 < 9) { if (set) gload_B(rb[1], chunk, tap + 2); else gload_B(rb[0], chunk, tap + 2); }
+      else if (more) { if (set) gload_B(rb[1], chunk + 1, tap + 2 - 9); else gload_B(rb[0], chunk + 1, tap + 2 - 9); }
+      // trickle the next chunk's halo: rounds {tap, tap + 9} are loaded before this tap's MFMAs and written after them
+      uint4 raw0 = make_uint4(0, 0, 0, 0), raw1 = make_uint4(0, 0, 0, 0);
+      int loff0 = -1, loff1 = -1;
+      bool real0 = false, real1 = false;
+      if (more) {
+        if (tap < A_ROUNDS) {
+          const T* s0 = piece_src(chunk + 1, tap, tid_o, loff0);
+          real0 = s0 != nullptr;
+          if (real0) raw0 = *reinterpret_cast<const uint4*>(s0);
+        }
+        if (tap + 9 < A_ROUNDS) {
+          const T* s1 = piece_src(chunk + 1, tap + 9, tid_o, loff1);
+          real1 = s1 != nullptr;
+          if (real1) raw1 = *reinterpret_cast<const uint4*>(s1);
+        }
+      }
+      compute((tap / 3) * HROWB + (tap % 3) * ROWB, set, abuf);
+      if (more) {
+        if (tap < A_ROUNDS) convert_write(raw0, real0, loff0, nextA, chunk + 1);
+        if (tap + 9 < A_ROUNDS) convert_write(raw1, real1, loff1, nextA, chunk + 1);
+      }
+    }
+  };
+  for (int chunk = 0; chunk < nchunks; chunk += 2) {
+    chunk_body(std::integral_constant<int, 0>{}, chunk);
+    if (chunk + 1 < nchunks) chunk_body(std::integral_constant<int, 1>{}, chunk + 1);
+  }
+
+  // ---------------------------------------------------------------- epilogue (as conv_igemm_kernel, T = bf16)
+  constexpr int EPP = 8;
+  constexpr int WROWS = MT * 32, WCOLS = NT * 32;
+  constexpr int WP = WCOLS * 2 + 16;
+  constexpr int WBYTES = WROWS * WP;
+  constexpr int EPR = WCOLS / EPP;
+  constexpr int ROWS_PER_PASS = 64 / EPR;
+  constexpr int PASSES = WROWS / ROWS_PER_PASS;
+  const int ncol = n0 + wn * WCOLS;
+  T* __restrict__ yg = a.y + ncol;
+  constexpr bool want_stats = (EPI == 1);
+  __syncthreads();
+  char* wbuf = smem + wave * WBYTES;
+  float st_n[NT], st_m[NT], st_q[NT];
+  float cnt = 0.f;
+  if constexpr (want_stats) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = wm * WROWS + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
+        cnt += (bb < a.B && yy < a.H && xx < a.W) ? 1.f : 0.f;
+      }
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + (wn * NT + nt) * 32 + l31;
+    const float ws = a.wscale[n];
+    const float bias_v = a.bias ? a.bias[n] : 0.f;
+    float sc2 = 1.f, sh2 = 0.f;
+    if constexpr (EPI == 2) { sc2 = a.scale[n]; sh2 = a.shift[n]; }
+    float s = 0.f, sq = 0.f;
+    const float K = to_float(from_float<T>(acc[0][nt][0] * ws + bias_v));
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[mt][nt][r] * ws + bias_v;
+        if constexpr (EPI == 2) {
+          v = v * sc2 + sh2;
+          if (a.relu) v = fmaxf(v, 0.f);
+        }
+        const T tv = from_float<T>(v);
+        *reinterpret_cast<T*>(wbuf + row * WP + (nt * 32 + l31) * 2) = tv;
+        if constexpr (want_stats) {
+          const int m = wm * WROWS + row;
+          const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
+          if (bb < a.B && yy < a.H && xx < a.W) {
+            const float d = to_float(tv) - K;
+            s += d; sq += d * d;
+          }
+        }
+      }
+    }
+    if constexpr (want_stats) {
+      const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+      st_n[nt] = cnt; st_m[nt] = K + s * inv; st_q[nt] = fmaxf(sq - s * s * inv, 0.f);
+    }
+  }
+#pragma unroll
+  for (int pass = 0; pass < PASSES; ++pass) {
+    const int row = pass * ROWS_PER_PASS + lane / EPR;
+    const int piece = lane % EPR;
+    const uint4 v = *reinterpret_cast<const uint4*>(wbuf + row * WP + piece * 16);
+    const int m = wm * WROWS + row;
+    const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
+    if (bb < a.B && yy < a.H && xx < a.W)
+      *reinterpret_cast<uint4*>(yg + (((size_t)bb * a.H + yy) * a.W + xx) * a.Co + piece * EPP) = v;
+  }
+  if (want_stats) {
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int nl = (wn * NT + nt) * 32 + l31;
+      float n = st_n[nt], m = st_m[nt], q = st_q[nt];
+      merge_moments_f32(n, m, q, __shfl_xor(n, 32, 64), __shfl_xor(m, 32, 64), __shfl_xor(q, 32, 64));
+      if (half == 0) { ldsS[(wm * BN + nl) * 3 + 0] = n; ldsS[(wm * BN + nl) * 3 + 1] = m; ldsS[(wm * BN + nl) * 3 + 2] = q; }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float n = ldsS[tid * 3 + 0], m = ldsS[tid * 3 + 1], q = ldsS[tid * 3 + 2];
+#pragma unroll
+      for (int i = 1; i < WM; ++i)
+        merge_moments_f32(n, m, q, ldsS[(i * BN + tid) * 3 + 0], ldsS[(i * BN + tid) * 3 + 1], ldsS[(i * BN + tid) * 3 + 2]);
+      float* st = a.stats + (size_t)tile_id * 3 * a.Co;
+      st[n0 + tid] = m;
+      st[a.Co + n0 + tid] = q;
+      st[2 * a.Co + n0 + tid] = n;
+    }
+  }
+}
+
+// w [Co][Ci][9] fp32 -> wq [Co][9][Ci] e4m3 with one power-of-two scale per output channel: max |w| -> (128, 256]
+__global__ __launch_bounds__(256) void pack_weight_fp8_kernel(const float* __restrict__ w, int Ci, int taps,
+                                                               unsigned char* __restrict__ wq, float* __restrict__ wscale) {
+  __shared__ float s_max[256];
+  const int co = blockIdx.x;
+  const int per = Ci * taps;
+  const float* wc = w + (size_t)co * per;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < per; i += 256) m = fmaxf(m, fabsf(wc[i]));
+  s_max[threadIdx.x] = m;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + off]);
+    __syncthreads();
+  }
+  const float amax = s_max[0];
+  int e = 0;
+  if (amax > 0.f) { frexpf(amax, &e); }                      // amax = f * 2^e, f in [0.5, 1)
+  const float scale = amax > 0.f ? ldexpf(1.f, e - 8) : 1.f;  // amax / scale in [128, 256)
+  const float inv = 1.f / scale;
+  if (threadIdx.x == 0) wscale[co] = scale;
+  for (int i = threadIdx.x; i < per; i += 256) {
+    const int ci = i / taps, tp = i % taps;                  // source index (ci, tap)
+    const float v = fminf(fmaxf(wc[i] * inv, -FP8_MAX), FP8_MAX);
+    const int q = __builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false);
+    wq[((size_t)co * taps + tp) * Ci + ci] = (unsigned char)(q & 0xff);
+  }
+}
+
+template <int TB, int TH, int TW, int BN, int WM, int WN, int EPI>
+int launch_fp8(const Fp8ConvArgs& a_in, hipStream_t stream) {
+  Fp8ConvArgs a = a_in;
+  a.tilesY = (int)cdiv(a.H, TH);
+  a.tilesX = (int)cdiv(a.W, TW);
+  constexpr int ROWB = 80;
+  constexpr size_t smem_main = (size_t)2 * TB * (TH + 2) * ((TW + 2) * ROWB + 96) + (size_t)2 * BN * ROWB;
+  constexpr size_t smem_epi = (size_t)4 * (TB * TH * TW / WM) * ((BN / WN) * 2 + 16);
+  const size_t smem_in = smem_main + ((a.in_ss || a.in_ss_hi) ? (size_t)2 * a.Ci * sizeof(float) : 0);
+  const size_t smem = smem_in > smem_epi ? smem_in : smem_epi;
+  auto kern = conv_fp8_kernel<TB, TH, TW, BN, WM, WN, EPI>;
+  static size_t attr_set = 0;
+  if (smem > 64 * 1024 && smem > attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = smem;
+  }
+  dim3 grid((unsigned)((size_t)cdiv(a.B, TB) * a.tilesY * a.tilesX), (unsigned)(a.Co / BN));
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, a);
+  return check_launch("conv_fp8_kernel");
+}
+
+template <int TB, int TH, int TW, int BN, int WM, int WN>
+int launch_fp8_epi(const Fp8ConvArgs& a, hipStream_t stream) {
+  if (a.stats) return launch_fp8<TB, TH, TW, BN, WM, WN, 1>(a, stream);
+  if (a.scale) return launch_fp8<TB, TH, TW, BN, WM, WN, 2>(a, stream);
+  return launch_fp8<TB, TH, TW, BN, WM, WN, 0>(a, stream);
+}
+
+}  // namespace
+
+extern "C" int64_t im2im_conv_fp8_stats_rows(int32_t B, int32_t H, int32_t W) {
+  const bool small = (H < 64 || W < 64);
+  return small ? im2im::cdiv(B, 4) * im2im::cdiv(H, 8) * im2im::cdiv(W, 8) : (int64_t)B * im2im::cdiv(H, 16) * im2im::cdiv(W, 16);
+}
+
+extern "C" int im2im_pack_conv_weight_fp8(const float* w, int32_t Co, int32_t Ci, int32_t taps, void* wq, float* wscale,
+                                          im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(w && wq && wscale && Co > 0 && Ci > 0 && taps > 0);
+  hipLaunchKernelGGL(pack_weight_fp8_kernel, dim3((unsigned)Co), dim3(256), 0, stream, w, (int)Ci, (int)taps, (unsigned char*)wq, wscale);
+  return im2im::check_launch("pack_weight_fp8_kernel");
+}
+
+extern "C" int im2im_conv_fwd_fp8(const void* x, const float* in_scale_shift, const void* x_hi, const float* in_scale_shift_hi,
+                                  int32_t Ci_lo, const void* wq, const float* wscale, const float* bias, const float* scale,
+                                  const float* shift, void* y, float* stats, int32_t B, int32_t H, int32_t W, int32_t Ci,
+                                  int32_t Co, int32_t relu, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(x && wq && wscale && y);
+  if (x_hi) {
+    IM2IM_REQUIRE(Ci_lo > 0 && Ci_lo % 64 == 0 && Ci == 2 * Ci_lo);
+  } else {
+    IM2IM_REQUIRE(in_scale_shift_hi == nullptr);
+    Ci_lo = Ci;
+  }
+  IM2IM_REQUIRE(B > 0 && H > 0 && W > 0);
+  IM2IM_REQUIRE(Ci > 0 && Ci % 64 == 0 && Ci <= 2048);
+  IM2IM_REQUIRE(Co > 0 && Co % 64 == 0);
+  IM2IM_REQUIRE((scale == nullptr) == (shift == nullptr));
+  IM2IM_REQUIRE(!(stats && scale));
+  Fp8ConvArgs a{(const bf16_t*)x, (const bf16_t*)x_hi, in_scale_shift, in_scale_shift_hi, (const unsigned char*)wq, wscale, bias,
+                scale, shift, (bf16_t*)y, stats, B, H, W, Ci, Co, Ci_lo, 0, 0, relu};
+  const bool small = (H < 64 || W < 64);
+  const bool wide = Co % 128 == 0;
+  if (!small) return wide ? launch_fp8_epi<1, 16, 16, 128, 2, 2>(a, stream) : launch_fp8_epi<1, 16, 16, 64, 4, 1>(a, stream);
+  return wide ? launch_fp8_epi<4, 8, 8, 128, 2, 2>(a, stream) : launch_fp8_epi<4, 8, 8, 64, 4, 1>(a, stream);
+}

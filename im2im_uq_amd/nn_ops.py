@@ -20,18 +20,30 @@ F32 = torch.float32
 BF16 = torch.bfloat16
 _DT = {F32: 0, BF16: 1}
 
-_default_dtype = {"bf16": BF16, "bfloat16": BF16, "fp32": F32, "float32": F32}[
-    os.environ.get("IM2IM_COMPUTE_DTYPE", "bf16").lower()]
+_mode = os.environ.get("IM2IM_COMPUTE_DTYPE", "bf16").lower()
+_default_dtype = {"bf16": BF16, "bfloat16": BF16, "fp32": F32, "float32": F32, "fp8": BF16}[_mode]
+_fp8_forward = _mode == "fp8"
 
 
 def set_compute_dtype(dt) -> None:
-    """'bf16' (throughput: bf16 storage + bf16 MFMA, fp32 accumulate) or 'fp32' (exact-fp32 MFMA, parity)."""
-    global _default_dtype
-    _default_dtype = {"bf16": BF16, "fp32": F32, BF16: BF16, F32: F32}[dt]
+    """'bf16' (throughput: bf16 storage + bf16 MFMA, fp32 accumulate), 'fp32' (exact-fp32 MFMA, parity) or 'fp8' (bf16
+    storage; the FORWARD 3x3 convolutions with >= 64 channels take e4m3 operands on the block-scaled MFMA at ~2x the bf16
+    rate, everything else -- first conv, 1x1 / head convs, the whole backward pass -- as in 'bf16')."""
+    global _default_dtype, _fp8_forward
+    _default_dtype = {"bf16": BF16, "fp32": F32, "fp8": BF16, BF16: BF16, F32: F32}[dt]
+    _fp8_forward = dt == "fp8"
 
 
 def get_compute_dtype():
     return _default_dtype
+
+
+def fp8_forward() -> bool:
+    return _fp8_forward
+
+
+def compute_mode() -> str:
+    return "fp8" if _fp8_forward else ("bf16" if _default_dtype == BF16 else "fp32")
 
 
 def nhwc(x: torch.Tensor, dtype=None) -> torch.Tensor:
@@ -115,6 +127,46 @@ def pack_weight(w: torch.Tensor, dtype, want_wd=True):
     check(lib.im2im_pack_conv_weight(dptr(w), co, ci, taps, _DT[dtype], dptr(wf), dptr(wd), stream_ptr(w.device)),
           "im2im_pack_conv_weight")
     return wf, wd
+
+
+def pack_weight_fp8(w: torch.Tensor):
+    """w [Co,Ci,3,3] fp32 -> (wq uint8 [Co,9,Ci] e4m3 bytes, wscale [Co] fp32 power-of-two scales)."""
+    co, ci = w.shape[0], w.shape[1]
+    taps = w.shape[2] * w.shape[3]
+    w = w.detach()
+    if w.dtype != F32 or not w.is_contiguous():
+        w = w.to(F32).contiguous()
+    wq = torch.empty((co, taps, ci), dtype=torch.uint8, device=w.device)
+    wscale = torch.empty((co,), dtype=F32, device=w.device)
+    check(lib.im2im_pack_conv_weight_fp8(dptr(w), co, ci, taps, dptr(wq), dptr(wscale), stream_ptr(w.device)),
+          "im2im_pack_conv_weight_fp8")
+    return wq, wscale
+
+
+def fp8_eligible(ci, co, x_dtype, ci_lo=None) -> bool:
+    return _fp8_forward and x_dtype == BF16 and ci % 64 == 0 and co % 64 == 0 and (ci_lo is None or ci_lo % 64 == 0)
+
+
+def conv_fwd_fp8(x, wq, wscale, bias=None, scale_shift=None, relu=False, want_stats=False, in_ss=None, x_hi=None, in_ss_hi=None):
+    """3x3 pad-1 conv with e4m3 operands (see csrc/conv_fp8.hip): x [B,H,W,Ci] bf16 -> y [B,H,W,Co] bf16 (+ stats)."""
+    b, h, w_, ci = x.shape
+    ci_lo = ci
+    if x_hi is not None:
+        ci = 2 * ci
+    co = wq.shape[0]
+    y = torch.empty((b, h, w_, co), dtype=BF16, device=x.device)
+    stats = torch.empty((lib.im2im_conv_fp8_stats_rows(b, h, w_), 3, co), dtype=F32, device=x.device) if want_stats else None
+    sc = sh = None
+    if scale_shift is not None:
+        sc, sh = scale_shift[0], scale_shift[1]
+    small = h < 64 or w_ < 64
+    name = f"conv_fp8_kernel<{'4x8x8' if small else '1x16x16'},{128 if co % 128 == 0 else 64}>"
+    ev = TIMER.wrap(name, 2.0 * b * h * w_ * co * ci * 9, x.device) if TIMER else None
+    check(lib.im2im_conv_fwd_fp8(dptr(x), dptr(in_ss), dptr(x_hi), dptr(in_ss_hi), ci_lo, dptr(wq), dptr(wscale), dptr(bias), dptr(sc),
+                                 dptr(sh), dptr(y), dptr(stats), b, h, w_, ci, co, int(relu), stream_ptr(x.device)), "im2im_conv_fwd_fp8")
+    if ev is not None:
+        ev.record(torch.cuda.current_stream(x.device))
+    return (y, stats) if want_stats else y
 
 
 BF16_CENTERING = False    # opt-in: bf16 train mode stores z - running_mean (im2im_conv_fwd `center`); measured gain on the
@@ -361,7 +413,11 @@ class ConvStats(torch.autograd.Function):
         else:
             xin = nhwc(x.detach(), cdt)
             wf, wd = pack_weight(weight, cdt)
-            z, stats = conv_fwd(xin, wf, bias.detach(), want_stats=True, in_ss=in_ss, center=center, x_hi=xin_hi, in_ss_hi=in_ss_hi)
+            if center is None and fp8_eligible(ci, co, cdt, xin.shape[3] if xin_hi is not None else None):
+                wq, wscale = pack_weight_fp8(weight)           # forward on the block-scaled fp8 MFMA; backward stays bf16 (wd)
+                z, stats = conv_fwd_fp8(xin, wq, wscale, bias.detach(), want_stats=True, in_ss=in_ss, x_hi=xin_hi, in_ss_hi=in_ss_hi)
+            else:
+                z, stats = conv_fwd(xin, wf, bias.detach(), want_stats=True, in_ss=in_ss, center=center, x_hi=xin_hi, in_ss_hi=in_ss_hi)
         mean_invstd, scale_shift = bn_finalize(stats, b * h * w_, gamma.detach(), beta.detach(), running_mean, running_var,
                                                momentum, eps, centered=center is not None)
         ctx.small = small
@@ -512,9 +568,13 @@ def conv_bn_relu_eval(x, weight, bias, gamma, beta, running_mean, running_var, e
         xin = x.detach().to(F32).contiguous()
         _, wd = pack_weight(weight, F32)
         return nchw(smallconv_s2l(xin, wd, None, fold, co, cdt, relu=True, flip=True))
+    xin = nhwc(x.detach(), cdt)
+    xin_hi = nhwc(x_hi.detach(), cdt) if x_hi is not None else None
+    if fp8_eligible(ci, co, cdt, xin.shape[3] if xin_hi is not None else None):
+        wq, wscale = pack_weight_fp8(weight)
+        return nchw(conv_fwd_fp8(xin, wq, wscale, None, fold, relu=True, x_hi=xin_hi))
     wf, _ = pack_weight(weight, cdt, want_wd=False)
-    return nchw(conv_fwd(nhwc(x.detach(), cdt), wf, None, fold, relu=True,
-                         x_hi=nhwc(x_hi.detach(), cdt) if x_hi is not None else None))
+    return nchw(conv_fwd(xin, wf, None, fold, relu=True, x_hi=xin_hi))
 
 
 # ----------------------------------------------------------------------------------------- GroupNorm (north-star extra)

@@ -32,6 +32,9 @@ typedef void* im2im_stream_t;      /* hipStream_t */
  * throughput mode (bf16 storage + bf16 MFMA inputs, fp32 accumulate). */
 #define IM2IM_F32 0
 #define IM2IM_BF16 1
+/* operand type of the fp8 forward convolution (im2im_conv_fwd_fp8): OCP e4m3fn on the block-scaled MFMA; activations stay
+ * IM2IM_BF16 in memory.  Not a storage dtype: the entry points that take `dtype` accept IM2IM_F32 / IM2IM_BF16 only. */
+#define IM2IM_FP8 2
 
 int im2im_abi_version(void);
 const char* im2im_last_error(void);
@@ -153,6 +156,24 @@ int im2im_conv_fwd_split(const void* x, const float* in_scale_shift, const void*
                          const float* center, const float* scale, const float* shift, void* y, void* y_hi,
                          int32_t Co_lo, float* stats, int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co,
                          int32_t taps, int32_t relu, int32_t dtype, im2im_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * fp8 forward convolution (BASELINE configs[4] "fp8 MFMA conv path"): 3x3 pad-1 conv whose operands are OCP e4m3 on
+ * v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64, ~2x the bf16 MFMA rate), fp32 accumulate, bf16 in/out.  Same contract as
+ * im2im_conv_fwd_split with dtype IM2IM_BF16 and taps = 9 (the nn.Conv2d forward of unet_parts.py:16,19), except:
+ *   wq / wscale come from im2im_pack_conv_weight_fp8: wq [Co][9][Ci] e4m3 bytes = w / wscale[co], wscale[co] the power
+ *     of two that maps the channel's max |w| into (128, 256];
+ *   x (bf16, optionally the producer's pre-BatchNorm z with lazy coefficients) is scaled by 2^4, clamped to +-448 and
+ *     converted to e4m3 while it is staged into LDS (the 2^4 is undone by the instruction's block scale);
+ *   Ci % 64 == 0 (Ci_lo % 64 == 0 when split), Co % 64 == 0; no split output, no `center`.
+ * stats rows: im2im_conv_fp8_stats_rows(B, H, W).  The backward pass uses the bf16 kernels. */
+int64_t im2im_conv_fp8_stats_rows(int32_t B, int32_t H, int32_t W);
+int im2im_pack_conv_weight_fp8(const float* w, int32_t Co, int32_t Ci, int32_t taps, void* wq, float* wscale,
+                               im2im_stream_t stream);
+int im2im_conv_fwd_fp8(const void* x, const float* in_scale_shift, const void* x_hi, const float* in_scale_shift_hi,
+                       int32_t Ci_lo, const void* wq, const float* wscale, const float* bias, const float* scale,
+                       const float* shift, void* y, float* stats, int32_t B, int32_t H, int32_t W, int32_t Ci,
+                       int32_t Co, int32_t relu, im2im_stream_t stream);
 
 /* Data-gradient of a convolution whose input was a lazy BatchNorm+ReLU activation (unet_parts.py:16-21 chained): dx is
  * the gradient da of that activation, and the epilogue that writes it also reads the producer's pre-BN output bn_z

@@ -109,12 +109,50 @@ def _operand(w, emulate):
     return _RoundFwd.apply(w) if emulate else w
 
 
+# ---- fp8 operand emulation (the 'fp8' compute mode, csrc/conv_fp8.hip) -------------------------------------------------
+# Forward 3x3 convolutions with Ci % 64 == 0 and Co % 64 == 0 take OCP e4m3 operands: the input activation is scaled by
+# 2^4, clamped to +-448 and rounded to e4m3; each output channel's weights are divided by the power of two that maps the
+# channel's max |w| into [128, 256) and rounded to e4m3; products accumulate in fp32.  Values pass through rounded,
+# gradients pass through untouched (the backward kernels run on the bf16 tensors).
+FP8_MAX = 448.0
+
+
+class _Fp8Fwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        q = (x * scale).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).to(torch.float32)
+        return q / scale
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def fp8_activation(x):
+    return _Fp8Fwd.apply(x, 16.0)
+
+
+def fp8_weight(w):
+    amax = w.detach().abs().amax(dim=(1, 2, 3), keepdim=True)
+    e = torch.floor(torch.log2(amax.clamp_min(1e-38))) + 1          # amax = f * 2^e, f in [0.5, 1)  (frexp)
+    scale = torch.where(amax > 0, torch.exp2(e - 8), torch.ones_like(amax))
+    return _Fp8Fwd.apply(w, 1.0 / scale)
+
+
+def fp8_eligible(w):
+    return w.shape[1] % 64 == 0 and w.shape[0] % 64 == 0 and w.shape[2] == 3
+
+
 def double_conv(x, state, prefix, training, emulate_bf16=False):
-    """(conv3x3 pad1 + bias -> BatchNorm2d -> ReLU) x 2, unet_parts.py:15-25."""
+    """(conv3x3 pad1 + bias -> BatchNorm2d -> ReLU) x 2, unet_parts.py:15-25.  emulate_bf16 = "fp8": bf16 storage as
+    for True, plus e4m3 operands in the eligible forward convolutions."""
     p = f"baseModel.{prefix}.double_conv"
     for idx in (0, 3):
         w = state[f"{p}.{idx}.weight"]
-        if w.shape[1] > 8:                      # the <=8-channel first conv runs on fp32 weights in the kernels
+        if emulate_bf16 == "fp8" and fp8_eligible(w):
+            w = fp8_weight(w)
+            x = fp8_activation(x)
+        elif w.shape[1] > 8:                    # the <=8-channel first conv runs on fp32 weights in the kernels
             w = _operand(w, emulate_bf16)
         x = F.conv2d(x, w, state[f"{p}.{idx}.bias"], padding=1)
         if f"{p}.{idx + 1}.running_mean" not in state:

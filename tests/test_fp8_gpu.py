@@ -1,0 +1,186 @@
+"""fp8 forward convolution (BASELINE configs[4]: "fp8 MFMA conv path"): OCP e4m3 operands on the block-scaled MFMA
+(v_mfma_scale_f32_32x32x64_f8f6f4), fp32 accumulate, bf16 storage; backward in bf16.
+
+Parity is stated two ways: (1) against the SAME arithmetic evaluated on the CPU -- operands rounded to e4m3 by the rules
+of csrc/conv_fp8.hip (activation x 2^4, clamp +-448; weights / per-channel power of two), fp32 F.conv2d -- which isolates
+the kernel from the number format: tight; (2) against the reference's fp32 arithmetic, which measures what e4m3 (3
+mantissa bits) costs: ~3 % per layer, ~11 % through the 17 eligible layers of the UNet (stated bounds below)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+F32, BF16 = torch.float32, torch.bfloat16
+PARAMS = dict(uncertainty_type="quantiles", q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1,
+              alpha=0.1, delta=0.1, num_lambdas=50, rcps_loss="fraction_missed", minimum_lambda=0, maximum_lambda=6,
+              device=DEV, dataset="synthetic", batch_size=8, lr=1e-3, input_normalization="standard",
+              output_normalization="min-max", num_validation_images=2)
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.fixture(autouse=True)
+def _restore_dtype():
+    from im2im_uq_amd import nn_ops
+    yield
+    nn_ops.set_compute_dtype("bf16")
+
+
+FP8_CASES = [
+    # B, H, W, Ci, Co, split
+    (2, 20, 24, 64, 64, False),        # 4x8x8 tiles, BN=64, overhang
+    (1, 40, 40, 128, 128, False),      # 4x8x8 tiles, BN=128, two chunks
+    (2, 70, 66, 64, 64, False),        # 16x16 tiles, BN=64, overhang
+    (1, 80, 72, 64, 128, False),       # 16x16 tiles, BN=128
+    (1, 64, 64, 192, 64, False),       # three chunks (both parities of the unrolled body)
+    (2, 36, 20, 128, 64, True),        # split input 64 + 64
+    (1, 96, 80, 256, 128, True),       # split input 128 + 128, 16x16 tiles
+    (5, 9, 7, 256, 256, False),        # deep-level style, B not a multiple of the 4 images per tile
+]
+
+
+@pytest.mark.parametrize("case", FP8_CASES)
+def test_conv_fwd_fp8_vs_cpu_on_identically_quantised_operands(case):
+    from im2im_uq_amd import nn_ops
+    from oracle import model as om
+    b, h, w, ci, co, split = case
+    x = rnd(b, ci, h, w, seed=1).abs() * 0.8                    # post-ReLU-like activations
+    wt = rnd(co, ci, 3, 3, seed=2, scale=(ci * 9) ** -0.5)
+    wt[3] *= 40.0                                               # one channel with a very different weight scale
+    bias = rnd(co, seed=3, scale=0.1)
+    xq = x.to(BF16).to(F32)
+    ref = F.conv2d(om.fp8_activation(xq), om.fp8_weight(wt), bias, padding=1)
+    x_d = x.to(DEV).permute(0, 2, 3, 1).contiguous().to(BF16)
+    wq, wscale = nn_ops.pack_weight_fp8(wt.to(DEV))
+    # packed weights are exactly the emulation's
+    deq = (wq.view(torch.float8_e4m3fn).to(F32) * wscale[:, None, None]).cpu().view(co, 3, 3, ci).permute(0, 3, 1, 2)
+    assert torch.equal(deq, om.fp8_weight(wt))
+    if split:
+        lo, hi = x_d[..., : ci // 2].contiguous(), x_d[..., ci // 2:].contiguous()
+        y, stats = nn_ops.conv_fwd_fp8(lo, wq, wscale, bias.to(DEV), want_stats=True, x_hi=hi)
+    else:
+        y, stats = nn_ops.conv_fwd_fp8(x_d, wq, wscale, bias.to(DEV), want_stats=True)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert rel_l2(got, ref) < 4e-3                              # bf16 rounding of the stored result
+    assert float((got - ref).abs().max()) < 3e-2 * float(ref.abs().max())
+    # BatchNorm partial statistics describe the stored values
+    st = stats.double().cpu()
+    n = st[:, 2].sum(0)
+    mean = (st[:, 2] * st[:, 0]).sum(0) / n
+    yst = y.double().cpu().reshape(-1, co)
+    assert float((n - yst.shape[0]).abs().max()) == 0.0
+    np.testing.assert_allclose(mean.numpy(), yst.mean(0).numpy(), rtol=1e-5, atol=1e-6)
+    # folded affine + ReLU epilogue (eval mode)
+    ss = torch.stack([rnd(co, seed=4).abs() + 0.5, rnd(co, seed=5)]).to(DEV)
+    args = dict(x_hi=hi) if split else {}
+    y2 = nn_ops.conv_fwd_fp8(lo if split else x_d, wq, wscale, None, ss, relu=True, **args).float().cpu().permute(0, 3, 1, 2)
+    ref2 = F.relu(F.conv2d(om.fp8_activation(xq), om.fp8_weight(wt), None, padding=1) * ss[0].cpu()[None, :, None, None]
+                  + ss[1].cpu()[None, :, None, None])
+    assert rel_l2(y2, ref2) < 4e-3
+
+
+def test_conv_fwd_fp8_lazy_batchnorm_input_and_saturation():
+    """the staging applies max(z*scale+shift, 0) (lazy BatchNorm+ReLU) before the e4m3 conversion, and values beyond the
+    e4m3 range saturate at 448/16 = 28 instead of turning into NaN."""
+    from im2im_uq_amd import nn_ops
+    from oracle import model as om
+    b, h, w, ci, co = 2, 24, 20, 64, 64
+    z = rnd(b, ci, h, w, seed=1)
+    z[0, 0, 0, 0] = 900.0                                        # -> activation far beyond 28
+    ss = torch.stack([1.0 + 0.2 * rnd(ci, seed=2), 0.3 * rnd(ci, seed=3)])
+    wt = rnd(co, ci, 3, 3, seed=4, scale=0.04)
+    zq = z.to(BF16).to(F32)
+    a = F.relu(zq * ss[0][None, :, None, None] + ss[1][None, :, None, None])
+    ref = F.conv2d(om.fp8_activation(a), om.fp8_weight(wt), None, padding=1)
+    z_d = z.to(DEV).permute(0, 2, 3, 1).contiguous().to(BF16)
+    wq, wscale = nn_ops.pack_weight_fp8(wt.to(DEV))
+    y = nn_ops.conv_fwd_fp8(z_d, wq, wscale, None, in_ss=ss.to(DEV)).float().cpu().permute(0, 3, 1, 2)
+    assert bool(torch.isfinite(y).all())
+    assert rel_l2(y, ref) < 4e-3
+
+
+def _build(dt):
+    from im2im_uq_amd import nn_ops
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from im2im_uq_amd.core.models.trunks.unet import UNet
+    from oracle import model as om
+    nn_ops.set_compute_dtype(dt)
+    model = add_uncertainty(UNet(1, 1), dict(PARAMS))
+    model.load_state_dict(om.det_state(1, 1))
+    return model.to(DEV)
+
+
+def test_unet_fp8_mode_vs_emulating_oracle_and_vs_fp32_reference():
+    """full network, 96x96: against the oracle with e4m3 operands in the 17 eligible convs (eval 2 %, train 5 %, loss
+    2 %), and against the reference's fp32 outputs (G4 fixture, 32x32 eval): 20 % -- e4m3's price, measured 11 %."""
+    from oracle import model as om
+    x, y = om.det_images(4, 1, 96, 96, salt=7)
+    model = _build("fp8")
+    model.eval()
+    with torch.no_grad():
+        out = model(x.to(DEV))
+        ref = om.model_forward(x, om.det_state(1, 1), training=False, emulate_bf16="fp8")
+    assert rel_l2(out.cpu(), ref) < 2e-2
+    model.train()
+    pred = model(x.to(DEV))
+    loss = model.loss_fn(pred, y.to(DEV))
+    loss.backward()
+    with torch.no_grad():
+        ref_t = om.model_forward(x, om.det_state(1, 1), training=True, emulate_bf16="fp8")
+        ref_loss = om.quantile_loss(ref_t, y, PARAMS)
+    assert rel_l2(pred.detach().cpu(), ref_t) < 5e-2
+    assert loss.item() == pytest.approx(ref_loss.item(), rel=2e-2)
+    assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+    g = load_golden("g4_model_fwd_nin1")
+    model.eval()
+    with torch.no_grad():
+        out32 = model(torch.from_numpy(g["x"]).to(DEV))
+    assert rel_l2(out32.cpu(), torch.from_numpy(g["out_eval"])) < 0.2
+
+
+def test_fp8_mode_trains_and_calibrates():
+    """configs[4]-shaped smoke with parity of the outcome: 2 input channels, fp8 forward + bf16 backward trains (loss falls
+    like the bf16 run's, within 15 %) and the calibrated model holds the risk."""
+    from im2im_uq_amd import nn_ops
+    from im2im_uq_amd.core.calibration.calibrate_model import calibrate_model
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from im2im_uq_amd.core.models.trunks.unet import UNet
+    from im2im_uq_amd.core.scripts.eval import eval_set_metrics
+    from torch.utils.data import TensorDataset
+    g = torch.Generator().manual_seed(3)
+    y = torch.rand(48, 1, 64, 64, generator=g)
+    x = torch.cat([y + 0.1 * torch.randn(48, 1, 64, 64, generator=g), y + 0.2 * torch.randn(48, 1, 64, 64, generator=g)], dim=1)
+    x, y = x.to(DEV), y.to(DEV)
+    tails = {}
+    for dt in ("bf16", "fp8"):
+        nn_ops.set_compute_dtype(dt)
+        torch.manual_seed(0)
+        model = add_uncertainty(UNet(2, 1), dict(PARAMS, num_lambdas=100)).to(DEV).train()
+        opt = nn_ops.FusedAdam(model.parameters(), lr=1e-3)
+        losses = []
+        for step in range(150):
+            s = (step % 2) * 16
+            loss = model.loss_fn(model(x[s:s + 16]), y[s:s + 16])
+            losses.append(loss.detach())
+            opt.zero_grad(); loss.backward(); opt.step()
+        losses = torch.stack(losses).cpu().numpy()
+        assert np.isfinite(losses).all() and losses[-30:].mean() < 0.2 * losses[0]
+        tails[dt] = float(losses[-30:].mean())
+        cfg = dict(PARAMS, num_lambdas=100, batch_size=16)
+        model, _ = calibrate_model(model, TensorDataset(x[32:], y[32:]), cfg)
+        torch.manual_seed(0); np.random.seed(0)
+        risk = float(eval_set_metrics(model, TensorDataset(x[:32], y[:32]), cfg)[0])
+        assert 0 < float(model.lhat) <= 6.0 and risk <= 0.1 + 0.02
+    assert abs(tails["fp8"] / tails["bf16"] - 1.0) < 0.15, tails
