@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0          # dense MFMA peak, MI355X_MICROARCH.md
 PEAK_FP32_TFLOPS = 157.3           # v_mfma_f32_32x32x2_f32 = the fp32 vector rate
+PEAK_FP8_TFLOPS = 5000.0           # dense MX-scaled fp8 MFMA peak (K = 64 / 128 forms), MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 MEASURED_BF16_RANDOM_TFLOPS = 1981.0   # register-only v_mfma_f32_32x32x16_bf16 loop on random operands, this part, profiles/r01_hwprobe.txt
 
@@ -47,7 +48,7 @@ CONFIGS = {
     "temca1024": dict(label="TEMCA2-shaped 1024x1024 tiles, 5-level (deeper) UNet (BASELINE configs[3])",
                       size=1024, n_in=1, depth=5, batch=4, calib_total=64, num_lambdas=100, lam=(7.0, 10.0), dtype="bf16"),
     "bsbcm512": dict(label="BSBCM-shaped 512x512, 2 input channels, 4-level UNet (BASELINE configs[4])",
-                     size=512, n_in=2, depth=4, batch=16, calib_total=256, num_lambdas=2000, lam=(0.0, 6.0), dtype="bf16"),
+                     size=512, n_in=2, depth=4, batch=16, calib_total=256, num_lambdas=2000, lam=(0.0, 6.0), dtype="fp8"),
 }
 
 
@@ -141,7 +142,8 @@ def main():
     ap.add_argument("--calib-images", type=int, default=None, help="calibration images per GPU (default: the config's total / N)")
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--depth", type=int, default=None)
-    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32", "fp8"],
+                    help="bf16 (default) | fp32 (parity mode) | fp8 (bf16 storage, e4m3 operands in the forward 3x3 convs)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -251,7 +253,7 @@ def main():
         return float(t.item())
 
     legs = set(args.legs.split(","))
-    peak = PEAK_BF16_TFLOPS if conf["dtype"] == "bf16" else PEAK_FP32_TFLOPS
+    peak = PEAK_FP32_TFLOPS if conf["dtype"] == "fp32" else PEAK_BF16_TFLOPS
     # ---------------------------------------------------------------- train leg
     model.train()
     if "train" in legs:
@@ -262,7 +264,7 @@ def main():
     train_ips = global_batch * args.steps / dt_train
 
     # ---------------------------------------------------------------- roofline leg (HIP events per conv launch)
-    roof = roof_w = per_kernel = None
+    roof = roof_w = per_kernel = roof_dgrad = None
     if not args.no_roofline:
         nn_ops.TIMER = nn_ops.KernelTimer()
         for _ in range(2):
@@ -279,6 +281,16 @@ def main():
                     "traffic": None, "launches_per_step": n // 2, "avg_launch_ms": t / n,
                     "algorithmic_gflop_per_launch": f / n / 1e9}
         roof = dict(agg(ig), kernel="conv_igemm_kernel (forward + data-gradient launches, all tile variants)")
+        f8 = [(n, f, t) for k, (n, f, t) in rows.items() if k.startswith("conv_fp8")]
+        if f8:                          # fp8 mode: the forward convs run on the block-scaled fp8 MFMA -> priced against ITS peak
+            n8, fl8, t8 = sum(a for a, _, _ in f8), sum(b for _, b, _ in f8), sum(c for _, _, c in f8)
+            roof_fp8 = {"bound": "mfma", "achieved": fl8 / t8 / 1e9, "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s",
+                        "frac": fl8 / t8 / 1e9 / PEAK_FP8_TFLOPS, "traffic": None, "launches_per_step": n8 // 2, "avg_launch_ms": t8 / n8,
+                        "algorithmic_gflop_per_launch": fl8 / n8 / 1e9, "kernel": "conv_fp8_kernel (forward 3x3 convs, e4m3 operands)"}
+            roof = dict(roof, kernel="conv_igemm_kernel (bf16: data-gradient launches + the non-eligible forward convs)")
+            roof, roof_dgrad = roof_fp8, roof
+        else:
+            roof_dgrad = None
         if conf["dtype"] == "bf16":
             # second stated peak: what the MFMA pipe sustains on random (non-zero) operands on this power-limited part
             roof["peak_random_operands"] = MEASURED_BF16_RANDOM_TFLOPS
@@ -294,7 +306,7 @@ def main():
 
     # ---------------------------------------------------------------- fp32 companion (parity mode, exact-fp32 MFMA)
     fp32 = None
-    if "train" in legs and conf["dtype"] == "bf16" and not args.no_fp32 and world == 1:
+    if "train" in legs and conf["dtype"] == "bf16" and not args.no_fp32 and world == 1 and args.config == "fastmri":
         nn_ops.set_compute_dtype("fp32")
         s32 = max(2, args.steps // 5)
         dt32 = timed(train_step, s32, 1)
@@ -414,6 +426,8 @@ def main():
                        "train_tflops": train_ips * train_flop / 1e12},
             "roofline": roof, "roofline_wgrad": roof_w, "fp32": fp32, "calib": calib, "cpu_baseline": cpu, "per_kernel": per_kernel,
         }
+        if roof_dgrad:
+            line["roofline_bf16_igemm"] = roof_dgrad
         if cpu:
             line["vs_cpu_train"] = train_ips / cpu["value"]
         print(json.dumps(line))

@@ -59,7 +59,7 @@ __device__ __forceinline__ void merge_moments_f32(float& n, float& m, float& q, 
 __device__ __forceinline__ uint2 to_fp8x8(const float (&v)[8]) {
   float c[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) c[k] = fminf(fmaxf(v[k], -FP8_MAX), FP8_MAX);
+  for (int k = 0; k < 8; ++k) c[k] = __builtin_amdgcn_fmed3f(v[k], -FP8_MAX, FP8_MAX);      // one v_med3_f32 per value
   int lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
   lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
   int hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], 0, false);
@@ -221,13 +221,20 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
   };
 
   const int nchunks = a.Ci / KC;
-  // prologue: the whole first halo, synchronously
-  for (int i = 0; i < A_ROUNDS; ++i) {
-    int loff;
-    const T* src = piece_src(0, i, tid, loff);
-    uint4 raw = make_uint4(0, 0, 0, 0);
-    if (src) raw = *reinterpret_cast<const uint4*>(src);
-    convert_write(raw, src != nullptr, loff, ldsA, 0);
+  // prologue: the whole first halo -- all its loads in flight at once (the accumulators are not live yet), then converted
+  {
+    uint4 raw[A_ROUNDS];
+    int loffs[A_ROUNDS];
+    bool real[A_ROUNDS];
+#pragma unroll
+    for (int i = 0; i < A_ROUNDS; ++i) {
+      const T* src = piece_src(0, i, tid, loffs[i]);
+      real[i] = src != nullptr;
+      raw[i] = make_uint4(0, 0, 0, 0);
+      if (real[i]) raw[i] = *reinterpret_cast<const uint4*>(src);
+    }
+#pragma unroll
+    for (int i = 0; i < A_ROUNDS; ++i) convert_write(raw[i], real[i], loffs[i], ldsA, 0);
   }
   gload_B(rb[0], 0, 0);
   gload_B(rb[1], 0, 1);
