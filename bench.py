@@ -46,7 +46,7 @@ CONFIGS = {
     "denoise32": dict(label="32x32 synthetic Gaussian-denoise, 2-level UNet (BASELINE configs[0])",
                       size=32, n_in=1, depth=2, batch=32, calib_total=64, num_lambdas=50, lam=(0.0, 6.0), dtype="bf16"),
     "temca1024": dict(label="TEMCA2-shaped 1024x1024 tiles, 5-level (deeper) UNet (BASELINE configs[3])",
-                      size=1024, n_in=1, depth=5, batch=4, calib_total=64, num_lambdas=100, lam=(7.0, 10.0), dtype="bf16"),
+                      size=1024, n_in=1, depth=5, batch=4, calib_total=256, num_lambdas=100, lam=(7.0, 10.0), dtype="bf16"),
     "bsbcm512": dict(label="BSBCM-shaped 512x512, 2 input channels, 4-level UNet (BASELINE configs[4])",
                      size=512, n_in=2, depth=4, batch=16, calib_total=256, num_lambdas=2000, lam=(0.0, 6.0), dtype="fp8"),
 }
@@ -329,11 +329,11 @@ def main():
     # ---------------------------------------------------------------- calibration leg
     # Labels are built from the model's own eval outputs (untimed) so that the scan stops mid-grid like a trained model's
     # does: y = pred + s*z*(half-width on that side), z ~ N(0,1)  =>  the miss rate at lambda is P(|z| > lambda/s); with
-    # s = mid-grid / 1.8 the Hoeffding-Bentkus bound crosses alpha = 0.1 a little below the middle of the grid (~55 % visited).
+    # s = mid-grid / 1.96 (5 % missed at mid-grid) the Hoeffding-Bentkus bound crosses alpha = 0.1 below the middle of the grid (~55-60 % visited).
     model.eval()
     xc = torch.randn(M, n_in, hw, hw, device=dev, generator=g)
     yc = torch.empty(M, 1, hw, hw, device=dev)
-    s_lab = (conf["lam"][0] + conf["lam"][1]) / 2 / 1.8
+    s_lab = (conf["lam"][0] + conf["lam"][1]) / 2 / 1.96
     if args.uncertainty_type == "quantiles":
         with torch.no_grad():
             for s in range(0, M, 64):
