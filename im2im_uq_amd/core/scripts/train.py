@@ -65,6 +65,9 @@ class GradSync:
     def __init__(self, params, bucket_bytes=8 << 20):
         self.params = [p for p in params if p.requires_grad]
         self.dist = _dist()
+        # gradients are ACCUMULATED into the flat buffer on the main stream as soon as a backward function returns them, so
+        # the weight-gradient kernels must run on that stream too
+        nn_ops.WGRAD_SIDE_STREAM = False
         dev = self.params[0].device
         self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
         off = 0

@@ -64,8 +64,8 @@ class _Scratch:
     bufs = {}
 
     @classmethod
-    def get(cls, nbytes: int, device) -> torch.Tensor:
-        key = (torch.device(device).index, "a")
+    def get(cls, nbytes: int, device, key: str = "a") -> torch.Tensor:
+        key = (torch.device(device).index, key)
         buf = cls.bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -240,7 +240,55 @@ def bn_relu_bwd_from_partial(da, z, scale_shift, mean_invstd, partial):
     return dz, dgamma, dbeta
 
 
-def conv_wgrad(x, dz, taps, x_ss=None, x_hi=None, x_ss_hi=None):
+# ---- second stream for the weight gradients --------------------------------------------------------------------------
+# In the backward pass the weight gradient of a conv (MFMA-bound, needs only dz and the saved input) is independent of the
+# chain  data-gradient -> BatchNorm backward of the producer -> next layer ...  whose BatchNorm / pooling / upsampling
+# kernels are HBM-bound.  Launched on a second HIP stream the two kinds of kernels share the chip: the side passes run in
+# the memory system while the matrix cores work on dW.  The streams meet again when the backward pass ends (an autograd
+# engine callback) and, defensively, before the optimizer reads the gradients.
+WGRAD_SIDE_STREAM = os.environ.get("IM2IM_WGRAD_STREAM", "1") != "0"
+_side_streams = {}
+_side_busy = set()
+_callback_queued = set()
+
+
+def side_stream(device):
+    idx = torch.device(device).index
+    st = _side_streams.get(idx)
+    if st is None:
+        st = _side_streams[idx] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_side_streams():
+    """make the current stream of every device wait for the weight-gradient stream's work."""
+    for idx in list(_side_busy):
+        torch.cuda.current_stream(idx).wait_stream(_side_streams[idx])
+    _side_busy.clear()
+    _callback_queued.clear()
+
+
+def _on_side_stream(device, tensors_in, fn):
+    """run fn() on the device's side stream after everything already queued on the current stream; inputs are kept alive
+    for the side stream, outputs handed back to the current one."""
+    main = torch.cuda.current_stream(device)
+    side = side_stream(device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        out = fn()
+    for t in tensors_in:
+        if t is not None and t.numel():
+            t.record_stream(side)
+    out.record_stream(main)
+    idx = torch.device(device).index
+    _side_busy.add(idx)
+    if idx not in _callback_queued:                      # join when this backward pass ends
+        _callback_queued.add(idx)
+        torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+    return out
+
+
+def conv_wgrad(x, dz, taps, x_ss=None, x_hi=None, x_ss_hi=None, scratch_key="a"):
     """x [B,H,W,Ci], dz [B,H,W,Co] -> dw [Co,Ci,taps] fp32 (x_ss: lazy BatchNorm+ReLU of x, as in conv_fwd; x_hi: second
     half of the input channels as in conv_fwd)."""
     b, h, w_, ci = x.shape
@@ -251,7 +299,7 @@ def conv_wgrad(x, dz, taps, x_ss=None, x_hi=None, x_ss_hi=None):
     nbytes = lib.im2im_conv_wgrad_workspace_bytes(b, h, w_, ci, co, taps)
     if nbytes < 0:
         raise _lib.Im2ImError(f"conv wgrad: unsupported channels Ci={ci} Co={co}")
-    ws = _Scratch.get(nbytes, x.device)
+    ws = _Scratch.get(nbytes, x.device, scratch_key)
     dw = torch.empty((co, ci, taps), dtype=F32, device=x.device)
     ev = TIMER.wrap(_tile_name("wgrad", h, w_, co, taps, x.dtype), 2.0 * b * h * w_ * co * ci * taps, x.device) if TIMER else None
     check(lib.im2im_conv_wgrad_split(dptr(x), dptr(x_ss), dptr(x_hi), dptr(x_ss_hi), ci_lo, dptr(dz), dptr(dw), dptr(ws), ws.numel(),
@@ -445,7 +493,12 @@ class ConvStats(torch.autograd.Function):
                 dx = smallconv_l2s(dz, wd, None, xin.shape[1])      # [B,Cin,H,W] fp32: correlation with the flipped taps
         else:
             ci = xin.shape[3] * (2 if xin_hi is not None else 1)
-            dw = conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi).view(dz.shape[3], ci, 3, 3)
+            if WGRAD_SIDE_STREAM and not torch.is_grad_enabled():
+                dw = _on_side_stream(dz.device, (xin, dz, in_ss, xin_hi, in_ss_hi),
+                                     lambda: conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi, scratch_key="side"))
+                dw = dw.view(dz.shape[3], ci, 3, 3)
+            else:
+                dw = conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi).view(dz.shape[3], ci, 3, 3)
             if xin_hi is not None:
                 # the data-gradient lands directly in d(skip) and d(up): no concatenated gradient tensor
                 dx, dx_hi = conv_fwd(dz, wd, split_out=xin.shape[3])
@@ -1194,6 +1247,7 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        join_side_streams()                       # weight gradients computed on the second stream (no-op when none are pending)
         for group in self.param_groups:
             by_step = {}                      # bias correction is per parameter (torch.optim.Adam): one launch per distinct step count
             for p in group["params"]:
