@@ -493,12 +493,8 @@ class ConvStats(torch.autograd.Function):
                 dx = smallconv_l2s(dz, wd, None, xin.shape[1])      # [B,Cin,H,W] fp32: correlation with the flipped taps
         else:
             ci = xin.shape[3] * (2 if xin_hi is not None else 1)
-            if WGRAD_SIDE_STREAM and not torch.is_grad_enabled():
-                dw = _on_side_stream(dz.device, (xin, dz, in_ss, xin_hi, in_ss_hi),
-                                     lambda: conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi, scratch_key="side"))
-                dw = dw.view(dz.shape[3], ci, 3, 3)
-            else:
-                dw = conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi).view(dz.shape[3], ci, 3, 3)
+            # data-gradient first: the chain it feeds (BatchNorm backward of the producer, pooling / upsampling backward) is
+            # HBM-bound and is what the weight gradient, launched behind it on the second stream, runs alongside
             if xin_hi is not None:
                 # the data-gradient lands directly in d(skip) and d(up): no concatenated gradient tensor
                 dx, dx_hi = conv_fwd(dz, wd, split_out=xin.shape[3])
@@ -511,6 +507,12 @@ class ConvStats(torch.autograd.Function):
                     dx = nchw(dx)
                 else:
                     dx = nchw(conv_fwd(dz, wd))           # gradient w.r.t. the (lazy) input activation
+            if WGRAD_SIDE_STREAM and not torch.is_grad_enabled():
+                dw = _on_side_stream(dz.device, (xin, dz, in_ss, xin_hi, in_ss_hi),
+                                     lambda: conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi, scratch_key="side"))
+                dw = dw.view(dz.shape[3], ci, 3, 3)
+            else:
+                dw = conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi).view(dz.shape[3], ci, 3, 3)
         return dx, dx_hi, dw, None, None, None, None, None, None, None, None
 
 
