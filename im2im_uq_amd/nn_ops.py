@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -244,8 +245,9 @@ def bn_relu_bwd_from_partial(da, z, scale_shift, mean_invstd, partial):
 # In the backward pass the weight gradient of a conv (MFMA-bound, needs only dz and the saved input) is independent of the
 # chain  data-gradient -> BatchNorm backward of the producer -> next layer ...  whose BatchNorm / pooling / upsampling
 # kernels are HBM-bound.  Launched on a second HIP stream the two kinds of kernels share the chip: the side passes run in
-# the memory system while the matrix cores work on dW.  The streams meet again when the backward pass ends (an autograd
-# engine callback) and, defensively, before the optimizer reads the gradients.
+# the memory system while the matrix cores work on dW.  Measured on MI355X (bench.py, batch 78): 46.0 -> 44.2 ms per step
+# (+4 %); launching dW only after the data-gradient gave nothing (46.7 ms) -- profiles/README.md.  The streams meet again
+# when the backward pass ends (an autograd engine callback) and, defensively, before the optimizer reads the gradients.
 WGRAD_SIDE_STREAM = os.environ.get("IM2IM_WGRAD_STREAM", "1") != "0"
 _side_streams = {}
 _side_busy = set()
@@ -469,6 +471,7 @@ class ConvStats(torch.autograd.Function):
         mean_invstd, scale_shift = bn_finalize(stats, b * h * w_, gamma.detach(), beta.detach(), running_mean, running_var,
                                                momentum, eps, centered=center is not None)
         ctx.small = small
+        ctx.weight_ref = weakref.ref(weight) if isinstance(weight, torch.nn.Parameter) or weight.is_leaf else None
         ctx.has = (in_ss is not None, xin_hi is not None, in_ss_hi is not None)
         ctx.set_materialize_grads(False)              # no zero tensors for the two non-differentiable outputs
         none = torch.empty(0)
@@ -493,8 +496,15 @@ class ConvStats(torch.autograd.Function):
                 dx = smallconv_l2s(dz, wd, None, xin.shape[1])      # [B,Cin,H,W] fp32: correlation with the flipped taps
         else:
             ci = xin.shape[3] * (2 if xin_hi is not None else 1)
-            # data-gradient first: the chain it feeds (BatchNorm backward of the producer, pooling / upsampling backward) is
-            # HBM-bound and is what the weight gradient, launched behind it on the second stream, runs alongside
+            # the weight gradient goes to the second stream (see _on_side_stream) unless autograd is about to ACCUMULATE it into
+            # an existing .grad on this stream the moment we return (gradient accumulation over several backward passes)
+            w_ref = ctx.weight_ref() if ctx.weight_ref is not None else None
+            if WGRAD_SIDE_STREAM and not torch.is_grad_enabled() and w_ref is not None and w_ref.grad is None:
+                dw = _on_side_stream(dz.device, (xin, dz, in_ss, xin_hi, in_ss_hi),
+                                     lambda: conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi, scratch_key="side"))
+                dw = dw.view(dz.shape[3], ci, 3, 3)
+            else:
+                dw = conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi).view(dz.shape[3], ci, 3, 3)
             if xin_hi is not None:
                 # the data-gradient lands directly in d(skip) and d(up): no concatenated gradient tensor
                 dx, dx_hi = conv_fwd(dz, wd, split_out=xin.shape[3])
@@ -507,12 +517,6 @@ class ConvStats(torch.autograd.Function):
                     dx = nchw(dx)
                 else:
                     dx = nchw(conv_fwd(dz, wd))           # gradient w.r.t. the (lazy) input activation
-            if WGRAD_SIDE_STREAM and not torch.is_grad_enabled():
-                dw = _on_side_stream(dz.device, (xin, dz, in_ss, xin_hi, in_ss_hi),
-                                     lambda: conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi, scratch_key="side"))
-                dw = dw.view(dz.shape[3], ci, 3, 3)
-            else:
-                dw = conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi).view(dz.shape[3], ci, 3, 3)
         return dx, dx_hi, dw, None, None, None, None, None, None, None, None
 
 
