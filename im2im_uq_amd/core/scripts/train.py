@@ -51,48 +51,45 @@ class DataParallelPassthrough(nn.Module):
 class GradSync:
     """Gradient exchange of data-parallel training (replaces nn.DataParallel's reduce-to-GPU0, reference :112-115).
 
-    All parameter gradients live in ONE pre-allocated flat fp32 buffer; every `p.grad` is a permanent view into it, so
-    autograd accumulates straight into the buffer and nothing is concatenated or copied per step.  The buffer is cut
-    into buckets in reverse registration order (the order backward produces gradients); a post-accumulate hook counts a
-    bucket's parameters down and launches its all-reduce (RCCL, asynchronous, on the communicator's own stream) the
-    moment the last one is written, so the exchange of the decoder's gradients runs under the encoder's backward.
-    `finish()` launches whatever is left, waits, and the optimizer reads the reduced views.
+    ONE pre-allocated flat fp32 buffer holds the reduced gradients; it is cut into buckets in reverse registration order
+    (the order backward produces gradients).  A post-accumulate hook counts a bucket's parameters down and, the moment the
+    last one has its gradient, packs the bucket into the flat buffer (one multi-tensor copy) and launches its all-reduce
+    (RCCL, asynchronous) -- so the exchange of the decoder's gradients runs under the encoder's backward.  Packing and the
+    collective are issued from the weight-gradient stream (nn_ops.side_stream): the conv weight gradients are computed
+    there, so the main stream's chain (data-gradients, BatchNorm backward) never waits for them.  `finish()` launches
+    whatever is left, waits, and points every `p.grad` at its slice of the flat buffer for the optimizer.
 
     Sum, not mean: the caller scales its loss by (local images / global images), so the summed gradients are the
-    gradient of the global-batch mean loss even when the global batch does not divide evenly over the ranks.
-    With one rank the class only provides the flat buffer (zero_grad = one memset)."""
+    gradient of the global-batch mean loss even when the global batch does not divide evenly over the ranks."""
 
     def __init__(self, params, bucket_bytes=8 << 20):
         self.params = [p for p in params if p.requires_grad]
         self.dist = _dist()
-        # gradients are ACCUMULATED into the flat buffer on the main stream as soon as a backward function returns them, so
-        # the weight-gradient kernels must run on that stream too
-        nn_ops.WGRAD_SIDE_STREAM = False
         dev = self.params[0].device
+        self.cuda = dev.type == "cuda"
         self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
         off = 0
-        self.buckets = []                       # [lo, hi) element ranges, first bucket = last parameters
-        self.bucket_of = {}
-        spans = []
+        self.spans = []
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            spans.append((off, off + p.numel()))
+            self.spans.append((off, off + p.numel()))
             off += p.numel()
+        self.views = [self.flat[lo:hi].view_as(p) for p, (lo, hi) in zip(self.params, self.spans)]
+        self.buckets = []                       # [lo, hi) element ranges + member indices, first bucket = last parameters
+        self.bucket_of = {}
         hi = off
         members = []
         for i in range(len(self.params) - 1, -1, -1):
             members.append(i)
-            if (hi - spans[i][0]) * 4 >= bucket_bytes or i == 0:
+            if (hi - self.spans[i][0]) * 4 >= bucket_bytes or i == 0:
                 b = len(self.buckets)
-                self.buckets.append((spans[i][0], hi))
+                self.buckets.append((self.spans[i][0], hi, tuple(members)))
                 for m in members:
                     self.bucket_of[m] = b
-                members, hi = [], spans[i][0]
+                members, hi = [], self.spans[i][0]
         self.expected = None                    # per bucket: how many parameters receive a gradient (learnt on step 1)
         self.seen = [0] * len(self.buckets)
         self.fired = set()
         self.launched = [None] * len(self.buckets)
-        self.handles = []
         if self.dist is not None:
             for i, p in enumerate(self.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
@@ -106,39 +103,57 @@ class GradSync:
                 self._launch(b)
         return hook
 
+    def _pack(self, b):
+        lo, hi, members = self.buckets[b]
+        src, dst = [], []
+        for m in members:
+            g = self.params[m].grad
+            if g is None:
+                self.views[m].zero_()
+            elif g.data_ptr() != self.views[m].data_ptr():
+                src.append(g if g.dtype == torch.float32 else g.to(torch.float32))
+                dst.append(self.views[m])
+        if src:
+            torch._foreach_copy_(dst, src)
+
     def _launch(self, b):
-        lo, hi = self.buckets[b]
-        self.launched[b] = self.dist.all_reduce(self.flat[lo:hi], async_op=True)
+        lo, hi, _ = self.buckets[b]
+        if self.cuda:
+            main = torch.cuda.current_stream(self.flat.device)
+            side = nn_ops.side_stream(self.flat.device)
+            side.wait_stream(main)              # gradients produced on the main stream (BatchNorm, biases, heads)
+            with torch.cuda.stream(side):       # ... and, in stream order, the conv weight gradients computed on this one
+                self._pack(b)
+                self.launched[b] = self.dist.all_reduce(self.flat[lo:hi], async_op=True)
+        else:
+            self._pack(b)
+            self.launched[b] = self.dist.all_reduce(self.flat[lo:hi], async_op=True)
 
     def zero_grad(self):
-        self.flat.zero_()
-        for p, (lo, hi) in zip(self.params, self._spans()):
-            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * lo:      # someone re-pointed it (zero_grad(set_to_none))
-                p.grad = self.flat[lo:hi].view_as(p)
-
-    def _spans(self):
-        off = 0
         for p in self.params:
-            yield off, off + p.numel()
-            off += p.numel()
+            p.grad = None
 
     def finish(self):
-        """call after backward(): every bucket reduced and visible to the current stream."""
-        if self.dist is None:
-            return
-        for b in range(len(self.buckets)):      # buckets no hook completed (first step, unused parameters, no local images)
-            if self.launched[b] is None:
-                self._launch(b)
-        for h in self.launched:
-            h.wait()
-        if self.expected is None:
-            exp = [0] * len(self.buckets)
-            for i in self.fired:
-                exp[self.bucket_of[i]] += 1
-            self.expected = [e if e > 0 else -1 for e in exp]
-        self.seen = [0] * len(self.buckets)
-        self.fired = set()
-        self.launched = [None] * len(self.buckets)
+        """call after backward(): every bucket reduced, visible to the current stream, and p.grad = its flat slice."""
+        if self.dist is not None:
+            for b in range(len(self.buckets)):  # buckets no hook completed (first step, unused parameters, no local images)
+                if self.launched[b] is None:
+                    self._launch(b)
+            for h in self.launched:
+                h.wait()
+            if self.expected is None:
+                exp = [0] * len(self.buckets)
+                for i in self.fired:
+                    exp[self.bucket_of[i]] += 1
+                self.expected = [e if e > 0 else -1 for e in exp]
+            self.seen = [0] * len(self.buckets)
+            self.fired = set()
+            self.launched = [None] * len(self.buckets)
+        else:
+            for b in range(len(self.buckets)):
+                self._pack(b)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
 
 def allreduce_gradients(params):
