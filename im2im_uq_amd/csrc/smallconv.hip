@@ -248,6 +248,254 @@ __global__ __launch_bounds__(256) void smallconv_l2s_kernel(L2SArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// MFMA forms of the two "few channels on one side" convolutions that dominate the tail of the network at full
+// resolution.  The VALU kernels above issue ~1 instruction per MAC and are issue-bound (the heads forward read its
+// 0.5 GB at 1.2 TB/s); on the matrix cores the same work is a sliver of MFMA time even though only CS of the 32 output
+// columns of a tile are real, and the kernels become HBM-bound.
+//   l2s (heads forward):  out[px][s] = bias[s] + sum_{tap,c} F[px+tap][c] * w[s][tap][c]
+//       A = the halo tile of the feature map in LDS (rows = pixels, as conv_mfma.hip), B = the CS weight rows.  bf16:
+//       the fp32 weights enter as hi + lo bf16 pairs (two MFMAs), which keeps 16 mantissa bits of them -- the VALU
+//       kernel multiplies bf16 features by fp32 weights, and the results agree to ~1e-5; fp32: v_mfma_f32_32x32x2_f32.
+//   s2l with flip (heads data-gradient):  dF[px][c] = sum_{tap,s} g[s][px-tap] * w[s][tap][c]
+//       K = (tap, s) with 8 s-slots per tap, so a lane's 8 k-values of one MFMA k-step are the 8 planes of ONE halo pixel:
+//       one ds_read_b128 of the [halo px][8] gradient tile.
+template <typename T> struct SmallFrag;
+template <> struct SmallFrag<bf16_t> {
+  using AB = short8;
+  static constexpr int KPS = 16;                      // k per MFMA step
+  static __device__ __forceinline__ AB load(const char* p) { return *reinterpret_cast<const AB*>(p); }
+  static __device__ __forceinline__ f32x16 mfma(AB a, AB b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
+  }
+};
+template <> struct SmallFrag<float> {
+  using AB = float;
+  static constexpr int KPS = 2;
+  static __device__ __forceinline__ AB load(const char* p) { return *reinterpret_cast<const float*>(p); }
+  static __device__ __forceinline__ f32x16 mfma(AB a, AB b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+};
+
+template <typename T, int CL>
+__global__ __launch_bounds__(256) void smallconv_l2s_mfma_kernel(L2SArgs a) {
+  constexpr int SZ = (int)sizeof(T);
+  constexpr bool IS_BF16 = SZ == 2;
+  constexpr int N = Vec16<T>::N;
+  constexpr int PF = CL * SZ + 16;                    // halo pixel pitch
+  constexpr int HROWB = HS * PF + (IS_BF16 ? 96 : 0); // halo row pitch (bf16: conflict-free ds_read_b128 across two tile rows)
+  constexpr int F_BYTES = HS * HROWB;
+  constexpr int PW = 9 * CL * SZ + 16;                // weight row pitch
+  constexpr int NPARTS = IS_BF16 ? 2 : 1;             // bf16: hi + lo
+  constexpr int W_BYTES = NPARTS * 8 * PW;
+  constexpr int KSTEPS = CL / SmallFrag<T>::KPS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsF = smem;
+  char* ldsW = smem + F_BYTES;
+  float* ldsO = reinterpret_cast<float*>(smem + F_BYTES + W_BYTES);     // [8][256]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  int t = blockIdx.x;
+  const int tx_id = t % a.tilesX; t /= a.tilesX;
+  const int ty_id = t % a.tilesY;
+  const int b = t / a.tilesY;
+  const int y0 = ty_id * TS, x0 = tx_id * TS;
+  const T* inb = reinterpret_cast<const T*>(a.in) + (size_t)b * a.H * a.W * CL;
+  // halo tile: all loads in flight, then the LDS writes
+  constexpr int PPR = CL / N;
+  constexpr int ROUNDS = (HS * HS * PPR + 255) / 256;
+  uint4 r[ROUNDS];
+#pragma unroll
+  for (int i = 0; i < ROUNDS; ++i) {
+    const int p = i * 256 + tid;
+    const int px = p / PPR, part = p % PPR;
+    const int yy = y0 + px / HS - 1, xx = x0 + px % HS - 1;
+    r[i] = make_uint4(0, 0, 0, 0);
+    if (px < HS * HS && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
+      r[i] = *reinterpret_cast<const uint4*>(inb + ((size_t)yy * a.W + xx) * CL + part * N);
+  }
+  // weights: w [CS][9][CL] fp32 -> rows s < 8 (zero beyond CS) of T, bf16 split into hi and lo = bf16(w - hi)
+  for (int i = tid; i < 8 * 9 * CL; i += 256) {
+    const int srow = i / (9 * CL), k = i % (9 * CL);
+    const float v = srow < a.CS ? a.w[(size_t)srow * 9 * CL + k] : 0.f;
+    if constexpr (IS_BF16) {
+      const bf16_t hi = (bf16_t)v;
+      const bf16_t lo = (bf16_t)(v - (float)hi);
+      *reinterpret_cast<bf16_t*>(ldsW + srow * PW + k * 2) = hi;
+      *reinterpret_cast<bf16_t*>(ldsW + 8 * PW + srow * PW + k * 2) = lo;
+    } else {
+      *reinterpret_cast<float*>(ldsW + srow * PW + k * 4) = v;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < ROUNDS; ++i) {
+    const int p = i * 256 + tid;
+    const int px = p / PPR, part = p % PPR;
+    if (px < HS * HS) *reinterpret_cast<uint4*>(ldsF + (px / HS) * HROWB + (px % HS) * PF + part * 16) = r[i];
+  }
+  __syncthreads();
+  // wave w: output tile rows 4w .. 4w+3 as two 32-pixel MFMA row tiles
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+  int aoff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) aoff[j] = (4 * wave + 2 * j + l31 / TS) * HROWB + (l31 % TS) * PF;
+  const int boff = (l31 & 7) * PW;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int toff = (tap / 3) * HROWB + (tap % 3) * PF;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int koff = IS_BF16 ? ks * 32 + half * 16 : (ks * 2 + half) * 4;
+      const auto fb = SmallFrag<T>::load(ldsW + boff + tap * CL * SZ + koff);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const auto fa = SmallFrag<T>::load(ldsF + aoff[j] + toff + koff);
+        acc[j] = SmallFrag<T>::mfma(fa, fb, acc[j]);
+        if constexpr (IS_BF16) {
+          const auto fl = SmallFrag<T>::load(ldsW + 8 * PW + boff + tap * CL * SZ + koff);
+          acc[j] = SmallFrag<T>::mfma(fa, fl, acc[j]);
+        }
+      }
+    }
+  }
+  if (l31 < a.CS) {
+    const float bv = a.bias ? a.bias[l31] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int m = (q & 3) + 8 * (q >> 2) + 4 * half;              // pixel within the 32-pixel row tile
+        ldsO[l31 * 256 + (4 * wave + 2 * j) * TS + m] = acc[j][q] + bv;
+      }
+  }
+  __syncthreads();
+  for (int i = tid; i < a.CS * 256; i += 256) {
+    const int sidx = i >> 8, px = i & 255;
+    const int yy = y0 + px / TS, xx = x0 + px % TS;
+    if (yy < a.H && xx < a.W) a.out[(((size_t)b * a.CS + sidx) * a.H + yy) * a.W + xx] = ldsO[i];
+  }
+}
+
+// data-gradient of the heads: g [B][CS][H][W] fp32, w [CS][9][CL] fp32 (forward layout, used flipped) -> dF [B][H][W][CL] T
+template <typename T, int CL>
+__global__ __launch_bounds__(256) void smallconv_s2l_dgrad_mfma_kernel(S2LArgs a) {
+  constexpr int SZ = (int)sizeof(T);
+  constexpr bool IS_BF16 = SZ == 2;
+  constexpr int PD = 8 * SZ + (IS_BF16 ? 0 : 4);      // halo pixel pitch of the gradient tile: 8 plane slots (fp32: +4 B, odd dword pitch)
+  constexpr int D_BYTES = (HS * HS + 2) * PD;
+  constexpr int TAPS_P = IS_BF16 ? 10 : 9;            // bf16: k-steps of 16 = two taps; the tenth is zero
+  constexpr int PW = TAPS_P * 8 * SZ + (IS_BF16 ? 16 : 4);   // weight row (one per output channel c): [tap][8 slots]
+  constexpr int W_BYTES = CL * PW;
+  constexpr int NT = CL / 32;
+  constexpr int OP = CL * SZ + 16;                    // output staging pitch
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsD = smem;
+  char* ldsW = smem + ((D_BYTES + 15) & ~15);
+  char* ldsOut = ldsW + W_BYTES;                      // [256][OP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  int t = blockIdx.x;
+  const int tx_id = t % a.tilesX; t /= a.tilesX;
+  const int ty_id = t % a.tilesY;
+  const int b = t / a.tilesY;
+  const int y0 = ty_id * TS, x0 = tx_id * TS;
+  const float* gb = a.in + (size_t)b * a.CS * a.H * a.W;
+  // gradient halo tile [px][8 slots] (slots >= CS zero)
+  for (int i = tid; i < HS * HS * 8; i += 256) {
+    const int slot = i / (HS * HS), px = i % (HS * HS);             // consecutive threads -> consecutive x of one plane
+    const int yy = y0 + px / HS - 1, xx = x0 + px % HS - 1;
+    float v = 0.f;
+    if (slot < a.CS && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) v = gb[((size_t)slot * a.H + yy) * a.W + xx];
+    *reinterpret_cast<T*>(ldsD + px * PD + slot * SZ) = from_float<T>(v);
+  }
+  // weights: row c, k = (tap', slot): w[slot][8 - tap'][c]  (the correlation runs over the flipped taps)
+  for (int i = tid; i < CL * TAPS_P * 8; i += 256) {
+    const int c = i / (TAPS_P * 8), k = i % (TAPS_P * 8);
+    const int tp = k / 8, slot = k % 8;
+    float v = 0.f;
+    if (tp < 9 && slot < a.CS) v = a.w[((size_t)slot * 9 + (a.flip ? 8 - tp : tp)) * CL + c];
+    *reinterpret_cast<T*>(ldsW + c * PW + k * SZ) = from_float<T>(v);
+  }
+  __syncthreads();
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[j][n][q] = 0.f;
+  int prow[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) prow[j] = (4 * wave + 2 * j + l31 / TS) * HS + (l31 % TS);      // halo index of (ty, tx) minus (1, 1)
+  if constexpr (IS_BF16) {
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      const int tp = 2 * ks + half;                    // this lane's tap of the k-step (tap 9: weights are zero)
+      const int tpc = tp < 9 ? tp : 8;
+      const int doff = ((tpc / 3) * HS + (tpc % 3)) * PD;
+      short8 fb[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) fb[n] = *reinterpret_cast<const short8*>(ldsW + (n * 32 + l31) * PW + tp * 16);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const short8 fa = *reinterpret_cast<const short8*>(ldsD + prow[j] * PD + doff);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[j][n] = SmallFrag<bf16_t>::mfma(fa, fb[n], acc[j][n]);
+      }
+    }
+  } else {
+#pragma unroll 4
+    for (int ks = 0; ks < 36; ++ks) {                  // k = ks*2 + half -> (tap, slot)
+      const int k = ks * 2 + half;
+      const int tp = k / 8, slot = k % 8;
+      const int doff = ((tp / 3) * HS + (tp % 3)) * PD + slot * 4;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float fa = *reinterpret_cast<const float*>(ldsD + prow[j] * PD + doff);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const float fb = *reinterpret_cast<const float*>(ldsW + (n * 32 + l31) * PW + k * 4);
+          acc[j][n] = SmallFrag<float>::mfma(fa, fb, acc[j][n]);
+        }
+      }
+    }
+  }
+  // transpose through LDS and write whole NHWC rows
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int m = (q & 3) + 8 * (q >> 2) + 4 * half;
+        const int px = (4 * wave + 2 * j) * TS + m;
+        *reinterpret_cast<T*>(ldsOut + px * OP + (n * 32 + l31) * SZ) = from_float<T>(acc[j][n][q]);
+      }
+  __syncthreads();
+  constexpr int N = Vec16<T>::N;
+  constexpr int PPR = CL / N;
+  T* outb = reinterpret_cast<T*>(a.out) + (size_t)b * a.H * a.W * CL;
+  for (int i = tid; i < 256 * PPR; i += 256) {
+    const int px = i / PPR, part = i % PPR;
+    const int yy = y0 + px / TS, xx = x0 + px % TS;
+    if (yy < a.H && xx < a.W)
+      *reinterpret_cast<uint4*>(outb + ((size_t)yy * a.W + xx) * CL + part * N) = *reinterpret_cast<const uint4*>(ldsOut + px * OP + part * 16);
+  }
+}
+
+template <typename T, int CL> constexpr size_t l2s_mfma_smem() {
+  constexpr int SZ = (int)sizeof(T);
+  return (size_t)HS * (HS * (CL * SZ + 16) + (SZ == 2 ? 96 : 0)) + (size_t)(SZ == 2 ? 2 : 1) * 8 * (9 * CL * SZ + 16) + 8 * 256 * sizeof(float);
+}
+template <typename T, int CL> constexpr size_t s2l_dgrad_mfma_smem() {
+  constexpr int SZ = (int)sizeof(T);
+  constexpr size_t d = (((size_t)(HS * HS + 2) * (8 * SZ + (SZ == 2 ? 0 : 4))) + 15) & ~(size_t)15;
+  return d + (size_t)CL * ((SZ == 2 ? 10 : 9) * 8 * SZ + (SZ == 2 ? 16 : 4)) + (size_t)256 * (CL * SZ + 16);
+}
+
 struct SWArgs {
   const float* S;       // [B][CS][H][W] fp32
   const void* L;        // [B][H][W][CL] T
@@ -402,6 +650,18 @@ extern "C" int im2im_smallconv_s2l_fwd(const float* in, const float* w, const fl
   return for_dtype_cl(dtype, CL, [&](auto* tag, auto cl) {
     using T = std::remove_pointer_t<decltype(tag)>;
     const dim3 grid((unsigned)(B * a.tilesY * a.tilesX));
+    if (CS > 1 && !bias && !center && !scale_shift && !stats && !relu) {
+      // the heads' data-gradient (plain correlation into a wide NHWC tensor): matrix-core form
+      constexpr int CLv = decltype(cl)::value;
+      constexpr size_t smem = s2l_dgrad_mfma_smem<T, CLv>();
+      auto kern = smallconv_s2l_dgrad_mfma_kernel<T, CLv>;
+      if (smem > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
+      }
+      hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, a);
+      return check_launch("smallconv_s2l_dgrad_mfma_kernel");
+    }
     if (CS == 1) hipLaunchKernelGGL((smallconv_s2l_kernel<T, decltype(cl)::value, true>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((smallconv_s2l_kernel<T, decltype(cl)::value, false>), grid, dim3(256), 0, stream, a);
     return check_launch("smallconv_s2l_kernel");
@@ -415,8 +675,15 @@ extern "C" int im2im_smallconv_l2s_fwd(const void* in, const float* w, const flo
   L2SArgs a{in, w, bias, out, B, H, W, CS, (int)cdiv(H, TS), (int)cdiv(W, TS)};
   return for_dtype_cl(dtype, CL, [&](auto* tag, auto cl) {
     using T = std::remove_pointer_t<decltype(tag)>;
-    hipLaunchKernelGGL((smallconv_l2s_kernel<T, decltype(cl)::value>), dim3((unsigned)(B * a.tilesY * a.tilesX)), dim3(256), 0, stream, a);
-    return check_launch("smallconv_l2s_kernel");
+    constexpr int CLv = decltype(cl)::value;
+    constexpr size_t smem = l2s_mfma_smem<T, CLv>();
+    auto kern = smallconv_l2s_mfma_kernel<T, CLv>;
+    if (smem > 64 * 1024) {
+      static bool attr_set = false;
+      if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(B * a.tilesY * a.tilesX)), dim3(256), smem, stream, a);
+    return check_launch("smallconv_l2s_mfma_kernel");
   });
 }
 
