@@ -189,6 +189,177 @@ __global__ __launch_bounds__(256) void smallconv_s2l_kernel(S2LArgs a) {
   }
 }
 
+// The same layer with the multiply-accumulates on the matrix cores (exact-fp32 v_mfma_f32_32x32x2_f32: the first conv keeps
+// fp32 inputs and weights in every compute mode): K = 9*CS (tap-major), one 128-pixel half of the tile at a time through an
+// fp32 LDS tile, then the per-(pixel, 8-channel group) epilogue of smallconv_s2l_kernel unchanged (bias, affine, ReLU, store,
+// BatchNorm partial statistics).
+template <typename T, int CL>
+__global__ __launch_bounds__(256) void smallconv_s2l_mfma_kernel(S2LArgs a) {
+  constexpr bool W_REGS = false;
+  constexpr int G = CL / 8;                 // channel groups (lanes per pixel)
+  constexpr int PPP = 256 / G;              // pixels per pass
+  constexpr int PASSES = TS * TS / PPP;
+  __shared__ float s_in[CS_MAX][HS][HS + 1];
+  __shared__ __attribute__((aligned(16))) float s_w[W_REGS ? 1 : CS_MAX * 9 * CL];
+  __shared__ float s_stat[4][3][CL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int t = blockIdx.x;
+  const int tx_id = t % a.tilesX; t /= a.tilesX;
+  const int ty_id = t % a.tilesY;
+  const int b = t / a.tilesY;
+  const int y0 = ty_id * TS, x0 = tx_id * TS;
+  const float* inb = a.in + (size_t)b * a.CS * a.H * a.W;
+  for (int i = tid; i < a.CS * HS * HS; i += 256) {
+    const int s = i / (HS * HS), r = i % (HS * HS);
+    const int hy = r / HS, hx = r % HS;
+    const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+    s_in[s][hy][hx] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? inb[((size_t)s * a.H + yy) * a.W + xx] : 0.f;
+  }
+  const int g = tid % G, c0 = g * 8;
+  float wreg[W_REGS ? 9 : 1][8];
+  if constexpr (W_REGS) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) wreg[tap][k] = a.w[(size_t)(a.flip ? 8 - tap : tap) * CL + c0 + k];
+  } else {
+    for (int i = tid; i < a.CS * 9 * CL; i += 256) {
+      const int s = i / (9 * CL), r = i % (9 * CL);
+      const int tap = r / CL, l = r % CL;
+      s_w[i] = a.w[((size_t)s * 9 + (a.flip ? 8 - tap : tap)) * CL + l];
+    }
+  }
+  float b0[8], sc[8], sh[8], s1[8], s2[8], K[8];
+  float cnt = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    b0[k] = (a.bias ? a.bias[c0 + k] : 0.f) - (a.center ? a.center[c0 + k] : 0.f);
+    sc[k] = a.scale_shift ? a.scale_shift[c0 + k] : 1.f;
+    sh[k] = a.scale_shift ? a.scale_shift[CL + c0 + k] : 0.f;
+    s1[k] = 0.f; s2[k] = 0.f; K[k] = 0.f;
+  }
+  __syncthreads();
+  T* outb = reinterpret_cast<T*>(a.out) + (size_t)b * a.H * a.W * CL + c0;
+  // all of this thread's pixels advance together through (input channel, tap), so a weight vector fetched from LDS
+  // (or held in registers) serves PASSES pixels; per output the summation order stays bias, then (s, tap) ascending
+  const int q = tid / G;
+  const int qy = q / TS, qx = q % TS;                    // pixel of pass p: (qy + p * PPP / TS, qx)
+  // ---- matrix-core accumulate, half a tile (8 tile rows = 4 MFMA row tiles) at a time
+  constexpr int NT = CL / 32;
+  constexpr int OPITCH = CL + 1;
+  __shared__ float s_o[128 * OPITCH];
+  const int wv = tid >> 6, hf = (tid & 63) >> 5, l31 = tid & 31;
+  const int ksteps = (9 * a.CS + 1) / 2;
+  float accv[PASSES][8];
+#pragma unroll
+  for (int hblk = 0; hblk < 2; ++hblk) {
+    f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    const int prow = hblk * 8 + wv * 2 + l31 / TS, pcol = l31 % TS;       // this lane's output pixel of the row tile
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const int k = 2 * ks + hf;
+      const bool on = k < 9 * a.CS;
+      const int tap = on ? k / a.CS : 0, sidx = on ? k % a.CS : 0;
+      const float fa = on ? s_in[sidx][prow + tap / 3][pcol + tap % 3] : 0.f;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float fb = on ? s_w[(sidx * 9 + tap) * CL + n * 32 + l31] : 0.f;
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[n], 0, 0, 0);
+      }
+    }
+    __syncthreads();                                  // the previous half's readers are done with s_o
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * hf;
+        s_o[(wv * 32 + m) * OPITCH + n * 32 + l31] = acc[n][r];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PASSES / 2; ++p) {
+      const int pl = (qy + p * (PPP / TS)) * TS + qx;                      // pixel within the half (qy < PPP/TS rows)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) accv[hblk * (PASSES / 2) + p][k] = b0[k] + s_o[pl * OPITCH + c0 + k];
+    }
+  }
+#pragma unroll
+  for (int pass = 0; pass < PASSES; ++pass) {
+    const int ty = qy + pass * (PPP / TS), tx = qx;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = accv[pass][k];
+    if (a.scale_shift) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = acc[k] * sc[k] + sh[k];
+    }
+    if (a.relu) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = fmaxf(acc[k], 0.f);
+    }
+    // round to the storage type first so the statistics describe what BatchNorm will normalise
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = to_float(from_float<T>(acc[k]));
+    const int yy = y0 + ty, xx = x0 + tx;
+    if (yy < a.H && xx < a.W) {
+      T* o = outb + ((size_t)yy * a.W + xx) * CL;
+      constexpr int N = Vec16<T>::N;
+#pragma unroll
+      for (int k = 0; k < 8; k += N) Vec16<T>::store(o + k, acc + k);
+      // statistics relative to this thread's first valid value (no cancellation when forming M2 below)
+      if (cnt == 0.f) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) K[k] = acc[k];
+      }
+      cnt += 1.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float d = acc[k] - K[k]; s1[k] += d; s2[k] += d * d; }
+    }
+  }
+  if (a.stats) {
+    // thread -> (count, mean, M2); merged over the lanes that share the channel group, then over the four waves
+    const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+    float mean[8], m2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { mean[k] = K[k] + s1[k] * inv; m2[k] = fmaxf(s2[k] - s1[k] * s1[k] * inv, 0.f); }
+#pragma unroll
+    for (int off = G; off < 64; off <<= 1) {
+      const float n2 = __shfl_xor(cnt, off, 64);
+      const float nn = cnt + n2;
+      const float ninv = nn > 0.f ? 1.f / nn : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float mo = __shfl_xor(mean[k], off, 64), qo = __shfl_xor(m2[k], off, 64);
+        const float d = mo - mean[k];
+        m2[k] = m2[k] + qo + d * d * (cnt * n2 * ninv);
+        mean[k] = (cnt * mean[k] + n2 * mo) * ninv;
+      }
+      cnt = nn;
+    }
+    if (lane < G) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { s_stat[wave][0][c0 + k] = mean[k]; s_stat[wave][1][c0 + k] = m2[k]; s_stat[wave][2][c0 + k] = cnt; }
+    }
+    __syncthreads();
+    if (tid < CL) {
+      float n = s_stat[0][2][tid], m = s_stat[0][0][tid], q = s_stat[0][1][tid];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float n2 = s_stat[w][2][tid], mo = s_stat[w][0][tid], qo = s_stat[w][1][tid];
+        const float nn = n + n2, ninv = nn > 0.f ? 1.f / nn : 0.f, d = mo - m;
+        q = q + qo + d * d * (n * n2 * ninv);
+        m = (n * m + n2 * mo) * ninv;
+        n = nn;
+      }
+      float* st = a.stats + (size_t)blockIdx.x * 3 * CL;
+      st[tid] = m; st[CL + tid] = q; st[2 * CL + tid] = n;
+    }
+  }
+}
+
 struct L2SArgs {
   const void* in;       // [B][H][W][CL] T
   const float* w;       // [CS][9][CL]
@@ -260,6 +431,16 @@ __global__ __launch_bounds__(256) void smallconv_l2s_kernel(L2SArgs a) {
 //   s2l with flip (heads data-gradient):  dF[px][c] = sum_{tap,s} g[s][px-tap] * w[s][tap][c]
 //       K = (tap, s) with 8 s-slots per tap, so a lane's 8 k-values of one MFMA k-step are the 8 planes of ONE halo pixel:
 //       one ds_read_b128 of the [halo px][8] gradient tile.
+struct WgFrag {      // K-contiguous bf16 fragment out of a pixel-major LDS tile: hardware 4x16 transpose read (see conv_mfma.hip)
+  static __device__ __forceinline__ short8 load(const char* p0, const char* p1) {
+    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(lds_char*)p0);
+    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(lds_char*)p1);
+    short8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
+};
 template <typename T> struct SmallFrag;
 template <> struct SmallFrag<bf16_t> {
   using AB = short8;
@@ -294,25 +475,7 @@ __global__ __launch_bounds__(256) void smallconv_l2s_mfma_kernel(L2SArgs a) {
   float* ldsO = reinterpret_cast<float*>(smem + F_BYTES + W_BYTES);     // [8][256]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  int t = blockIdx.x;
-  const int tx_id = t % a.tilesX; t /= a.tilesX;
-  const int ty_id = t % a.tilesY;
-  const int b = t / a.tilesY;
-  const int y0 = ty_id * TS, x0 = tx_id * TS;
-  const T* inb = reinterpret_cast<const T*>(a.in) + (size_t)b * a.H * a.W * CL;
-  // halo tile: all loads in flight, then the LDS writes
-  constexpr int PPR = CL / N;
-  constexpr int ROUNDS = (HS * HS * PPR + 255) / 256;
-  uint4 r[ROUNDS];
-#pragma unroll
-  for (int i = 0; i < ROUNDS; ++i) {
-    const int p = i * 256 + tid;
-    const int px = p / PPR, part = p % PPR;
-    const int yy = y0 + px / HS - 1, xx = x0 + px % HS - 1;
-    r[i] = make_uint4(0, 0, 0, 0);
-    if (px < HS * HS && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
-      r[i] = *reinterpret_cast<const uint4*>(inb + ((size_t)yy * a.W + xx) * CL + part * N);
-  }
+  // persistent workgroups: the weights are converted ONCE per workgroup, the next tile's halo is in flight during the MFMAs
   // weights: w [CS][9][CL] fp32 -> rows s < 8 (zero beyond CS) of T, bf16 split into hi and lo = bf16(w - hi)
   for (int i = tid; i < 8 * 9 * CL; i += 256) {
     const int srow = i / (9 * CL), k = i % (9 * CL);
@@ -326,56 +489,86 @@ __global__ __launch_bounds__(256) void smallconv_l2s_mfma_kernel(L2SArgs a) {
       *reinterpret_cast<float*>(ldsW + srow * PW + k * 4) = v;
     }
   }
+  constexpr int PPR = CL / N;
+  constexpr int ROUNDS = (HS * HS * PPR + 255) / 256;
+  uint4 r[ROUNDS];
+  const int ntiles = a.B * a.tilesY * a.tilesX;
+  auto gload = [&](int tile) {
+    int t = tile;
+    const int tx_id = t % a.tilesX; t /= a.tilesX;
+    const int ty_id = t % a.tilesY;
+    const int b = t / a.tilesY;
+    const int y0 = ty_id * TS, x0 = tx_id * TS;
+    const T* inb = reinterpret_cast<const T*>(a.in) + (size_t)b * a.H * a.W * CL;
 #pragma unroll
-  for (int i = 0; i < ROUNDS; ++i) {
-    const int p = i * 256 + tid;
-    const int px = p / PPR, part = p % PPR;
-    if (px < HS * HS) *reinterpret_cast<uint4*>(ldsF + (px / HS) * HROWB + (px % HS) * PF + part * 16) = r[i];
-  }
-  __syncthreads();
-  // wave w: output tile rows 4w .. 4w+3 as two 32-pixel MFMA row tiles
-  f32x16 acc[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+    for (int i = 0; i < ROUNDS; ++i) {
+      const int p = i * 256 + tid;
+      const int px = p / PPR, part = p % PPR;
+      const int yy = y0 + px / HS - 1, xx = x0 + px % HS - 1;
+      r[i] = make_uint4(0, 0, 0, 0);
+      if (px < HS * HS && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
+        r[i] = *reinterpret_cast<const uint4*>(inb + ((size_t)yy * a.W + xx) * CL + part * N);
+    }
+  };
   int aoff[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) aoff[j] = (4 * wave + 2 * j + l31 / TS) * HROWB + (l31 % TS) * PF;
   const int boff = (l31 & 7) * PW;
+  if ((int)blockIdx.x < ntiles) gload(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int t = tile;
+    const int tx_id = t % a.tilesX; t /= a.tilesX;
+    const int ty_id = t % a.tilesY;
+    const int b = t / a.tilesY;
+    const int y0 = ty_id * TS, x0 = tx_id * TS;
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    const int toff = (tap / 3) * HROWB + (tap % 3) * PF;
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      const int koff = IS_BF16 ? ks * 32 + half * 16 : (ks * 2 + half) * 4;
-      const auto fb = SmallFrag<T>::load(ldsW + boff + tap * CL * SZ + koff);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const auto fa = SmallFrag<T>::load(ldsF + aoff[j] + toff + koff);
-        acc[j] = SmallFrag<T>::mfma(fa, fb, acc[j]);
-        if constexpr (IS_BF16) {
-          const auto fl = SmallFrag<T>::load(ldsW + 8 * PW + boff + tap * CL * SZ + koff);
-          acc[j] = SmallFrag<T>::mfma(fa, fl, acc[j]);
-        }
-      }
+    for (int i = 0; i < ROUNDS; ++i) {
+      const int p = i * 256 + tid;
+      const int px = p / PPR, part = p % PPR;
+      if (px < HS * HS) *reinterpret_cast<uint4*>(ldsF + (px / HS) * HROWB + (px % HS) * PF + part * 16) = r[i];
     }
-  }
-  if (l31 < a.CS) {
-    const float bv = a.bias ? a.bias[l31] : 0.f;
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) gload(tile + gridDim.x);
+    // wave w: output tile rows 4w .. 4w+3 as two 32-pixel MFMA row tiles
+    f32x16 acc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int m = (q & 3) + 8 * (q >> 2) + 4 * half;              // pixel within the 32-pixel row tile
-        ldsO[l31 * 256 + (4 * wave + 2 * j) * TS + m] = acc[j][q] + bv;
+      for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int toff = (tap / 3) * HROWB + (tap % 3) * PF;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int koff = IS_BF16 ? ks * 32 + half * 16 : (ks * 2 + half) * 4;
+        const auto fb = SmallFrag<T>::load(ldsW + boff + tap * CL * SZ + koff);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const auto fa = SmallFrag<T>::load(ldsF + aoff[j] + toff + koff);
+          acc[j] = SmallFrag<T>::mfma(fa, fb, acc[j]);
+          if constexpr (IS_BF16) {
+            const auto fl = SmallFrag<T>::load(ldsW + 8 * PW + boff + tap * CL * SZ + koff);
+            acc[j] = SmallFrag<T>::mfma(fa, fl, acc[j]);
+          }
+        }
       }
-  }
-  __syncthreads();
-  for (int i = tid; i < a.CS * 256; i += 256) {
-    const int sidx = i >> 8, px = i & 255;
-    const int yy = y0 + px / TS, xx = x0 + px % TS;
-    if (yy < a.H && xx < a.W) a.out[(((size_t)b * a.CS + sidx) * a.H + yy) * a.W + xx] = ldsO[i];
+    }
+    if (l31 < a.CS) {
+      const float bv = a.bias ? a.bias[l31] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int m = (q & 3) + 8 * (q >> 2) + 4 * half;              // pixel within the 32-pixel row tile
+          ldsO[l31 * 256 + (4 * wave + 2 * j) * TS + m] = acc[j][q] + bv;
+        }
+    }
+    __syncthreads();                                    // results staged; every wave is done reading the halo tile
+    for (int i = tid; i < a.CS * 256; i += 256) {
+      const int sidx = i >> 8, px = i & 255;
+      const int yy = y0 + px / TS, xx = x0 + px % TS;
+      if (yy < a.H && xx < a.W) a.out[(((size_t)b * a.CS + sidx) * a.H + yy) * a.W + xx] = ldsO[i];
+    }
   }
 }
 
@@ -397,21 +590,7 @@ __global__ __launch_bounds__(256) void smallconv_s2l_dgrad_mfma_kernel(S2LArgs a
   char* ldsOut = ldsW + W_BYTES;                      // [256][OP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  int t = blockIdx.x;
-  const int tx_id = t % a.tilesX; t /= a.tilesX;
-  const int ty_id = t % a.tilesY;
-  const int b = t / a.tilesY;
-  const int y0 = ty_id * TS, x0 = tx_id * TS;
-  const float* gb = a.in + (size_t)b * a.CS * a.H * a.W;
-  // gradient halo tile [px][8 slots] (slots >= CS zero)
-  for (int i = tid; i < HS * HS * 8; i += 256) {
-    const int slot = i / (HS * HS), px = i % (HS * HS);             // consecutive threads -> consecutive x of one plane
-    const int yy = y0 + px / HS - 1, xx = x0 + px % HS - 1;
-    float v = 0.f;
-    if (slot < a.CS && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) v = gb[((size_t)slot * a.H + yy) * a.W + xx];
-    *reinterpret_cast<T*>(ldsD + px * PD + slot * SZ) = from_float<T>(v);
-  }
-  // weights: row c, k = (tap', slot): w[slot][8 - tap'][c]  (the correlation runs over the flipped taps)
+  // persistent workgroups: weights converted once.  row c, k = (tap', slot): w[slot][8 - tap'][c] (correlation over the flipped taps)
   for (int i = tid; i < CL * TAPS_P * 8; i += 256) {
     const int c = i / (TAPS_P * 8), k = i % (TAPS_P * 8);
     const int tp = k / 8, slot = k % 8;
@@ -419,76 +598,114 @@ __global__ __launch_bounds__(256) void smallconv_s2l_dgrad_mfma_kernel(S2LArgs a
     if (tp < 9 && slot < a.CS) v = a.w[((size_t)slot * 9 + (a.flip ? 8 - tp : tp)) * CL + c];
     *reinterpret_cast<T*>(ldsW + c * PW + k * SZ) = from_float<T>(v);
   }
-  __syncthreads();
-  f32x16 acc[2][NT];
+  constexpr int G_ROUNDS = (HS * HS * 8 + 255) / 256;  // gradient halo elements per thread
+  float gv[G_ROUNDS];
+  const int ntiles = a.B * a.tilesY * a.tilesX;
+  auto gload = [&](int tile) {
+    int t = tile;
+    const int tx_id = t % a.tilesX; t /= a.tilesX;
+    const int ty_id = t % a.tilesY;
+    const int b = t / a.tilesY;
+    const int y0 = ty_id * TS, x0 = tx_id * TS;
+    const float* gb = a.in + (size_t)b * a.CS * a.H * a.W;
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[j][n][q] = 0.f;
+    for (int i = 0; i < G_ROUNDS; ++i) {
+      const int e = i * 256 + tid;
+      const int slot = e / (HS * HS), px = e % (HS * HS);           // consecutive threads -> consecutive x of one plane
+      const int yy = y0 + px / HS - 1, xx = x0 + px % HS - 1;
+      gv[i] = 0.f;
+      if (slot < a.CS && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) gv[i] = gb[((size_t)slot * a.H + yy) * a.W + xx];
+    }
+  };
   int prow[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) prow[j] = (4 * wave + 2 * j + l31 / TS) * HS + (l31 % TS);      // halo index of (ty, tx) minus (1, 1)
-  if constexpr (IS_BF16) {
+  if ((int)blockIdx.x < ntiles) gload(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int t = tile;
+    const int tx_id = t % a.tilesX; t /= a.tilesX;
+    const int ty_id = t % a.tilesY;
+    const int b = t / a.tilesY;
+    const int y0 = ty_id * TS, x0 = tx_id * TS;
 #pragma unroll
-    for (int ks = 0; ks < 5; ++ks) {
-      const int tp = 2 * ks + half;                    // this lane's tap of the k-step (tap 9: weights are zero)
-      const int tpc = tp < 9 ? tp : 8;
-      const int doff = ((tpc / 3) * HS + (tpc % 3)) * PD;
-      short8 fb[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) fb[n] = *reinterpret_cast<const short8*>(ldsW + (n * 32 + l31) * PW + tp * 16);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const short8 fa = *reinterpret_cast<const short8*>(ldsD + prow[j] * PD + doff);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[j][n] = SmallFrag<bf16_t>::mfma(fa, fb[n], acc[j][n]);
-      }
+    for (int i = 0; i < G_ROUNDS; ++i) {
+      const int e = i * 256 + tid;
+      const int slot = e / (HS * HS), px = e % (HS * HS);
+      if (slot < 8) *reinterpret_cast<T*>(ldsD + px * PD + slot * SZ) = from_float<T>(gv[i]);
     }
-  } else {
+    __syncthreads();                                    // (also: the previous tile's output staging has been drained)
+    if (tile + (int)gridDim.x < ntiles) gload(tile + gridDim.x);
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[j][n][q] = 0.f;
+    if constexpr (IS_BF16) {
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) {
+        const int tp = 2 * ks + half;                    // this lane's tap of the k-step (tap 9: weights are zero)
+        const int tpc = tp < 9 ? tp : 8;
+        const int doff = ((tpc / 3) * HS + (tpc % 3)) * PD;
+        short8 fb[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) fb[n] = *reinterpret_cast<const short8*>(ldsW + (n * 32 + l31) * PW + tp * 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const short8 fa = *reinterpret_cast<const short8*>(ldsD + prow[j] * PD + doff);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[j][n] = SmallFrag<bf16_t>::mfma(fa, fb[n], acc[j][n]);
+        }
+      }
+    } else {
 #pragma unroll 4
-    for (int ks = 0; ks < 36; ++ks) {                  // k = ks*2 + half -> (tap, slot)
-      const int k = ks * 2 + half;
-      const int tp = k / 8, slot = k % 8;
-      const int doff = ((tp / 3) * HS + (tp % 3)) * PD + slot * 4;
+      for (int ks = 0; ks < 36; ++ks) {                  // k = ks*2 + half -> (tap, slot)
+        const int k = ks * 2 + half;
+        const int tp = k / 8, slot = k % 8;
+        const int doff = ((tp / 3) * HS + (tp % 3)) * PD + slot * 4;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float fa = *reinterpret_cast<const float*>(ldsD + prow[j] * PD + doff);
+        for (int j = 0; j < 2; ++j) {
+          const float fa = *reinterpret_cast<const float*>(ldsD + prow[j] * PD + doff);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const float fb = *reinterpret_cast<const float*>(ldsW + (n * 32 + l31) * PW + k * 4);
-          acc[j][n] = SmallFrag<float>::mfma(fa, fb, acc[j][n]);
+          for (int n = 0; n < NT; ++n) {
+            const float fb = *reinterpret_cast<const float*>(ldsW + (n * 32 + l31) * PW + k * 4);
+            acc[j][n] = SmallFrag<float>::mfma(fa, fb, acc[j][n]);
+          }
         }
       }
     }
-  }
-  // transpose through LDS and write whole NHWC rows
+    // transpose through LDS and write whole NHWC rows
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+      for (int n = 0; n < NT; ++n)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int m = (q & 3) + 8 * (q >> 2) + 4 * half;
-        const int px = (4 * wave + 2 * j) * TS + m;
-        *reinterpret_cast<T*>(ldsOut + px * OP + (n * 32 + l31) * SZ) = from_float<T>(acc[j][n][q]);
-      }
-  __syncthreads();
-  constexpr int N = Vec16<T>::N;
-  constexpr int PPR = CL / N;
-  T* outb = reinterpret_cast<T*>(a.out) + (size_t)b * a.H * a.W * CL;
-  for (int i = tid; i < 256 * PPR; i += 256) {
-    const int px = i / PPR, part = i % PPR;
-    const int yy = y0 + px / TS, xx = x0 + px % TS;
-    if (yy < a.H && xx < a.W)
-      *reinterpret_cast<uint4*>(outb + ((size_t)yy * a.W + xx) * CL + part * N) = *reinterpret_cast<const uint4*>(ldsOut + px * OP + part * 16);
+        for (int q = 0; q < 16; ++q) {
+          const int m = (q & 3) + 8 * (q >> 2) + 4 * half;
+          const int px = (4 * wave + 2 * j) * TS + m;
+          *reinterpret_cast<T*>(ldsOut + px * OP + (n * 32 + l31) * SZ) = from_float<T>(acc[j][n][q]);
+        }
+    __syncthreads();                                    // staged; every wave is done reading the gradient tile
+    constexpr int N = Vec16<T>::N;
+    constexpr int PPR = CL / N;
+    T* outb = reinterpret_cast<T*>(a.out) + (size_t)b * a.H * a.W * CL;
+    for (int i = tid; i < 256 * PPR; i += 256) {
+      const int px = i / PPR, part = i % PPR;
+      const int yy = y0 + px / TS, xx = x0 + px % TS;
+      if (yy < a.H && xx < a.W)
+        *reinterpret_cast<uint4*>(outb + ((size_t)yy * a.W + xx) * CL + part * N) = *reinterpret_cast<const uint4*>(ldsOut + px * OP + part * 16);
+    }
   }
 }
 
 template <typename T, int CL> constexpr size_t l2s_mfma_smem() {
   constexpr int SZ = (int)sizeof(T);
   return (size_t)HS * (HS * (CL * SZ + 16) + (SZ == 2 ? 96 : 0)) + (size_t)(SZ == 2 ? 2 : 1) * 8 * (9 * CL * SZ + 16) + 8 * 256 * sizeof(float);
+}
+template <typename T, int CL> constexpr size_t wgrad_mfma_smem() {
+  constexpr int SZ = (int)sizeof(T);
+  return (size_t)TS * TS * (CL * SZ + (SZ == 2 ? 16 : 4)) + (size_t)(SZ == 2 ? 2 : 1) * ((size_t)HS * HS * (SZ == 2 ? 16 : 36) + 128);
 }
 template <typename T, int CL> constexpr size_t s2l_dgrad_mfma_smem() {
   constexpr int SZ = (int)sizeof(T);
@@ -609,6 +826,171 @@ __global__ __launch_bounds__(256) void smallconv_wgrad_kernel(SWArgs a) {
   }
 }
 
+// MFMA form of the weight gradients above:  out[s][tap][l] = sum_px L[px][l] * S[s][px + off(tap)]  (+ sum_px S[s][px]).
+// Per tap a GEMM with M = the wide side's channels l, N = the 8 plane slots of the small side, K = pixels.  Both operands
+// live pixel-major in LDS ([px][channels]) but the matrix cores want k (= pixel) contiguous per lane: bf16 fragments are
+// fetched with ds_read_b64_tr_b16 (as conv_wgrad_kernel in conv_mfma.hip), fp32 ones are single scalars.  The small side
+// enters as hi + lo bf16 pairs (it is fp32 data: network input / loss gradient).  Persistent workgroups; wave w owns the
+// taps {w, w+4, w+8}; partial rows in the layout of smallconv_wgrad_kernel, so the same reduction finishes them.
+template <typename T, int CL>
+__global__ __launch_bounds__(256) void smallconv_wgrad_mfma_kernel(SWArgs a) {
+  constexpr int SZ = (int)sizeof(T);
+  constexpr bool IS_BF16 = SZ == 2;
+  constexpr int N = Vec16<T>::N;
+  constexpr int PL = CL * SZ + (IS_BF16 ? 16 : 4);    // L tile pixel pitch
+  constexpr int L_BYTES = TS * TS * PL;
+  constexpr int PD = IS_BF16 ? 16 : 36;               // S tile: [halo px][8 slots]
+  constexpr int D_BYTES = (HS * HS) * PD + 128;       // + slack: transposed reads of slots 8..31 run into the following pixels
+  constexpr int NPARTS = IS_BF16 ? 2 : 1;
+  constexpr int MT = CL / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsL = smem;
+  char* ldsD = smem + L_BYTES;                        // NPARTS tiles
+  float* ldsR = reinterpret_cast<float*>(smem);       // final reduction scratch (after the loop)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int q = lane & 15;
+  const int tr_col_b = (((lane >> 4) & 1) * 16 + (q & 3) * 4) * 2;
+  const int tr_row = q >> 2;
+  f32x16 acc[3][MT];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.f;
+  constexpr int PPR = CL / N;
+  constexpr int L_ROUNDS = (TS * TS * PPR + 255) / 256;
+  constexpr int S_ROUNDS = (HS * HS * 8 + 255) / 256;
+  uint4 rl[L_ROUNDS];
+  float rs[S_ROUNDS], bs[S_ROUNDS];                    // bs: running sums of this thread's small-side elements (bias gradient)
+#pragma unroll
+  for (int i = 0; i < S_ROUNDS; ++i) bs[i] = 0.f;
+  const int ntiles = a.B * a.tilesY * a.tilesX;
+  auto gload = [&](int tile) {
+    int t = tile;
+    const int tx_id = t % a.tilesX; t /= a.tilesX;
+    const int ty_id = t % a.tilesY;
+    const int b = t / a.tilesY;
+    const int y0 = ty_id * TS, x0 = tx_id * TS;
+    const float* Sb = a.S + (size_t)b * a.CS * a.H * a.W;
+    const T* Lb = reinterpret_cast<const T*>(a.L) + (size_t)b * a.H * a.W * CL;
+#pragma unroll
+    for (int i = 0; i < L_ROUNDS; ++i) {
+      const int p = i * 256 + tid;
+      const int px = p / PPR, part = p % PPR;
+      const int yy = y0 + px / TS, xx = x0 + px % TS;
+      rl[i] = make_uint4(0, 0, 0, 0);
+      if (px < TS * TS && yy < a.H && xx < a.W) rl[i] = *reinterpret_cast<const uint4*>(Lb + ((size_t)yy * a.W + xx) * CL + part * N);
+    }
+#pragma unroll
+    for (int i = 0; i < S_ROUNDS; ++i) {
+      const int e = i * 256 + tid;
+      const int slot = e / (HS * HS), px = e % (HS * HS);
+      const int yy = y0 + px / HS - 1, xx = x0 + px % HS - 1;
+      rs[i] = 0.f;
+      if (slot < a.CS && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) rs[i] = Sb[((size_t)slot * a.H + yy) * a.W + xx];
+    }
+  };
+  if ((int)blockIdx.x < ntiles) gload(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();                                   // the previous tile's readers are done
+#pragma unroll
+    for (int i = 0; i < L_ROUNDS; ++i) {
+      const int p = i * 256 + tid;
+      const int px = p / PPR, part = p % PPR;
+      if (px < TS * TS) *reinterpret_cast<uint4*>(ldsL + px * PL + part * 16) = rl[i];
+    }
+#pragma unroll
+    for (int i = 0; i < S_ROUNDS; ++i) {
+      const int e = i * 256 + tid;
+      const int slot = e / (HS * HS), px = e % (HS * HS);
+      if (slot < 8) {
+        if constexpr (IS_BF16) {
+          const bf16_t hi = (bf16_t)rs[i];
+          *reinterpret_cast<bf16_t*>(ldsD + px * PD + slot * 2) = hi;
+          *reinterpret_cast<bf16_t*>(ldsD + D_BYTES + px * PD + slot * 2) = (bf16_t)(rs[i] - (float)hi);
+        } else {
+          *reinterpret_cast<float*>(ldsD + px * PD + slot * 4) = rs[i];
+        }
+        const int hy = px / HS, hx = px % HS;
+        if (hy >= 1 && hy <= TS && hx >= 1 && hx <= TS) bs[i] += rs[i];     // tile interior (zero beyond the image)
+      }
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) gload(tile + gridDim.x);
+    // k-step = one tile row of 16 pixels
+#pragma unroll 1
+    for (int ty = 0; ty < TS; ++ty) {
+      if constexpr (IS_BF16) {
+        short8 fa[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const char* p0 = ldsL + (ty * TS + half * 8 + tr_row) * PL + m * 64 + tr_col_b;
+          fa[m] = WgFrag::load(p0, p0 + 4 * PL);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int tp = wave + 4 * i;
+          if (tp < 9) {
+            const char* d0 = ldsD + ((ty + tp / 3) * HS + (tp % 3) + half * 8 + tr_row) * PD + tr_col_b;
+#pragma unroll
+            for (int part = 0; part < NPARTS; ++part) {
+              const short8 fb = WgFrag::load(d0 + part * D_BYTES, d0 + part * D_BYTES + 4 * PD);
+#pragma unroll
+              for (int m = 0; m < MT; ++m) acc[i][m] = SmallFrag<bf16_t>::mfma(fa[m], fb, acc[i][m]);
+            }
+          }
+        }
+      } else {
+#pragma unroll 2
+        for (int kk = 0; kk < 8; ++kk) {                 // two pixels per MFMA: x = 2 kk + half
+          const int tx = 2 * kk + half;
+          float fa[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) fa[m] = *reinterpret_cast<const float*>(ldsL + (ty * TS + tx) * PL + (m * 32 + l31) * 4);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const int tp = wave + 4 * i;
+            if (tp < 9) {
+              const float fb = *reinterpret_cast<const float*>(ldsD + ((ty + tp / 3) * HS + tx + (tp % 3)) * PD + (l31 & 7) * 4);
+#pragma unroll
+              for (int m = 0; m < MT; ++m) acc[i][m] = SmallFrag<float>::mfma(fa[m], fb, acc[i][m]);
+            }
+          }
+        }
+      }
+    }
+  }
+  // partial row of this workgroup: out[(s*9 + tap)*CL + l], then the CS plane sums
+  const int K = a.CS * 9 * CL + a.CS;
+  float* out = a.partial + (size_t)blockIdx.x * K;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int tp = wave + 4 * i;
+    if (tp < 9 && l31 < a.CS) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int l = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          out[((size_t)l31 * 9 + tp) * CL + l] = acc[i][m][r];
+        }
+    }
+  }
+  __syncthreads();
+  // plane sums: element e = i*256 + tid belongs to slot e / (HS*HS); summed per slot in a fixed order
+#pragma unroll
+  for (int i = 0; i < S_ROUNDS; ++i) ldsR[i * 256 + tid] = bs[i];
+  __syncthreads();
+  if (tid < a.CS) {
+    float v = 0.f;
+    for (int e = tid * HS * HS; e < (tid + 1) * HS * HS; ++e) v += ldsR[e];
+    out[(size_t)a.CS * 9 * CL + tid] = v;
+  }
+}
+
 // tmp[S][K] -> dw with index map, dbias tail
 //   l_major != 0: dw[(l*CS + s)*9 + tap]        (first conv: weight [co=l][ci=s][tap])
 //   l_major == 0: dw[(s*CL + l)*9 + (8 - tap)]  (heads: weight [co=s][ci=l][tap], correlation flipped)
@@ -659,12 +1041,12 @@ extern "C" int im2im_smallconv_s2l_fwd(const float* in, const float* w, const fl
         static bool attr_set = false;
         if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
       }
-      hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, a);
+      const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / smem));
+      hipLaunchKernelGGL(kern, dim3(std::min<unsigned>(grid.x, 256u * per_cu)), dim3(256), smem, stream, a);
       return check_launch("smallconv_s2l_dgrad_mfma_kernel");
     }
-    if (CS == 1) hipLaunchKernelGGL((smallconv_s2l_kernel<T, decltype(cl)::value, true>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((smallconv_s2l_kernel<T, decltype(cl)::value, false>), grid, dim3(256), 0, stream, a);
-    return check_launch("smallconv_s2l_kernel");
+    hipLaunchKernelGGL((smallconv_s2l_mfma_kernel<T, decltype(cl)::value>), grid, dim3(256), 0, stream, a);
+    return check_launch("smallconv_s2l_mfma_kernel");
   });
 }
 
@@ -682,7 +1064,9 @@ extern "C" int im2im_smallconv_l2s_fwd(const void* in, const float* w, const flo
       static bool attr_set = false;
       if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(B * a.tilesY * a.tilesX)), dim3(256), smem, stream, a);
+    const int64_t ntiles = (int64_t)B * a.tilesY * a.tilesX;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / smem));
+    hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(ntiles, 256 * per_cu)), dim3(256), smem, stream, a);
     return check_launch("smallconv_l2s_mfma_kernel");
   });
 }
@@ -706,7 +1090,17 @@ extern "C" int im2im_smallconv_wgrad(const float* S, const void* L, float* dw, f
   return for_dtype_cl(dtype, CL, [&](auto* tag, auto cl) {
     using T = std::remove_pointer_t<decltype(tag)>;
     constexpr int CLv = decltype(cl)::value;
-    if (CS == 1) hipLaunchKernelGGL((smallconv_wgrad_kernel<T, CLv, 1>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
+    if (true) {
+      constexpr size_t smem = wgrad_mfma_smem<T, CLv>();
+      static_assert(smem >= (size_t)((HS * HS * 8 + 255) / 256) * 256 * sizeof(float), "bias scratch fits");
+      auto kern = smallconv_wgrad_mfma_kernel<T, CLv>;
+      if (smem > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, stream, a);
+    }
+    else if (CS == 1) hipLaunchKernelGGL((smallconv_wgrad_kernel<T, CLv, 1>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
     else if (CS == 2) hipLaunchKernelGGL((smallconv_wgrad_kernel<T, CLv, 2>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
     else if (CS <= 4) hipLaunchKernelGGL((smallconv_wgrad_kernel<T, CLv, 4>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((smallconv_wgrad_kernel<T, CLv, 8>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
