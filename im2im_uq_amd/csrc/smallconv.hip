@@ -189,177 +189,6 @@ __global__ __launch_bounds__(256) void smallconv_s2l_kernel(S2LArgs a) {
   }
 }
 
-// The same layer with the multiply-accumulates on the matrix cores (exact-fp32 v_mfma_f32_32x32x2_f32: the first conv keeps
-// fp32 inputs and weights in every compute mode): K = 9*CS (tap-major), one 128-pixel half of the tile at a time through an
-// fp32 LDS tile, then the per-(pixel, 8-channel group) epilogue of smallconv_s2l_kernel unchanged (bias, affine, ReLU, store,
-// BatchNorm partial statistics).
-template <typename T, int CL>
-__global__ __launch_bounds__(256) void smallconv_s2l_mfma_kernel(S2LArgs a) {
-  constexpr bool W_REGS = false;
-  constexpr int G = CL / 8;                 // channel groups (lanes per pixel)
-  constexpr int PPP = 256 / G;              // pixels per pass
-  constexpr int PASSES = TS * TS / PPP;
-  __shared__ float s_in[CS_MAX][HS][HS + 1];
-  __shared__ __attribute__((aligned(16))) float s_w[W_REGS ? 1 : CS_MAX * 9 * CL];
-  __shared__ float s_stat[4][3][CL];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int t = blockIdx.x;
-  const int tx_id = t % a.tilesX; t /= a.tilesX;
-  const int ty_id = t % a.tilesY;
-  const int b = t / a.tilesY;
-  const int y0 = ty_id * TS, x0 = tx_id * TS;
-  const float* inb = a.in + (size_t)b * a.CS * a.H * a.W;
-  for (int i = tid; i < a.CS * HS * HS; i += 256) {
-    const int s = i / (HS * HS), r = i % (HS * HS);
-    const int hy = r / HS, hx = r % HS;
-    const int yy = y0 + hy - 1, xx = x0 + hx - 1;
-    s_in[s][hy][hx] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? inb[((size_t)s * a.H + yy) * a.W + xx] : 0.f;
-  }
-  const int g = tid % G, c0 = g * 8;
-  float wreg[W_REGS ? 9 : 1][8];
-  if constexpr (W_REGS) {
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-      for (int k = 0; k < 8; ++k) wreg[tap][k] = a.w[(size_t)(a.flip ? 8 - tap : tap) * CL + c0 + k];
-  } else {
-    for (int i = tid; i < a.CS * 9 * CL; i += 256) {
-      const int s = i / (9 * CL), r = i % (9 * CL);
-      const int tap = r / CL, l = r % CL;
-      s_w[i] = a.w[((size_t)s * 9 + (a.flip ? 8 - tap : tap)) * CL + l];
-    }
-  }
-  float b0[8], sc[8], sh[8], s1[8], s2[8], K[8];
-  float cnt = 0.f;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    b0[k] = (a.bias ? a.bias[c0 + k] : 0.f) - (a.center ? a.center[c0 + k] : 0.f);
-    sc[k] = a.scale_shift ? a.scale_shift[c0 + k] : 1.f;
-    sh[k] = a.scale_shift ? a.scale_shift[CL + c0 + k] : 0.f;
-    s1[k] = 0.f; s2[k] = 0.f; K[k] = 0.f;
-  }
-  __syncthreads();
-  T* outb = reinterpret_cast<T*>(a.out) + (size_t)b * a.H * a.W * CL + c0;
-  // all of this thread's pixels advance together through (input channel, tap), so a weight vector fetched from LDS
-  // (or held in registers) serves PASSES pixels; per output the summation order stays bias, then (s, tap) ascending
-  const int q = tid / G;
-  const int qy = q / TS, qx = q % TS;                    // pixel of pass p: (qy + p * PPP / TS, qx)
-  // ---- matrix-core accumulate, half a tile (8 tile rows = 4 MFMA row tiles) at a time
-  constexpr int NT = CL / 32;
-  constexpr int OPITCH = CL + 1;
-  __shared__ float s_o[128 * OPITCH];
-  const int wv = tid >> 6, hf = (tid & 63) >> 5, l31 = tid & 31;
-  const int ksteps = (9 * a.CS + 1) / 2;
-  float accv[PASSES][8];
-#pragma unroll
-  for (int hblk = 0; hblk < 2; ++hblk) {
-    f32x16 acc[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-    const int prow = hblk * 8 + wv * 2 + l31 / TS, pcol = l31 % TS;       // this lane's output pixel of the row tile
-    for (int ks = 0; ks < ksteps; ++ks) {
-      const int k = 2 * ks + hf;
-      const bool on = k < 9 * a.CS;
-      const int tap = on ? k / a.CS : 0, sidx = on ? k % a.CS : 0;
-      const float fa = on ? s_in[sidx][prow + tap / 3][pcol + tap % 3] : 0.f;
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const float fb = on ? s_w[(sidx * 9 + tap) * CL + n * 32 + l31] : 0.f;
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[n], 0, 0, 0);
-      }
-    }
-    __syncthreads();                                  // the previous half's readers are done with s_o
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * hf;
-        s_o[(wv * 32 + m) * OPITCH + n * 32 + l31] = acc[n][r];
-      }
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < PASSES / 2; ++p) {
-      const int pl = (qy + p * (PPP / TS)) * TS + qx;                      // pixel within the half (qy < PPP/TS rows)
-#pragma unroll
-      for (int k = 0; k < 8; ++k) accv[hblk * (PASSES / 2) + p][k] = b0[k] + s_o[pl * OPITCH + c0 + k];
-    }
-  }
-#pragma unroll
-  for (int pass = 0; pass < PASSES; ++pass) {
-    const int ty = qy + pass * (PPP / TS), tx = qx;
-    float acc[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = accv[pass][k];
-    if (a.scale_shift) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) acc[k] = acc[k] * sc[k] + sh[k];
-    }
-    if (a.relu) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) acc[k] = fmaxf(acc[k], 0.f);
-    }
-    // round to the storage type first so the statistics describe what BatchNorm will normalise
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = to_float(from_float<T>(acc[k]));
-    const int yy = y0 + ty, xx = x0 + tx;
-    if (yy < a.H && xx < a.W) {
-      T* o = outb + ((size_t)yy * a.W + xx) * CL;
-      constexpr int N = Vec16<T>::N;
-#pragma unroll
-      for (int k = 0; k < 8; k += N) Vec16<T>::store(o + k, acc + k);
-      // statistics relative to this thread's first valid value (no cancellation when forming M2 below)
-      if (cnt == 0.f) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) K[k] = acc[k];
-      }
-      cnt += 1.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { const float d = acc[k] - K[k]; s1[k] += d; s2[k] += d * d; }
-    }
-  }
-  if (a.stats) {
-    // thread -> (count, mean, M2); merged over the lanes that share the channel group, then over the four waves
-    const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
-    float mean[8], m2[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { mean[k] = K[k] + s1[k] * inv; m2[k] = fmaxf(s2[k] - s1[k] * s1[k] * inv, 0.f); }
-#pragma unroll
-    for (int off = G; off < 64; off <<= 1) {
-      const float n2 = __shfl_xor(cnt, off, 64);
-      const float nn = cnt + n2;
-      const float ninv = nn > 0.f ? 1.f / nn : 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float mo = __shfl_xor(mean[k], off, 64), qo = __shfl_xor(m2[k], off, 64);
-        const float d = mo - mean[k];
-        m2[k] = m2[k] + qo + d * d * (cnt * n2 * ninv);
-        mean[k] = (cnt * mean[k] + n2 * mo) * ninv;
-      }
-      cnt = nn;
-    }
-    if (lane < G) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { s_stat[wave][0][c0 + k] = mean[k]; s_stat[wave][1][c0 + k] = m2[k]; s_stat[wave][2][c0 + k] = cnt; }
-    }
-    __syncthreads();
-    if (tid < CL) {
-      float n = s_stat[0][2][tid], m = s_stat[0][0][tid], q = s_stat[0][1][tid];
-#pragma unroll
-      for (int w = 1; w < 4; ++w) {
-        const float n2 = s_stat[w][2][tid], mo = s_stat[w][0][tid], qo = s_stat[w][1][tid];
-        const float nn = n + n2, ninv = nn > 0.f ? 1.f / nn : 0.f, d = mo - m;
-        q = q + qo + d * d * (n * n2 * ninv);
-        m = (n * m + n2 * mo) * ninv;
-        n = nn;
-      }
-      float* st = a.stats + (size_t)blockIdx.x * 3 * CL;
-      st[tid] = m; st[CL + tid] = q; st[2 * CL + tid] = n;
-    }
-  }
-}
-
 struct L2SArgs {
   const void* in;       // [B][H][W][CL] T
   const float* w;       // [CS][9][CL]
@@ -1045,8 +874,11 @@ extern "C" int im2im_smallconv_s2l_fwd(const float* in, const float* w, const fl
       hipLaunchKernelGGL(kern, dim3(std::min<unsigned>(grid.x, 256u * per_cu)), dim3(256), smem, stream, a);
       return check_launch("smallconv_s2l_dgrad_mfma_kernel");
     }
-    hipLaunchKernelGGL((smallconv_s2l_mfma_kernel<T, decltype(cl)::value>), grid, dim3(256), 0, stream, a);
-    return check_launch("smallconv_s2l_mfma_kernel");
+    // (an exact-fp32 MFMA form of this layer was measured slower than the VALU kernel: K = 9*CS is too short to pay for the
+    // LDS round trip of the accumulators -- 0.60 vs 0.50 ms at batch 78, 320x320, CS = 1)
+    if (CS == 1) hipLaunchKernelGGL((smallconv_s2l_kernel<T, decltype(cl)::value, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((smallconv_s2l_kernel<T, decltype(cl)::value, false>), grid, dim3(256), 0, stream, a);
+    return check_launch("smallconv_s2l_kernel");
   });
 }
 
@@ -1090,7 +922,7 @@ extern "C" int im2im_smallconv_wgrad(const float* S, const void* L, float* dw, f
   return for_dtype_cl(dtype, CL, [&](auto* tag, auto cl) {
     using T = std::remove_pointer_t<decltype(tag)>;
     constexpr int CLv = decltype(cl)::value;
-    if (true) {
+    if (CS >= 3) {                                     // matrix cores pay from 3 planes up (CS = 1: 0.83 vs 0.48 ms, the VALU kernel wins)
       constexpr size_t smem = wgrad_mfma_smem<T, CLv>();
       static_assert(smem >= (size_t)((HS * HS * 8 + 255) / 256) * 256 * sizeof(float), "bias scratch fits");
       auto kern = smallconv_wgrad_mfma_kernel<T, CLv>;
