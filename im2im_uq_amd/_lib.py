@@ -76,6 +76,9 @@ SIGNATURES = {
     "im2im_affine_relu_apply_per_image": (_i32, [_ptr, _ptr, _ptr, _i32, _i64, _i32, _i32, _ptr]),
     "im2im_groupnorm_relu_bwd_workspace_bytes": (_i64, [_i32, _i64, _i32]),
     "im2im_groupnorm_relu_bwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i64, _i32, _i32, _i32, _ptr, _i64, _ptr]),
+    "im2im_head_activation_fwd": (_i32, [_ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr]),
+    "im2im_head_activation_bwd": (_i32, [_ptr, _ptr, _i64, _i64, _i64, _i64, _i32, _ptr]),
+    "im2im_depth_space2": (_i32, [_ptr, _ptr, _i64, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_colsum_workspace_bytes": (_i64, [_i64, _i32]),
     "im2im_colsum": (_i32, [_ptr, _ptr, _i64, _i32, _i32, _ptr, _i64, _ptr]),
     "im2im_maxpool2_fwd": (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr]),

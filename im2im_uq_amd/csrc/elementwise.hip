@@ -460,6 +460,54 @@ __global__ __launch_bounds__(256) void gn_relu_bwd_apply_kernel(const T* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// Small elementwise pieces of the (f)-row layers that used to be torch ops:
+//   * head activation: ReLU on the Gaussian layer's variance plane (finallayers/gaussian_layer.py:15-17), abs on the
+//     residual-magnitude plane (residual_magnitude_layer.py:15-17).  out [B][K][P] fp32, plane `k` of every image is
+//     rewritten in place, its pre-activation values are kept in pre [B][P] for the backward mask / sign.
+//   * depth <-> space of the learned upsampling (nn.ConvTranspose2d(k=2, s=2), unet_parts.py:53, as a 1x1 conv to
+//     4*Co channels): y4 [B][h][w][(a, b, co)] <-> y [B][2h][2w][co], 16-byte vectors.
+__global__ __launch_bounds__(256) void head_act_fwd_kernel(float* __restrict__ out, float* __restrict__ pre, int64_t B, int64_t P,
+                                                            int64_t img_stride, int64_t plane_off, int kind) {
+  const int64_t total = B * P;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / P, p = i - b * P;
+    float* o = out + b * img_stride + plane_off + p;
+    const float v = *o;
+    pre[i] = v;
+    *o = kind == 0 ? fmaxf(v, 0.f) : fabsf(v);
+  }
+}
+__global__ __launch_bounds__(256) void head_act_bwd_kernel(float* __restrict__ dout, const float* __restrict__ pre, int64_t B, int64_t P,
+                                                            int64_t img_stride, int64_t plane_off, int kind) {
+  const int64_t total = B * P;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / P, p = i - b * P;
+    float* g = dout + b * img_stride + plane_off + p;
+    const float v = pre[i];
+    // torch: relu' = [v > 0]; abs' = sign(v) (0 at 0)
+    const float m = kind == 0 ? (v > 0.f ? 1.f : 0.f) : (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f));
+    *g = *g * m;
+  }
+}
+// to_space != 0: in [B][h][w][4*C] -> out [B][2h][2w][C];  else the inverse
+__global__ __launch_bounds__(256) void depth_space2_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int64_t B, int h, int w,
+                                                            int vpc, int to_space) {
+  const int64_t total = B * h * w * 4 * vpc;                 // 16-byte vectors
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    // i indexes the depth layout: (b, y, x, a, bb, cv)
+    int64_t t = i;
+    const int cv = (int)(t % vpc); t /= vpc;
+    const int bb = (int)(t % 2); t /= 2;
+    const int aa = (int)(t % 2); t /= 2;
+    const int x = (int)(t % w); t /= w;
+    const int y = (int)(t % h);
+    const int64_t b = t / h;
+    const int64_t j = (((b * 2 * h + 2 * y + aa) * 2 * w) + 2 * x + bb) * vpc + cv;
+    if (to_space) out[j] = in[i]; else out[i] = in[j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // column sums of an [M][C] tensor (bias gradient of the 1x1 out conv): partial[blk][C]; fixed-order, deterministic
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int64_t M, int C, int64_t rows_per_block,
@@ -1417,6 +1465,35 @@ extern "C" int im2im_groupnorm_relu_bwd(const void* da, const void* z, const flo
                        scale_shift, mean_rstd, coef, gamma, (T*)dz, nvec, (int)C);
     return check_launch("gn_relu_bwd_apply_kernel");
   });
+}
+
+extern "C" int im2im_head_activation_fwd(float* out, float* pre, int64_t B, int64_t P, int64_t img_stride, int64_t plane_offset,
+                                         int32_t kind, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(out && pre && B > 0 && P > 0 && (kind == 0 || kind == 1));
+  hipLaunchKernelGGL(head_act_fwd_kernel, dim3(ew_blocks(B * P)), dim3(256), 0, stream, out, pre, B, P, img_stride, plane_offset, (int)kind);
+  return check_launch("head_act_fwd_kernel");
+}
+
+extern "C" int im2im_head_activation_bwd(float* dout, const float* pre, int64_t B, int64_t P, int64_t img_stride,
+                                         int64_t plane_offset, int32_t kind, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(dout && pre && B > 0 && P > 0 && (kind == 0 || kind == 1));
+  hipLaunchKernelGGL(head_act_bwd_kernel, dim3(ew_blocks(B * P)), dim3(256), 0, stream, dout, pre, B, P, img_stride, plane_offset, (int)kind);
+  return check_launch("head_act_bwd_kernel");
+}
+
+extern "C" int im2im_depth_space2(const void* in, void* out, int64_t B, int32_t h, int32_t w, int32_t C, int32_t to_space,
+                                  int32_t dtype, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(in && out && B > 0 && h > 0 && w > 0 && C > 0);
+  const int esz = dtype == IM2IM_BF16 ? 2 : 4;
+  IM2IM_REQUIRE(dtype == IM2IM_BF16 || dtype == IM2IM_F32);
+  IM2IM_REQUIRE((C * esz) % 16 == 0);
+  const int vpc = C * esz / 16;
+  hipLaunchKernelGGL(depth_space2_kernel, dim3(ew_blocks(B * h * w * 4 * vpc)), dim3(256), 0, stream, (const uint4*)in, (uint4*)out, B, (int)h,
+                     (int)w, vpc, (int)to_space);
+  return check_launch("depth_space2_kernel");
 }
 
 extern "C" int64_t im2im_colsum_workspace_bytes(int64_t M, int32_t C) {

@@ -410,7 +410,7 @@ def smallconv_wgrad(s_nchw, l_nhwc, l_major, want_bias):
 # ----------------------------------------------------------------------------------------- autograd
 LAZY_ATTR = "_im2im_lazy_ss"
 LINK_ATTR = "_im2im_bn_link"
-FUSE_BN_REDUCE = False    # opt-in: a conv that is the only consumer of a lazy activation folds that layer's BatchNorm-backward
+FUSE_BN_REDUCE = os.environ.get("IM2IM_FUSE_BN_REDUCE", "0") == "1"    # opt-in: a conv that is the only consumer of a lazy activation folds that layer's BatchNorm-backward
                           # reduction into its own data-gradient epilogue (im2im_conv_dgrad_bn).  Measured (tools/bench_bn_fuse.py,
                           # profiles): every layer gains 0.02-0.18 ms in isolation, but in the step the power-limited MFMA
                           # kernels pay for the extra epilogue work and the net is +0.5 % -- not worth making the conv kernel
@@ -907,6 +907,19 @@ class Upsample2x(torch.autograd.Function):
         return nchw(ddeep), None, None
 
 
+def depth_space2(t, co, to_space):
+    """pixel shuffle of the 2x2 transposed conv: [B,h,w,4*co] -> [B,2h,2w,co] (to_space) or back."""
+    if to_space:
+        b, h, w_, _ = t.shape
+        out = torch.empty((b, 2 * h, 2 * w_, co), dtype=t.dtype, device=t.device)
+    else:
+        b, h2, w2, _ = t.shape
+        h, w_ = h2 // 2, w2 // 2
+        out = torch.empty((b, h, w_, 4 * co), dtype=t.dtype, device=t.device)
+    check(lib.im2im_depth_space2(dptr(t), dptr(out), b, h, w_, co, int(to_space), _DT[t.dtype], stream_ptr(t.device)), "im2im_depth_space2")
+    return out
+
+
 class ConvTranspose2x2(torch.autograd.Function):
     """nn.ConvTranspose2d(Ci, Co, kernel_size=2, stride=2) (Up with bilinear=False, unet_parts.py:53): every input pixel
     produces a 2x2 output patch and patches do not overlap, so it is ONE 1x1 convolution to 4*Co channels on the MFMA
@@ -922,7 +935,7 @@ class ConvTranspose2x2(torch.autograd.Function):
         w1 = weight.detach().permute(2, 3, 1, 0).reshape(4 * co, ci, 1, 1)        # row (a, b, co) <- weight[ci, co, a, b]
         wf, wd = pack_weight(w1, cdt)
         y4 = conv_fwd(xin, wf, bias.detach().to(F32).repeat(4), in_ss=ss)          # [B,h,w,(a,b,co)]
-        y = y4.view(b, h, w_, 2, 2, co).permute(0, 1, 3, 2, 4, 5).reshape(b, 2 * h, 2 * w_, co)
+        y = depth_space2(y4, co, to_space=True)
         ctx.has_ss = ss is not None
         ctx.save_for_backward(xin, wd, ss if ss is not None else torch.empty(0))
         return nchw(y)
@@ -934,7 +947,7 @@ class ConvTranspose2x2(torch.autograd.Function):
         b, h, w_, ci = xin.shape
         dy = nhwc(dy, xin.dtype)
         co = dy.shape[3]
-        d4 = dy.view(b, h, 2, w_, 2, co).permute(0, 1, 3, 2, 4, 5).reshape(b, h, w_, 4 * co)
+        d4 = depth_space2(dy.contiguous(), co, to_space=False)
         dx = nchw(conv_fwd(d4, wd)) if ctx.needs_input_grad[0] else None
         dw = conv_wgrad(xin, d4, 1, x_ss=ss).view(2, 2, co, ci).permute(3, 2, 0, 1).contiguous()
         db = colsum(dy.contiguous())                           # every output pixel gets the bias once
@@ -1004,6 +1017,9 @@ class QuantileHeads(torch.autograd.Function):
         return dfeat, dw[0], db[0], dw[1], db[1], dw[2], db[2], None
 
 
+_HEAD_ACT = {"relu": 0, "abs": 1}
+
+
 class Heads(torch.autograd.Function):
     """K 3x3 heads (K = 2 or 3) in one kernel, output [B,K,C,H,W] fp32, with an optional activation on head 1:
     'relu' (GaussianRegressionLayer's variance, gaussian_layer.py:15-17) or 'abs' (ResidualMagnitude*Layer's magnitude,
@@ -1022,13 +1038,12 @@ class Heads(torch.autograd.Function):
         out = smallconv_l2s(x, wf, b_all, k * c_out).view(b, k, c_out, h, w_)
         pre = torch.empty(0)
         if act is not None:
-            pre = out[:, 1].clone()
-            if act == "relu":
-                out[:, 1].clamp_(min=0)
-            elif act == "abs":
-                out[:, 1].abs_()
-            else:
+            if act not in _HEAD_ACT:
                 raise ValueError(f"unknown head activation {act!r}")
+            p = c_out * h * w_
+            pre = torch.empty((b, p), dtype=F32, device=out.device)
+            check(lib.im2im_head_activation_fwd(dptr(out), dptr(pre), b, p, k * p, p, _HEAD_ACT[act], stream_ptr(out.device)),
+                  "im2im_head_activation_fwd")
         ctx.save_for_backward(x, wf, pre)
         ctx.cfg = (c_out, k, act)
         return out
@@ -1040,8 +1055,10 @@ class Heads(torch.autograd.Function):
         b, h, w_, cmid = x.shape
         dout = dout.to(F32).contiguous()
         if act is not None:
-            dout = dout.clone()
-            dout[:, 1] *= (pre > 0).to(F32) if act == "relu" else torch.sign(pre)
+            dout = dout.clone()                    # the incoming gradient tensor belongs to autograd
+            p = c * h * w_
+            check(lib.im2im_head_activation_bwd(dptr(dout), dptr(pre), b, p, k * p, p, _HEAD_ACT[act], stream_ptr(dout.device)),
+                  "im2im_head_activation_bwd")
         dout = dout.view(b, k * c, h, w_)
         dfeat = None
         if ctx.needs_input_grad[0]:

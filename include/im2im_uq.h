@@ -283,6 +283,22 @@ int im2im_groupnorm_relu_bwd(const void* da, const void* z, const float* scale_s
                              int32_t C, int32_t G, int32_t dtype, void* ws, int64_t ws_bytes,
                              im2im_stream_t stream);
 
+/* Elementwise pieces of the SURVEY 8(f) layers.
+ *   im2im_head_activation_fwd/bwd: the activation on one plane of a final layer's packed output out [B][K][P] fp32 (plane
+ *     at element offset plane_offset inside each image of img_stride elements): kind 0 = ReLU (GaussianRegressionLayer's
+ *     variance, finallayers/gaussian_layer.py:15-17), 1 = abs (ResidualMagnitude*Layer, residual_magnitude_layer.py:15-17).
+ *     fwd rewrites the plane in place and keeps the pre-activation values in pre [B][P]; bwd multiplies the plane's
+ *     gradient in place by [pre > 0] or sign(pre).
+ *   im2im_depth_space2: the pixel shuffle of nn.ConvTranspose2d(k=2, s=2) evaluated as a 1x1 convolution to 4*C channels
+ *     (Up with bilinear=False, unet_parts.py:53): to_space != 0: in [B][h][w][(a, b, c)] -> out [B][2h][2w][c]; else the
+ *     inverse (its backward).  C * element size must be a multiple of 16 bytes. */
+int im2im_head_activation_fwd(float* out, float* pre, int64_t B, int64_t P, int64_t img_stride, int64_t plane_offset,
+                              int32_t kind, im2im_stream_t stream);
+int im2im_head_activation_bwd(float* dout, const float* pre, int64_t B, int64_t P, int64_t img_stride,
+                              int64_t plane_offset, int32_t kind, im2im_stream_t stream);
+int im2im_depth_space2(const void* in, void* out, int64_t B, int32_t h, int32_t w, int32_t C, int32_t to_space,
+                       int32_t dtype, im2im_stream_t stream);
+
 /* out[c] = sum_m x[m][c] (bias gradient of the 1x1 out conv, unet_parts.py:90). */
 int64_t im2im_colsum_workspace_bytes(int64_t M, int32_t C);
 int im2im_colsum(const void* x, float* out, int64_t M, int32_t C, int32_t dtype, void* ws,
