@@ -12,6 +12,7 @@
 #include "common.h"
 #include "dtypes.h"
 #include "reduce.h"
+#include <cstdlib>
 
 namespace {
 using namespace im2im;
@@ -837,6 +838,12 @@ __global__ __launch_bounds__(256) void smallconv_wgrad_final_kernel(const double
   else dw[((size_t)s * CL + l) * 9 + (8 - tp)] = (float)v;
 }
 
+// IM2IM_SMALLCONV_VALU: bit mask that forces the VALU forms (A/B runs): 1 = heads forward, 2 = heads data-gradient, 4 = weight gradient
+inline int valu_mask() {
+  static const int m = [] { const char* e = getenv("IM2IM_SMALLCONV_VALU"); return e ? atoi(e) : 0; }();
+  return m;
+}
+
 template <typename F> int for_dtype_cl(int dtype, int CL, F f) {
   if (dtype == IM2IM_BF16 && CL == 64) return f((bf16_t*)nullptr, std::integral_constant<int, 64>{});
   if (dtype == IM2IM_BF16 && CL == 32) return f((bf16_t*)nullptr, std::integral_constant<int, 32>{});
@@ -861,7 +868,7 @@ extern "C" int im2im_smallconv_s2l_fwd(const float* in, const float* w, const fl
   return for_dtype_cl(dtype, CL, [&](auto* tag, auto cl) {
     using T = std::remove_pointer_t<decltype(tag)>;
     const dim3 grid((unsigned)(B * a.tilesY * a.tilesX));
-    if (CS > 1 && !bias && !center && !scale_shift && !stats && !relu) {
+    if (CS > 1 && !bias && !center && !scale_shift && !stats && !relu && !(valu_mask() & 2)) {
       // the heads' data-gradient (plain correlation into a wide NHWC tensor): matrix-core form
       constexpr int CLv = decltype(cl)::value;
       constexpr size_t smem = s2l_dgrad_mfma_smem<T, CLv>();
@@ -890,6 +897,10 @@ extern "C" int im2im_smallconv_l2s_fwd(const void* in, const float* w, const flo
   return for_dtype_cl(dtype, CL, [&](auto* tag, auto cl) {
     using T = std::remove_pointer_t<decltype(tag)>;
     constexpr int CLv = decltype(cl)::value;
+    if (valu_mask() & 1) {
+      hipLaunchKernelGGL((smallconv_l2s_kernel<T, CLv>), dim3((unsigned)(B * a.tilesY * a.tilesX)), dim3(256), 0, stream, a);
+      return check_launch("smallconv_l2s_kernel");
+    }
     constexpr size_t smem = l2s_mfma_smem<T, CLv>();
     auto kern = smallconv_l2s_mfma_kernel<T, CLv>;
     if (smem > 64 * 1024) {
@@ -922,7 +933,7 @@ extern "C" int im2im_smallconv_wgrad(const float* S, const void* L, float* dw, f
   return for_dtype_cl(dtype, CL, [&](auto* tag, auto cl) {
     using T = std::remove_pointer_t<decltype(tag)>;
     constexpr int CLv = decltype(cl)::value;
-    if (CS >= 3) {                                     // matrix cores pay from 3 planes up (CS = 1: 0.83 vs 0.48 ms, the VALU kernel wins)
+    if (CS >= 3 && !(valu_mask() & 4)) {               // matrix cores pay from 3 planes up (CS = 1: 0.83 vs 0.48 ms, the VALU kernel wins)
       constexpr size_t smem = wgrad_mfma_smem<T, CLv>();
       static_assert(smem >= (size_t)((HS * HS * 8 + 255) / 256) * 256 * sizeof(float), "bias scratch fits");
       auto kern = smallconv_wgrad_mfma_kernel<T, CLv>;

@@ -1,19 +1,19 @@
 """bf16 (the benchmarked mode) against fp32 (the parity mode, itself pinned to the reference by G4/G5/G11/G17) over a
-REAL training run, end to end: same initial weights, same batches in the same order, 600 Adam steps (lr 1e-3) on a 64x64
+REAL training run, end to end: same initial weights, same batches in the same order, 600 Adam steps (lr 3e-4) on a 64x64
 denoising task, then calibration and validation -- the sequence of core/scripts/train.py:141-165 followed by
 calibrate_model.py:89-145 and eval.py:130-157.
 
 Training is chaotic: two fp32 runs that differ by a 1e-4 relative perturbation of the initial weights (40x smaller than
-one bf16 rounding) end up a few percent apart in every metric below.  That fp32-vs-fp32' distance is the yardstick: the
-bf16 run has to land as close to the fp32 run as a second fp32 run does (<= 2x the yardstick plus a small absolute
-margin), and within the absolute bounds stated in the asserts (measured on MI355X -- the kernels are deterministic, so
-the printed numbers reproduce run to run -- with ~1.5-2x head-room, tight enough that a wrong rounding point or a lost
-gradient term, which costs tens of percent, trips them):
-  * loss curve: mean train loss over the last 200 steps within 10 % of fp32's;
-  * both trained models calibrate (alpha = delta = 0.1, 100 lambdas) inside the grid, lambda-hat within 3 grid steps;
-  * both calibrated models hold the risk on 96 held-out images: validation risk <= alpha;
-  * the trained models agree as functions: prediction images within 8 % relative L2, calibrated lower / upper edges
-    within 10 % / 14 %.
+one bf16 rounding), or just by the summation order of one kernel, end up percents apart in every metric below; at lr 1e-3
+the calibrated interval size of fp32 runs alone spreads over 0.13-0.23 (tools/train_parity_probe.py), which is why this
+test trains at 3e-4, where the spread is small enough to compare against.  That fp32-vs-fp32' distance is the yardstick:
+the bf16 run has to land as close to the fp32 run as a second fp32 run does (<= 2x the yardstick plus a margin), and
+within absolute bounds.  Measured on MI355X over 3 perturbation seeds (fp32' vs fp32 | bf16 vs fp32):
+  tail-200 train loss 0.3-2.4 % | 2.0-6.3 %;  lambda-hat 1-3 | 1-4 grid steps of 100;  prediction images (rel. L2)
+  6.7-6.8 % | 6.0-8.0 %;  calibrated lower edge 7.2-9.1 % | 6.2-12.5 %;  upper edge 5.5-8.2 % | 4.8-9.1 %;  mean
+  calibrated interval size 0.142-0.147 | 0.138-0.162 (fp32: 0.138);  validation risk 0.050-0.052 for all (alpha = 0.1).
+Bounds asserted: loss 10 %, lambda-hat 6 steps, prediction 12 %, lower 20 %, upper 15 %, size ratio in [0.75, 1.35], risk
+<= alpha -- a wrong rounding point or a lost gradient term costs tens of percent and a broken calibration moves the risk.
 """
 import numpy as np
 import pytest
@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 PARAMS = dict(uncertainty_type="quantiles", q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1,
               alpha=0.1, delta=0.1, num_lambdas=100, rcps_loss="fraction_missed", minimum_lambda=0, maximum_lambda=6,
-              device=DEV, dataset="synthetic", batch_size=16, lr=1e-3, input_normalization="standard",
+              device=DEV, dataset="synthetic", batch_size=16, lr=3e-4, input_normalization="standard",
               output_normalization="min-max", num_validation_images=2)
 
 
@@ -40,7 +40,7 @@ def _restore_dtype():
     nn_ops.set_compute_dtype("bf16")
 
 
-def _run(dt, data, steps, hw, perturb=0.0):
+def _run(dt, data, steps, hw, perturb=0.0, seed=99):
     from im2im_uq_amd import nn_ops
     from im2im_uq_amd.core.calibration.calibrate_model import calibrate_model
     from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
@@ -51,7 +51,7 @@ def _run(dt, data, steps, hw, perturb=0.0):
     model = add_uncertainty(UNet(1, 1), dict(PARAMS))
     st = om.det_state(1, 1)
     if perturb:
-        g = torch.Generator().manual_seed(99)
+        g = torch.Generator().manual_seed(seed)
         st = {k: (v * (1 + perturb * torch.randn(v.shape, generator=g)) if om.is_param(k) else v) for k, v in st.items()}
     model.load_state_dict(st)
     model = model.to(DEV).train()
@@ -96,17 +96,20 @@ def test_bf16_training_tracks_fp32_training_then_calibrates_alike():
           f"{r32b['lhat']:.4f}  val risk {r32['risk']:.4f}/{r16['risk']:.4f}/{r32b['risk']:.4f}\n"
           f"  bf16 vs fp32 : " + "  ".join(f"{k} {v:.4f}" for k, v in d16.items()) + "\n"
           f"  fp32' vs fp32: " + "  ".join(f"{k} {v:.4f}" for k, v in dself.items()))
+    size = {k: float((r["hi"] - r["lo"]).mean()) for k, r in (("fp32", r32), ("bf16", r16), ("fp32'", r32b))}
+    print("  mean calibrated interval size: " + "  ".join(f"{k} {v:.4f}" for k, v in size.items()))
     for r in (r32, r16, r32b):
         assert np.isfinite(r["losses"]).all()
         assert r["losses"][-200:].mean() < 0.1 * r["losses"][0]                       # actually trained
         assert 0 < r["lhat"] < 6                                                      # the scan stopped inside the grid
         assert r["risk"] <= PARAMS["alpha"]                                           # the calibrated sets hold the risk
     assert r16["losses"][0] == pytest.approx(r32["losses"][0], rel=1e-2)              # same start
-    # absolute bounds (measured, see the module docstring)
-    assert d16["loss"] < 0.10 and d16["lhat"] <= 3.0 + 1e-6
-    assert d16["mid"] < 0.08 and d16["lo"] < 0.10 and d16["hi"] < 0.14
+    # absolute bounds (measured spreads in the module docstring)
+    assert d16["loss"] < 0.10 and d16["lhat"] <= 6.0 + 1e-6
+    assert d16["mid"] < 0.12 and d16["lo"] < 0.20 and d16["hi"] < 0.15
+    assert 0.75 < size["bf16"] / size["fp32"] < 1.35
     # and no further from fp32 than fp32 is from itself (2x + margin)
     assert d16["loss"] <= 2 * dself["loss"] + 0.05
-    assert d16["lhat"] <= 2 * dself["lhat"] + 2.0
+    assert d16["lhat"] <= 2 * dself["lhat"] + 3.0
     for k in ("mid", "lo", "hi"):
-        assert d16[k] <= 2 * dself[k] + 0.02, (k, d16[k], dself[k])
+        assert d16[k] <= 2 * dself[k] + 0.04, (k, d16[k], dself[k])
