@@ -41,11 +41,9 @@ struct Fp8ConvArgs {
   const float* bias;     // [Co] or null
   const float* scale;    // [Co] or null (EPI 2)
   const float* shift;
-  bf16_t* y;             // [B][H][W][Co]  (or [.., Co_lo) when y_hi is set)
+  bf16_t* y;             // [B][H][W][Co]
   float* stats;          // [tiles][3][Co] or null
   int B, H, W, Ci, Co, Ci_lo, tilesY, tilesX, relu;
-  bf16_t* y_hi;          // null, or output channels [Co_lo, Co)
-  int Co_lo;
 };
 
 __device__ __forceinline__ void merge_moments_f32(float& n, float& m, float& q, float n2, float m2, float q2) {
@@ -70,22 +68,17 @@ __device__ __forceinline__ uint2 to_fp8x8(const float (&v)[8]) {
 }
 
 // EPI: 0 = (+bias) store; 1 = +bias, store, BatchNorm partial statistics; 2 = folded BatchNorm affine (+ReLU)
-// FP8 = false: the same staging structure (LDS-double-buffered halo, trickled in under the MFMAs) with bf16 operands --
-// 32-channel chunks, two v_mfma_f32_32x32x16_bf16 k-steps per tap, no scales: the bf16 forward / data-gradient kernel.
-template <bool FP8, int TB, int TH, int TW, int BN, int WM, int WN, int EPI>
+template <int TB, int TH, int TW, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
   using T = bf16_t;
   constexpr int HH = TH + 2, HWD = TW + 2, HPI = HH * HWD, HPX = TB * HPI;
   constexpr int MI = TH * TW;
-  constexpr int KC = FP8 ? 64 : 32;                   // channels per chunk (fp8: one MFMA k-step; bf16: two)
-  constexpr int PPX = FP8 ? 8 : 4;                    // 16-byte global pieces (8 bf16 channels) per pixel and chunk
-  constexpr int LPB = FP8 ? 8 : 16;                   // bytes a piece occupies in LDS
-  constexpr float XS = FP8 ? XSCALE : 1.f;
-  constexpr int ROWB = 64 + 16;                       // LDS row pitch (bytes): 64 fp8 / 32 bf16 + pad
+  constexpr int KC = 64;                              // channels per chunk = one MFMA k-step
+  constexpr int ROWB = KC + 16;                       // LDS row pitch (bytes): 64 fp8 + pad
   constexpr int M = TB * TH * TW;
   constexpr int MT = M / (32 * WM), NT = BN / (32 * WN);
   static_assert(WM * WN == 4 && MT >= 1 && NT >= 1, "tile split");
-  constexpr int A_PIECES = HPX * PPX;                 // 16-byte global pieces (8 bf16 channels) per halo chunk
+  constexpr int A_PIECES = HPX * 8;                   // 16-byte global pieces (8 bf16 channels) per halo chunk
   constexpr int A_ROUNDS = (A_PIECES + 255) / 256;
   constexpr int B_ROUNDS = (BN * 4 + 255) / 256;      // 16-byte pieces (16 fp8 channels) per weight tile
   constexpr int HROWB = HWD * ROWB + 96;              // halo rows padded: conflict-free ds_read_b128 (enumerated)
@@ -120,11 +113,6 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
   }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) boff[nt] = ((wn * NT + nt) * 32 + l31) * ROWB + half * 32;
-  int aoffb[MT], boffb[NT];                          // bf16 operand addressing: 16 bytes per lane and k-step
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) aoffb[mt] = aoff[mt] - half * 16;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) boffb[nt] = boff[nt] - half * 16;
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -137,13 +125,13 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
   const bool lazy_lo = a.in_ss != nullptr, lazy_hi = a.in_ss_hi != nullptr;
   if (lazy_lo || lazy_hi) {
     const int clo = split_in ? a.Ci_lo : a.Ci, chi = a.Ci - clo;
-    if (lazy_lo) for (int i = tid; i < clo; i += 256) { ldsSS[i] = a.in_ss[i] * XS; ldsSS[a.Ci + i] = a.in_ss[clo + i] * XS; }
-    if (lazy_hi) for (int i = tid; i < chi; i += 256) { ldsSS[clo + i] = a.in_ss_hi[i] * XS; ldsSS[a.Ci + clo + i] = a.in_ss_hi[chi + i] * XS; }
+    if (lazy_lo) for (int i = tid; i < clo; i += 256) { ldsSS[i] = a.in_ss[i] * XSCALE; ldsSS[a.Ci + i] = a.in_ss[clo + i] * XSCALE; }
+    if (lazy_hi) for (int i = tid; i < chi; i += 256) { ldsSS[clo + i] = a.in_ss_hi[i] * XSCALE; ldsSS[a.Ci + clo + i] = a.in_ss_hi[chi + i] * XSCALE; }
     __syncthreads();
   }
 
   // ---- halo staging, one 16-byte piece (pixel, 8 channels) at a time.  part = tid % 8 is the same for all of a thread's pieces.
-  const int part = tid & (PPX - 1);
+  const int part = tid & 7;
   const T* __restrict__ xg_tile = a.x + (size_t)b0 * a.H * a.W * xstride;
   const T* __restrict__ xh_tile = a.x_hi + (size_t)b0 * a.H * a.W * xstride;
   // `t` is the thread id, passed through an opaque asm once per chunk so that the compiler RE-COMPUTES the ~20 integer
@@ -151,75 +139,54 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
   // keeping the 2 x A_ROUNDS offsets of the whole halo live across the loop, which the 128 accumulators leave no room for
   auto piece_src = [&](int chunk, int i, int t, int& loff) -> const T* {       // null: padding (zeros); loff < 0: no such piece
     const int p = i * 256 + t;
-    const int px = p / PPX;
+    const int px = p >> 3;
     loff = -1;
     if (A_PIECES % 256 != 0 && px >= HPX) return nullptr;
     const int tb = px / HPI, pi = px % HPI;
     const int hy = pi / HWD, hx = pi % HWD;
-    loff = tb * HIMGB + hy * HROWB + hx * ROWB + (t & (PPX - 1)) * LPB;
+    loff = tb * HIMGB + hy * HROWB + hx * ROWB + (t & 7) * 8;
     const int yy = y0 + hy - 1, xx = x0 + hx - 1;
     if (b0 + tb >= a.B || yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) return nullptr;
     const int c = chunk * KC;
     const T* base = (split_in && c >= a.Ci_lo) ? xh_tile + (c - a.Ci_lo) : xg_tile + c;
-    return base + ((size_t)(tb * a.H + yy) * a.W + xx) * xstride + (t & (PPX - 1)) * 8;
+    return base + ((size_t)(tb * a.H + yy) * a.W + xx) * xstride + (t & 7) * 8;
   };
   // lazy coefficients are read from LDS per piece (4 x ds_read_b128; registers are the scarce resource here), pre-scaled by 2^4
   auto convert_write = [&](const uint4& raw, bool real, int loff, char* dst, int chunk) {
     if (loff < 0) return;
-    const bool lazy_cur = (split_in && chunk * KC >= a.Ci_lo) ? lazy_hi : lazy_lo;
-    if constexpr (!FP8) {
-      uint4 q = make_uint4(0, 0, 0, 0);
-      if (real) {
-        q = raw;
-        if (lazy_cur) {
-          float v[8];
-          Vec16<T>::load(reinterpret_cast<const T*>(&raw), v);
-          const int c0 = chunk * KC + part * 8;
-          const float4 s0 = *reinterpret_cast<const float4*>(ldsSS + c0), s1 = *reinterpret_cast<const float4*>(ldsSS + c0 + 4);
-          const float4 h0 = *reinterpret_cast<const float4*>(ldsSS + a.Ci + c0), h1 = *reinterpret_cast<const float4*>(ldsSS + a.Ci + c0 + 4);
-          const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-          const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    uint2 q = make_uint2(0u, 0u);
+    if (real) {
+      float v[8];
+      Vec16<T>::load(reinterpret_cast<const T*>(&raw), v);
+      const bool lazy_cur = (split_in && chunk * KC >= a.Ci_lo) ? lazy_hi : lazy_lo;
+      if (lazy_cur) {
+        const int c0 = chunk * KC + part * 8;
+        const float4 s0 = *reinterpret_cast<const float4*>(ldsSS + c0), s1 = *reinterpret_cast<const float4*>(ldsSS + c0 + 4);
+        const float4 h0 = *reinterpret_cast<const float4*>(ldsSS + a.Ci + c0), h1 = *reinterpret_cast<const float4*>(ldsSS + a.Ci + c0 + 4);
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+        // 16 * max(z*scale + shift, 0) == max(z*(16 scale) + 16 shift, 0): ldsSS holds the coefficients times 2^4 (exact)
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] * sc[k] + sh[k], 0.f);      // same expression and rounding as bn_relu_apply
-          Vec16<T>::store(reinterpret_cast<T*>(&q), v);
-        }
+        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] * sc[k] + sh[k], 0.f);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= XSCALE;
       }
-      *reinterpret_cast<uint4*>(dst + loff) = q;
-    } else {
-      uint2 q = make_uint2(0u, 0u);
-      if (real) {
-        float v[8];
-        Vec16<T>::load(reinterpret_cast<const T*>(&raw), v);
-        if (lazy_cur) {
-          const int c0 = chunk * KC + part * 8;
-          const float4 s0 = *reinterpret_cast<const float4*>(ldsSS + c0), s1 = *reinterpret_cast<const float4*>(ldsSS + c0 + 4);
-          const float4 h0 = *reinterpret_cast<const float4*>(ldsSS + a.Ci + c0), h1 = *reinterpret_cast<const float4*>(ldsSS + a.Ci + c0 + 4);
-          const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-          const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-          // 16 * max(z*scale + shift, 0) == max(z*(16 scale) + 16 shift, 0): ldsSS holds the coefficients times 2^4 (exact)
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] * sc[k] + sh[k], 0.f);
-        } else {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] *= XSCALE;
-        }
-        q = to_fp8x8(v);
-      }
-      *reinterpret_cast<uint2*>(dst + loff) = q;
+      q = to_fp8x8(v);
     }
+    *reinterpret_cast<uint2*>(dst + loff) = q;
   };
 
-  constexpr int WSZ = FP8 ? 1 : 2;                    // bytes per weight element; a weight row chunk is 64 bytes either way
-  const unsigned char* __restrict__ wg_tile = a.w + (size_t)n0 * 9 * a.Ci * WSZ;
+  const unsigned char* __restrict__ wg_tile = a.w + (size_t)n0 * 9 * a.Ci;
   uint4 rb[2][B_ROUNDS];
   auto gload_B = [&](uint4 (&r)[B_ROUNDS], int chunk, int tap) {
-    const unsigned char* src = wg_tile + ((size_t)tap * a.Ci + chunk * KC) * WSZ;
+    const unsigned char* src = wg_tile + (size_t)tap * a.Ci + chunk * KC;
 #pragma unroll
     for (int i = 0; i < B_ROUNDS; ++i) {
       const int p = i * 256 + tid;
       const int n = p >> 2, pt = p & 3;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if ((BN * 4) % 256 == 0 || n < BN) v = *reinterpret_cast<const uint4*>(src + (size_t)n * 9 * a.Ci * WSZ + pt * 16);
+      if ((BN * 4) % 256 == 0 || n < BN) v = *reinterpret_cast<const uint4*>(src + (size_t)n * 9 * a.Ci + pt * 16);
       r[i] = v;
     }
   };
@@ -234,39 +201,22 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
   auto compute = [&](int toff, int bbuf, int abuf) {
     const char* pa = ldsA + abuf * A_BYTES + toff;
     const char* pb = ldsB + bbuf * B_BYTES;
-    if constexpr (FP8) {
-      i32x8 fb[NT];
+    i32x8 fb[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const uint4 lo = *reinterpret_cast<const uint4*>(pb + boff[nt]);
-        const uint4 hi = *reinterpret_cast<const uint4*>(pb + boff[nt] + 16);
-        fb[nt] = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-      }
-      // one A fragment (8 registers) at a time, reused by the NT weight fragments: the 128 accumulators leave no room for four
+    for (int nt = 0; nt < NT; ++nt) {
+      const uint4 lo = *reinterpret_cast<const uint4*>(pb + boff[nt]);
+      const uint4 hi = *reinterpret_cast<const uint4*>(pb + boff[nt] + 16);
+      fb[nt] = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+    }
+    // one A fragment (8 registers) at a time, reused by the NT weight fragments: the 128 accumulators leave no room for four
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const uint4 lo = *reinterpret_cast<const uint4*>(pa + aoff[mt]);
-        const uint4 hi = *reinterpret_cast<const uint4*>(pa + aoff[mt] + 16);
-        const i32x8 fa = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+    for (int mt = 0; mt < MT; ++mt) {
+      const uint4 lo = *reinterpret_cast<const uint4*>(pa + aoff[mt]);
+      const uint4 hi = *reinterpret_cast<const uint4*>(pa + aoff[mt] + 16);
+      const i32x8 fa = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb[nt], acc[mt][nt], 0, 0, 0, XSCALE_E8M0, 0, 127);
-      }
-    } else {
-      // bf16: a lane's 32 bytes of a row are its two k-steps (channels [half*8, +8) of each 16-channel step live at +ks*32 + half*16)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        short8 fa[MT], fb[NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) fa[mt] = *reinterpret_cast<const short8*>(pa + aoffb[mt] + ks * 32);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) fb[nt] = *reinterpret_cast<const short8*>(pb + boffb[nt] + ks * 32);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fa[mt]), as_bf16x8(fb[nt]), acc[mt][nt], 0, 0, 0);
-      }
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb[nt], acc[mt][nt], 0, 0, 0, XSCALE_E8M0, 0, 127);
     }
   };
 
@@ -339,9 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
   constexpr int ROWS_PER_PASS = 64 / EPR;
   constexpr int PASSES = WROWS / ROWS_PER_PASS;
   const int ncol = n0 + wn * WCOLS;
-  const bool to_hi = a.y_hi != nullptr && ncol >= a.Co_lo;
-  T* __restrict__ yg = (to_hi ? a.y_hi : a.y) + (to_hi ? ncol - a.Co_lo : ncol);
-  const int ystride = a.y_hi == nullptr ? a.Co : (to_hi ? a.Co - a.Co_lo : a.Co_lo);
+  T* __restrict__ yg = a.y + ncol;
   constexpr bool want_stats = (EPI == 1);
   __syncthreads();
   char* wbuf = smem + wave * WBYTES;
@@ -360,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = n0 + (wn * NT + nt) * 32 + l31;
-    const float ws = FP8 ? a.wscale[n] : 1.f;
+    const float ws = a.wscale[n];
     const float bias_v = a.bias ? a.bias[n] : 0.f;
     float sc2 = 1.f, sh2 = 0.f;
     if constexpr (EPI == 2) { sc2 = a.scale[n]; sh2 = a.shift[n]; }
@@ -401,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
     const int m = wm * WROWS + row;
     const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
     if (bb < a.B && yy < a.H && xx < a.W)
-      *reinterpret_cast<uint4*>(yg + (((size_t)bb * a.H + yy) * a.W + xx) * ystride + piece * EPP) = v;
+      *reinterpret_cast<uint4*>(yg + (((size_t)bb * a.H + yy) * a.W + xx) * a.Co + piece * EPP) = v;
   }
   if (want_stats) {
     __syncthreads();
@@ -455,7 +403,7 @@ __global__ __launch_bounds__(256) void pack_weight_fp8_kernel(const float* __res
   }
 }
 
-template <bool FP8, int TB, int TH, int TW, int BN, int WM, int WN, int EPI>
+template <int TB, int TH, int TW, int BN, int WM, int WN, int EPI>
 int launch_fp8(const Fp8ConvArgs& a_in, hipStream_t stream) {
   Fp8ConvArgs a = a_in;
   a.tilesY = (int)cdiv(a.H, TH);
@@ -465,7 +413,7 @@ int launch_fp8(const Fp8ConvArgs& a_in, hipStream_t stream) {
   constexpr size_t smem_epi = (size_t)4 * (TB * TH * TW / WM) * ((BN / WN) * 2 + 16);
   const size_t smem_in = smem_main + ((a.in_ss || a.in_ss_hi) ? (size_t)2 * a.Ci * sizeof(float) : 0);
   const size_t smem = smem_in > smem_epi ? smem_in : smem_epi;
-  auto kern = conv_fp8_kernel<FP8, TB, TH, TW, BN, WM, WN, EPI>;
+  auto kern = conv_fp8_kernel<TB, TH, TW, BN, WM, WN, EPI>;
   static size_t attr_set = 0;
   if (smem > 64 * 1024 && smem > attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -476,19 +424,11 @@ int launch_fp8(const Fp8ConvArgs& a_in, hipStream_t stream) {
   return check_launch("conv_fp8_kernel");
 }
 
-template <bool FP8, int TB, int TH, int TW, int BN, int WM, int WN>
+template <int TB, int TH, int TW, int BN, int WM, int WN>
 int launch_fp8_epi(const Fp8ConvArgs& a, hipStream_t stream) {
-  if (a.stats) return launch_fp8<FP8, TB, TH, TW, BN, WM, WN, 1>(a, stream);
-  if (a.scale) return launch_fp8<FP8, TB, TH, TW, BN, WM, WN, 2>(a, stream);
-  return launch_fp8<FP8, TB, TH, TW, BN, WM, WN, 0>(a, stream);
-}
-
-template <bool FP8>
-int dispatch_trickle(const Fp8ConvArgs& a, hipStream_t stream) {
-  const bool small = (a.H < 64 || a.W < 64);
-  const bool wide = a.Co % 128 == 0;
-  if (!small) return wide ? launch_fp8_epi<FP8, 1, 16, 16, 128, 2, 2>(a, stream) : launch_fp8_epi<FP8, 1, 16, 16, 64, 4, 1>(a, stream);
-  return wide ? launch_fp8_epi<FP8, 4, 8, 8, 128, 2, 2>(a, stream) : launch_fp8_epi<FP8, 4, 8, 8, 64, 4, 1>(a, stream);
+  if (a.stats) return launch_fp8<TB, TH, TW, BN, WM, WN, 1>(a, stream);
+  if (a.scale) return launch_fp8<TB, TH, TW, BN, WM, WN, 2>(a, stream);
+  return launch_fp8<TB, TH, TW, BN, WM, WN, 0>(a, stream);
 }
 
 }  // namespace
@@ -524,15 +464,9 @@ extern "C" int im2im_conv_fwd_fp8(const void* x, const float* in_scale_shift, co
   IM2IM_REQUIRE((scale == nullptr) == (shift == nullptr));
   IM2IM_REQUIRE(!(stats && scale));
   Fp8ConvArgs a{(const bf16_t*)x, (const bf16_t*)x_hi, in_scale_shift, in_scale_shift_hi, (const unsigned char*)wq, wscale, bias,
-                scale, shift, (bf16_t*)y, stats, B, H, W, Ci, Co, Ci_lo, 0, 0, relu, nullptr, Co};
-  return dispatch_trickle<true>(a, stream);
-}
-
-// bf16 operands through the trickled-halo kernel (called by im2im_conv_fwd_split for dtype IM2IM_BF16, taps = 9, Co % 64 == 0)
-int im2im_conv_trickle_bf16(const void* x, const float* in_ss, const void* x_hi, const float* in_ss_hi, int Ci_lo, const void* wf,
-                            const float* bias, const float* scale, const float* shift, void* y, void* y_hi, int Co_lo, float* stats,
-                            int B, int H, int W, int Ci, int Co, int relu, hipStream_t stream) {
-  Fp8ConvArgs a{(const bf16_t*)x, (const bf16_t*)x_hi, in_ss, in_ss_hi, (const unsigned char*)wf, nullptr, bias, scale, shift,
-                (bf16_t*)y, stats, B, H, W, Ci, Co, Ci_lo, 0, 0, relu, (bf16_t*)y_hi, Co_lo};
-  return dispatch_trickle<false>(a, stream);
+                scale, shift, (bf16_t*)y, stats, B, H, W, Ci, Co, Ci_lo, 0, 0, relu};
+  const bool small = (H < 64 || W < 64);
+  const bool wide = Co % 128 == 0;
+  if (!small) return wide ? launch_fp8_epi<1, 16, 16, 128, 2, 2>(a, stream) : launch_fp8_epi<1, 16, 16, 64, 4, 1>(a, stream);
+  return wide ? launch_fp8_epi<4, 8, 8, 128, 2, 2>(a, stream) : launch_fp8_epi<4, 8, 8, 64, 4, 1>(a, stream);
 }

@@ -24,7 +24,6 @@
 #define IM2IM_WGRAD_XCD 1
 #endif
 #include <type_traits>
-#include <cstdlib>
 
 namespace {
 
@@ -944,14 +943,6 @@ int conv_fwd_impl(const void* x, const float* in_scale_shift, int in_ss_img, boo
                   const float* scale, const float* shift, void* y, void* y_hi, int32_t Co_lo, float* stats, int32_t B, int32_t H,
                   int32_t W, int32_t Ci, int32_t Co, int32_t taps, int32_t relu, int32_t dtype, im2im_stream_t stream_);
 }
-// conv_fp8.hip: the trickled-halo kernel with bf16 operands
-int im2im_conv_trickle_bf16(const void* x, const float* in_ss, const void* x_hi, const float* in_ss_hi, int Ci_lo, const void* wf,
-                            const float* bias, const float* scale, const float* shift, void* y, void* y_hi, int Co_lo, float* stats,
-                            int B, int H, int W, int Ci, int Co, int relu, hipStream_t stream);
-static int trickle_mode() {      // IM2IM_CONV_TRICKLE: 1 = use it for every eligible bf16 3x3 launch (A/B switch while it is being evaluated)
-  static const int m = [] { const char* e = getenv("IM2IM_CONV_TRICKLE"); return e ? atoi(e) : 0; }();
-  return m;
-}
 
 extern "C" int im2im_conv_fwd_per_image(const void* x, const float* in_scale_shift_per_image, const void* w, const float* bias,
                                         void* y, float* stats, int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co,
@@ -997,10 +988,6 @@ int conv_fwd_impl(const void* x, const float* in_scale_shift, int in_ss_img, boo
   IM2IM_REQUIRE(!(stats && scale));                              // statistics describe the raw conv output
   IM2IM_REQUIRE(Ci <= 2048);
   IM2IM_REQUIRE(in_ss_img == 0 || (per_image && x_hi == nullptr));   // per-image coefficients need one image per tile
-  if (trickle_mode() && dtype == IM2IM_BF16 && taps == 9 && !center && !per_image && Co % 64 == 0 && Ci % 32 == 0 &&
-      (!x_hi || Ci_lo % 32 == 0))
-    return im2im_conv_trickle_bf16(x, in_scale_shift, x_hi, in_scale_shift_hi, Ci_lo, w, bias, scale, shift, y, y_hi, Co_lo, stats, B, H, W,
-                                   Ci, Co, relu, stream);
   ConvArgs a{x, w, bias, scale, shift, y, stats, B, H, W, Ci, Co, 0, 0, relu, center, in_scale_shift,
              x_hi, in_scale_shift_hi, Ci_lo, y_hi, Co_lo, nullptr, nullptr, nullptr, nullptr, in_ss_img};
   if (dtype == IM2IM_BF16) return taps == 9 ? dispatch_conv<bf16_t, 9>(a, stream, per_image) : dispatch_conv<bf16_t, 1>(a, stream, per_image);
