@@ -161,7 +161,7 @@ def conv_fwd_fp8(x, wq, wscale, bias=None, scale_shift=None, relu=False, want_st
     if scale_shift is not None:
         sc, sh = scale_shift[0], scale_shift[1]
     small = h < 64 or w_ < 64
-    name = f"conv_fp8_kernel<{'4x8x8' if small else '1x16x16'},{128 if co % 128 == 0 else 64}>"
+    name = f"conv_fp8_kernel<{'2x8x8' if small else '1x16x16'},{128 if co % 128 == 0 else 64}>"
     ev = TIMER.wrap(name, 2.0 * b * h * w_ * co * ci * 9, x.device) if TIMER else None
     check(lib.im2im_conv_fwd_fp8(dptr(x), dptr(in_ss), dptr(x_hi), dptr(in_ss_hi), ci_lo, dptr(wq), dptr(wscale), dptr(bias), dptr(sc),
                                  dptr(sh), dptr(y), dptr(stats), b, h, w_, ci, co, int(relu), stream_ptr(x.device)), "im2im_conv_fwd_fp8")
