@@ -237,6 +237,8 @@ def main():
         opt.step()
         return loss
 
+    host_dt = [0.0]
+
     def timed(fn, steps, warmup):
         for _ in range(warmup):
             fn()
@@ -244,6 +246,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
+        host_dt[0] = time.perf_counter() - t0        # time the host needed to ENQUEUE the steps (launch-bound when ~ the total)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         barrier()
@@ -256,8 +259,10 @@ def main():
     peak = PEAK_FP32_TFLOPS if conf["dtype"] == "fp32" else PEAK_BF16_TFLOPS
     # ---------------------------------------------------------------- train leg
     model.train()
+    host_train = None
     if "train" in legs:
         dt_train = timed(train_step, args.steps, args.warmup)
+        host_train = host_dt[0] / args.steps * 1e3
     else:
         dt_train = float("nan")
         args.no_roofline = True
@@ -326,7 +331,7 @@ def main():
         if rank == 0:
             print(json.dumps({"metric": "train imgs/sec (train leg only)", "value": train_ips, "unit": "imgs/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_train / args.steps * 1e3,
-                              "dtype": conf["dtype"], "roofline": roof, "roofline_wgrad": roof_w, "fp32": fp32, "per_kernel": per_kernel}))
+                              "host_enqueue_ms_per_step": host_train, "dtype": conf["dtype"], "roofline": roof, "roofline_wgrad": roof_w, "fp32": fp32, "per_kernel": per_kernel}))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -423,7 +428,7 @@ def main():
         line = {
             "metric": f"train imgs/sec (+ calib imgs/sec in `calib`), {hw}x{hw} UNet " + what,
             "value": train_ips, "unit": "imgs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt_train / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "ms_per_step": dt_train / args.steps * 1e3, "host_enqueue_ms_per_step": host_train, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": conf["dtype"], "data": "synthetic (shaped like the named dataset, random-init weights)",
             "config": {"workload": conf["label"] + (f" [overrides: {', '.join(custom)}]" if custom else "") + f", {args.uncertainty_type}",
                        "per_gpu_batch": B, "global_batch": global_batch, "parallelism": f"dp{world}", "unet_depth": depth,
