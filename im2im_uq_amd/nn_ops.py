@@ -251,6 +251,7 @@ def bn_relu_bwd_from_partial(da, z, scale_shift, mean_invstd, partial):
 WGRAD_SIDE_STREAM = os.environ.get("IM2IM_WGRAD_STREAM", "1") != "0"
 _side_streams = {}
 _side_busy = set()
+_side_keep = {}            # device index -> tensors the side stream still reads or writes; dropped once the main stream joined it
 _callback_queued = set()
 
 
@@ -266,33 +267,37 @@ def join_side_streams():
     """make the current stream of every device wait for the weight-gradient stream's work."""
     for idx in list(_side_busy):
         torch.cuda.current_stream(idx).wait_stream(_side_streams[idx])
+        _side_keep.pop(idx, None)                        # from here on the main stream is ordered after every side-stream use
     _side_busy.clear()
     _callback_queued.clear()
 
 
-def _on_side_stream(device, tensors_in, fn):
-    """run fn() on the device's side stream after everything already queued on the current stream; inputs are kept alive
-    for the side stream, outputs handed back to the current one."""
+def _on_side_stream(device, tensors, fn):
+    """run fn() on the device's side stream after everything already queued on the current stream.
+
+    Memory discipline: every tensor the side stream touches (inputs AND the outputs, which the caller allocates on the
+    current stream before calling) is owned by the current stream's allocator pool and kept referenced until the join, so
+    a block is only ever reused in current-stream order after the join.  Tensor.record_stream is deliberately not used:
+    it parks a freed block until an event on the other stream has COMPLETED, and a host that runs several steps ahead of
+    the GPU (no sync in a training loop) then never gets a block back -- the caching allocator grew to 190 GB for a
+    12 GB working set, and a process starting while the driver was still releasing that memory ran 2x slower
+    (profiles/r02_allocator_stall.txt)."""
     main = torch.cuda.current_stream(device)
     side = side_stream(device)
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        out = fn()
-    for t in tensors_in:
-        if t is not None and t.numel():
-            t.record_stream(side)
-    out.record_stream(main)
+        fn()
     idx = torch.device(device).index
+    _side_keep.setdefault(idx, []).extend(t for t in tensors if t is not None)
     _side_busy.add(idx)
     if idx not in _callback_queued:                      # join when this backward pass ends
         _callback_queued.add(idx)
         torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
-    return out
 
 
-def conv_wgrad(x, dz, taps, x_ss=None, x_hi=None, x_ss_hi=None, scratch_key="a"):
+def conv_wgrad(x, dz, taps, x_ss=None, x_hi=None, x_ss_hi=None, scratch_key="a", out=None):
     """x [B,H,W,Ci], dz [B,H,W,Co] -> dw [Co,Ci,taps] fp32 (x_ss: lazy BatchNorm+ReLU of x, as in conv_fwd; x_hi: second
-    half of the input channels as in conv_fwd)."""
+    half of the input channels as in conv_fwd).  out: a preallocated [Co,Ci,taps] fp32 result."""
     b, h, w_, ci = x.shape
     ci_lo = ci
     if x_hi is not None:
@@ -302,7 +307,7 @@ def conv_wgrad(x, dz, taps, x_ss=None, x_hi=None, x_ss_hi=None, scratch_key="a")
     if nbytes < 0:
         raise _lib.Im2ImError(f"conv wgrad: unsupported channels Ci={ci} Co={co}")
     ws = _Scratch.get(nbytes, x.device, scratch_key)
-    dw = torch.empty((co, ci, taps), dtype=F32, device=x.device)
+    dw = torch.empty((co, ci, taps), dtype=F32, device=x.device) if out is None else out
     ev = TIMER.wrap(_tile_name("wgrad", h, w_, co, taps, x.dtype), 2.0 * b * h * w_ * co * ci * taps, x.device) if TIMER else None
     check(lib.im2im_conv_wgrad_split(dptr(x), dptr(x_ss), dptr(x_hi), dptr(x_ss_hi), ci_lo, dptr(dz), dptr(dw), dptr(ws), ws.numel(),
                                      b, h, w_, ci, co, taps, _DT[x.dtype], stream_ptr(x.device)), "im2im_conv_wgrad_split")
@@ -500,8 +505,9 @@ class ConvStats(torch.autograd.Function):
             # an existing .grad on this stream the moment we return (gradient accumulation over several backward passes)
             w_ref = ctx.weight_ref() if ctx.weight_ref is not None else None
             if WGRAD_SIDE_STREAM and not torch.is_grad_enabled() and w_ref is not None and w_ref.grad is None:
-                dw = _on_side_stream(dz.device, (xin, dz, in_ss, xin_hi, in_ss_hi),
-                                     lambda: conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi, scratch_key="side"))
+                dw = torch.empty((dz.shape[3], ci, 9), dtype=F32, device=dz.device)     # owned by the current stream's pool
+                _on_side_stream(dz.device, (xin, dz, in_ss, xin_hi, in_ss_hi, dw),
+                                lambda: conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi, scratch_key="side", out=dw))
                 dw = dw.view(dz.shape[3], ci, 3, 3)
             else:
                 dw = conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi).view(dz.shape[3], ci, 3, 3)
