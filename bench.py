@@ -273,14 +273,14 @@ def main():
     if not args.no_roofline:
         # per-launch durations of the conv kernels, HIP events on the launch stream.  The weight gradients are put back on the
         # main stream for these two steps: a kernel's roofline is about the kernel alone, not about what it shares the chip with
-        side_stream_was = nn_ops.WGRAD_SIDE_STREAM
-        nn_ops.WGRAD_SIDE_STREAM = False
+        side_stream_was, pipeline_was = nn_ops.WGRAD_SIDE_STREAM, nn_ops.BWD_PIPELINE
+        nn_ops.WGRAD_SIDE_STREAM = nn_ops.BWD_PIPELINE = False
         nn_ops.TIMER = nn_ops.KernelTimer()
         for _ in range(2):
             train_step()
         rows = nn_ops.TIMER.collect()
         nn_ops.TIMER = None
-        nn_ops.WGRAD_SIDE_STREAM = side_stream_was
+        nn_ops.WGRAD_SIDE_STREAM, nn_ops.BWD_PIPELINE = side_stream_was, pipeline_was
         per_kernel = {k: {"launches": n, "avg_ms": t / n, "tflops": f / t / 1e9} for k, (n, f, t) in sorted(rows.items())}
         ig = [(n, f, t) for k, (n, f, t) in rows.items() if k.startswith("conv_igemm")]
         wg = [(n, f, t) for k, (n, f, t) in rows.items() if k.startswith("conv_wgrad")]

@@ -68,6 +68,8 @@ SIGNATURES = {
     "im2im_bn_relu_pool_bwd_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "im2im_bn_relu_pool_bwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr, _i64, _ptr]),
     "im2im_bn_relu_bwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i64, _ptr]),
+    "im2im_bn_bwd_rows_per_block": (_i64, [_i64]),
+    "im2im_bn_relu_bwd_phase": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i64, _i32, _i64, _i64, _ptr]),
     "im2im_conv_tiles_per_image": (_i64, [_i32, _i32]),
     "im2im_conv_fwd_per_image": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_groupnorm_stats_rows": (_i64, [_i32, _i64]),

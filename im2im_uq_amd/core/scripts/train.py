@@ -122,6 +122,9 @@ class GradSync:
             main = torch.cuda.current_stream(self.flat.device)
             side = nn_ops.side_stream(self.flat.device)
             side.wait_stream(main)              # gradients produced on the main stream (BatchNorm, biases, heads)
+            bn = nn_ops._bn_streams.get(self.flat.device.index)
+            if bn is not None:
+                side.wait_stream(bn)            # ... and dgamma / dbeta of the pipelined BatchNorm backward on its stream
             with torch.cuda.stream(side):       # ... and, in stream order, the conv weight gradients computed on this one
                 self._pack(b)
                 self.launched[b] = self.dist.all_reduce(self.flat[lo:hi], async_op=True)

@@ -1309,6 +1309,57 @@ extern "C" int im2im_bn_relu_bwd(const void* da, const void* z, const float* sca
   });
 }
 
+// The same BatchNorm+ReLU backward cut into phases over row ranges, so that a caller can run it on its own stream while
+// the data-gradient kernels that produce `da` / consume `dz` work on another half of the batch (nn_ops.BnReluLazy):
+//   phase 1: per-block partial sums of rows [row0,row1)   (row0 a multiple of im2im_bn_bwd_rows_per_block(M))
+//   phase 2: reduce all partial rows -> dgamma, dbeta, coefficients (needs phase 1 over every row)
+//   phase 4: dz rows [row0,row1)                          (needs phase 2)
+// The block decomposition, and therefore every bit of the result, is that of im2im_bn_relu_bwd on the whole tensor.
+extern "C" int64_t im2im_bn_bwd_rows_per_block(int64_t M) {
+  if (M <= 0) return 0;
+  const int64_t nblk = std::min<int64_t>(cdiv(M, 64), 2048);
+  return cdiv(M, nblk);
+}
+
+extern "C" int im2im_bn_relu_bwd_phase(const void* da, const void* z, const float* scale_shift, const float* mean_invstd, void* dz,
+                                       float* dgamma, float* dbeta, int64_t M, int32_t C, int32_t dtype, void* ws, int64_t ws_bytes,
+                                       int32_t phase, int64_t row0, int64_t row1, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(da && z && scale_shift && mean_invstd && dz && dgamma && dbeta && ws && M > 0 && C > 0 && C % 8 == 0);
+  IM2IM_REQUIRE(ws_bytes >= im2im_bn_bwd_workspace_bytes(M, C));
+  IM2IM_REQUIRE(C <= 1024);
+  IM2IM_REQUIRE(phase == 1 || phase == 2 || phase == 4);
+  const int64_t nblk = std::min<int64_t>(cdiv(M, 64), 2048);
+  const int64_t rpb = cdiv(M, nblk);
+  IM2IM_REQUIRE(phase == 2 || (row0 >= 0 && row0 < row1 && row1 <= M));
+  IM2IM_REQUIRE(phase != 1 || row0 % rpb == 0);
+  float* partial = (float*)ws;
+  double* tmp = (double*)((char*)ws + nblk * 2 * C * sizeof(float));
+  float* coef = (float*)((char*)tmp + reduce_tmp_bytes(2 * (int64_t)C));
+  return for_dtype(dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    if (phase == 1) {
+      const int64_t rows = row1 - row0;
+      hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<T>, dim3((unsigned)cdiv(rows, rpb)), dim3(256), 0, stream,
+                         (const T*)da + row0 * C, (const T*)z + row0 * C, scale_shift, mean_invstd, rows, (int)C, rpb,
+                         partial + (row0 / rpb) * 2 * C);
+      return check_launch("bn_relu_bwd_reduce_kernel");
+    }
+    if (phase == 2) {
+      int rc;
+      const int S = launch_reduce_stage1(partial, cdiv(M, rpb), 2 * (int64_t)C, tmp, stream, &rc);
+      if (rc) return rc;
+      hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, stream, (const double*)tmp, S, (int)C,
+                         (double)M, dgamma, dbeta, coef);
+      return check_launch("bn_bwd_finalize_kernel");
+    }
+    const int64_t nvec = (row1 - row0) * C / Vec16<T>::N;
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, stream, (const T*)da + row0 * C,
+                       (const T*)z + row0 * C, scale_shift, mean_invstd, coef, (T*)dz + row0 * C, nvec, (int)C);
+    return check_launch("bn_relu_bwd_apply_kernel");
+  });
+}
+
 namespace {
 inline dim3 pool_bwd_grid(int B, int H, int W, int vpr) {
   const int Hc = (H + 1) / 2, Wc = (W + 1) / 2;

@@ -176,7 +176,7 @@ BF16_CENTERING = False    # opt-in: bf16 train mode stores z - running_mean (im2
 
 
 def conv_fwd(x, wf, bias=None, scale_shift=None, relu=False, want_stats=False, in_ss=None, center=None, x_hi=None,
-             in_ss_hi=None, split_out=0):
+             in_ss_hi=None, split_out=0, out=None, out_hi=None):
     """x [B,H,W,Ci], wf [Co,taps,Ci] -> y [B,H,W,Co] (+ stats [R,2,Co]).  in_ss [2,Ci]: x is a producer's pre-BN z and
     the kernel applies max(z*scale+shift, 0) while staging it (lazy BatchNorm+ReLU).
     x_hi: second half of the input channels (the concatenation [x, x_hi] is never materialised); split_out = Co_lo > 0:
@@ -189,7 +189,9 @@ def conv_fwd(x, wf, bias=None, scale_shift=None, relu=False, want_stats=False, i
         ci = 2 * ci
     co, taps = wf.shape[0], wf.shape[1]
     y_hi = None
-    if split_out:
+    if out is not None:                               # preallocated result(s): a batch slice of a larger tensor
+        y, y_hi = out, out_hi
+    elif split_out:
         y = torch.empty((b, h, w_, split_out), dtype=x.dtype, device=x.device)
         y_hi = torch.empty((b, h, w_, co - split_out), dtype=x.dtype, device=x.device)
     else:
@@ -264,15 +266,80 @@ def side_stream(device):
 
 
 def join_side_streams():
-    """make the current stream of every device wait for the weight-gradient stream's work."""
+    """make the current stream of every device wait for the weight-gradient and BatchNorm-backward streams' work."""
     for idx in list(_side_busy):
-        torch.cuda.current_stream(idx).wait_stream(_side_streams[idx])
+        main = torch.cuda.current_stream(idx)
+        for pool in (_side_streams, _bn_streams):
+            if idx in pool:
+                main.wait_stream(pool[idx])
         _side_keep.pop(idx, None)                        # from here on the main stream is ordered after every side-stream use
     _side_busy.clear()
     _callback_queued.clear()
+    _halves.clear()
 
 
-def _on_side_stream(device, tensors, fn):
+def _queue_join(idx):
+    _side_busy.add(idx)
+    if idx not in _callback_queued:                      # join when this backward pass ends
+        _callback_queued.add(idx)
+        torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+
+
+# ---- backward pass pipelined over two halves of the batch ------------------------------------------------------------
+# The backward chain  data-gradient (MFMA-bound) -> BatchNorm backward (two HBM-bound passes) -> data-gradient of the
+# layer below ...  is strictly sequential per tensor, so the matrix cores idle during the BatchNorm passes and HBM idles
+# during the data-gradients.  Cut along the batch it pipelines: the data-gradient writes images [0,b/2) and then
+# [b/2,b); BatchNorm's reduction starts on the first half while the second is still being computed, and its second pass
+# hands the first half of dz to the next data-gradient while finishing the second.  The BatchNorm kernels run on their
+# own stream (the weight gradients have theirs), ordered by events; every launch uses the block decomposition of the
+# unsplit call, so the results are bit-identical to the sequential schedule (tests/test_model_gpu.py).
+# OPT-IN, measured negative on MI355X at the bench shape (profiles/r02_ab_experiments.txt): 43.05 ms/step sequential vs
+# 43.6-44.1 pipelined (any size threshold), 44.6 vs 45.0 without the weight-gradient stream.  The data-gradients of the
+# full-resolution 64-channel layers are themselves half HBM-bound and all MFMA kernels are power-limited, so a BatchNorm
+# pass running beside them takes from them what it hides; the weight-gradient stream (+3.6 %) already fills the gaps.
+BWD_PIPELINE = os.environ.get("IM2IM_BWD_PIPELINE", "0") == "1"
+BWD_PIPELINE_MIN_BYTES = int(os.environ.get("IM2IM_BWD_PIPELINE_MIN_BYTES", str(64 << 20)))   # per tensor; below this the extra launches cost more
+_bn_streams = {}
+_halves = {}             # data_ptr -> Halves of a gradient tensor whose two batch halves become ready at different times
+
+
+class Halves:
+    """a gradient tensor [B,H,W,C] (NHWC storage) whose images [0,b_first) are complete at `first` and all of it at `rest`
+    (an event, or None = in the order of the current stream).  Holds the tensor so its memory cannot be reused while
+    the record exists."""
+    __slots__ = ("tensor", "b_first", "first", "rest")
+
+    def __init__(self, tensor, b_first, first, rest):
+        self.tensor, self.b_first, self.first, self.rest = tensor, b_first, first, rest
+
+
+def bn_stream(device):
+    idx = torch.device(device).index
+    st = _bn_streams.get(idx)
+    if st is None:
+        st = _bn_streams[idx] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _publish_halves(t, b_first, first, rest=None):
+    _halves[t.data_ptr()] = Halves(t, b_first, first, rest)
+
+
+def _take_halves(t):
+    h = _halves.pop(t.data_ptr(), None)
+    if h is not None and (h.tensor.numel() != t.numel() or h.tensor.shape[0] != (t.shape[0])):
+        raise _lib.Im2ImError("backward pipeline: a gradient tensor changed shape between producer and consumer")
+    return h
+
+
+def _pipeline_split(t):
+    """images in the first half of NHWC tensor t, or 0 when the tensor is too small to be worth two launches."""
+    if not BWD_PIPELINE or torch.is_grad_enabled() or t.shape[0] < 2 or t.numel() * t.element_size() < BWD_PIPELINE_MIN_BYTES:
+        return 0
+    return t.shape[0] // 2
+
+
+def _on_side_stream(device, tensors, fn, after=None):
     """run fn() on the device's side stream after everything already queued on the current stream.
 
     Memory discipline: every tensor the side stream touches (inputs AND the outputs, which the caller allocates on the
@@ -285,14 +352,13 @@ def _on_side_stream(device, tensors, fn):
     main = torch.cuda.current_stream(device)
     side = side_stream(device)
     side.wait_stream(main)
+    if after is not None:                                # an operand produced on a third stream (pipelined BatchNorm backward)
+        side.wait_event(after)
     with torch.cuda.stream(side):
         fn()
     idx = torch.device(device).index
     _side_keep.setdefault(idx, []).extend(t for t in tensors if t is not None)
-    _side_busy.add(idx)
-    if idx not in _callback_queued:                      # join when this backward pass ends
-        _callback_queued.add(idx)
-        torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+    _queue_join(idx)
 
 
 def conv_wgrad(x, dz, taps, x_ss=None, x_hi=None, x_ss_hi=None, scratch_key="a", out=None):
@@ -355,6 +421,49 @@ def bn_relu_bwd(da, z, scale_shift, mean_invstd):
     ws = _Scratch.get(nbytes, dev)
     check(lib.im2im_bn_relu_bwd(dptr(da), dptr(z), dptr(scale_shift), dptr(mean_invstd), dptr(dz), dptr(dgamma), dptr(dbeta), m, c,
                                 _DT[z.dtype], dptr(ws), ws.numel(), stream_ptr(dev)), "im2im_bn_relu_bwd")
+    return dz, dgamma, dbeta
+
+
+def bn_relu_bwd_pipelined(da, z, scale_shift, mean_invstd, halves, b_first):
+    """bn_relu_bwd on the BatchNorm stream, in two halves of the batch (see BWD_PIPELINE): the reduction of images
+    [0,b_first) starts at halves.first (or at once), the rest when the current stream's queued work is done; dz is
+    published with the events at which its two halves are complete.  Bit-identical to bn_relu_bwd."""
+    c = z.shape[-1]
+    m = z.numel() // c
+    dev = z.device
+    idx = dev.index
+    dz = torch.empty_like(z)
+    dgamma = torch.empty((c,), dtype=F32, device=dev)
+    dbeta = torch.empty((c,), dtype=F32, device=dev)
+    ws = _Scratch.get(lib.im2im_bn_bwd_workspace_bytes(m, c), dev, "bn")      # this stream's own scratch
+    rpb = lib.im2im_bn_bwd_rows_per_block(m)
+    r_apply = b_first * (m // z.shape[0])
+    r_reduce = (r_apply // rpb) * rpb                      # whole reduction blocks inside the first half
+    main = torch.cuda.current_stream(dev)
+    bn = bn_stream(dev)
+
+    def phase(which, r0, r1):
+        check(lib.im2im_bn_relu_bwd_phase(dptr(da), dptr(z), dptr(scale_shift), dptr(mean_invstd), dptr(dz), dptr(dgamma), dptr(dbeta),
+                                          m, c, _DT[z.dtype], dptr(ws), ws.numel(), which, r0, r1, bn.cuda_stream), "im2im_bn_relu_bwd_phase")
+
+    if halves is not None and halves.first is not None and r_reduce > 0:
+        bn.wait_event(halves.first)
+        phase(1, 0, r_reduce)
+        bn.wait_stream(main)                               # the second half, and every earlier user of the new tensors' memory
+        phase(1, r_reduce, m)
+    else:
+        bn.wait_stream(main)
+        phase(1, 0, m)
+    phase(2, 0, 0)
+    phase(4, 0, r_apply)
+    first = torch.cuda.Event()
+    first.record(bn)
+    phase(4, r_apply, m)
+    rest = torch.cuda.Event()
+    rest.record(bn)
+    _publish_halves(dz, b_first, first, rest)
+    _side_keep.setdefault(idx, []).extend((da, z, scale_shift, mean_invstd, dz))     # NOT dgamma/dbeta: autograd must be able to adopt them without a copy
+    _queue_join(idx)
     return dz, dgamma, dbeta
 
 
@@ -492,7 +601,13 @@ class ConvStats(torch.autograd.Function):
         in_ss = in_ss if ctx.has[0] else None
         xin_hi = xin_hi if ctx.has[1] else None
         in_ss_hi = in_ss_hi if ctx.has[2] else None
+        halves = _take_halves(dz)                     # dz from the pipelined BatchNorm backward lives on ITS stream until these events
+        main = torch.cuda.current_stream(dz.device)
+        if halves is not None and halves.rest is not None and (ctx.small or dz.dtype != xin.dtype):
+            main.wait_event(halves.rest)
+            halves = None
         dz = nhwc(dz, xin.dtype if not ctx.small else dz.dtype)
+        dz_ready = halves.rest if halves is not None else None
         dx = dx_hi = None
         if ctx.small:
             dw, _ = smallconv_wgrad(xin, dz, l_major=True, want_bias=False)
@@ -507,22 +622,54 @@ class ConvStats(torch.autograd.Function):
             if WGRAD_SIDE_STREAM and not torch.is_grad_enabled() and w_ref is not None and w_ref.grad is None:
                 dw = torch.empty((dz.shape[3], ci, 9), dtype=F32, device=dz.device)     # owned by the current stream's pool
                 _on_side_stream(dz.device, (xin, dz, in_ss, xin_hi, in_ss_hi, dw),
-                                lambda: conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi, scratch_key="side", out=dw))
+                                lambda: conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi, scratch_key="side", out=dw),
+                                after=dz_ready)
                 dw = dw.view(dz.shape[3], ci, 3, 3)
             else:
+                if dz_ready is not None:
+                    main.wait_event(dz_ready)
+                    halves = dz_ready = None
                 dw = conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi).view(dz.shape[3], ci, 3, 3)
-            if xin_hi is not None:
-                # the data-gradient lands directly in d(skip) and d(up): no concatenated gradient tensor
-                dx, dx_hi = conv_fwd(dz, wd, split_out=xin.shape[3])
-                dx, dx_hi = nchw(dx), nchw(dx_hi)
-            elif ctx.needs_input_grad[0]:
-                link = ctx.link
-                if FUSE_BN_REDUCE and link is not None and link.consumers == 1 and link.z.dtype == dz.dtype:
-                    # sole consumer of a lazy activation: its BatchNorm-backward sums ride on this data-gradient's epilogue
-                    dx, link.partial = conv_dgrad_bn(dz, wd, link.z, link.ss, link.mi)
-                    dx = nchw(dx)
+            link = ctx.link
+            fuse = (FUSE_BN_REDUCE and xin_hi is None and link is not None and link.consumers == 1 and link.z.dtype == dz.dtype)
+            b_first = 0
+            if (xin_hi is not None or ctx.needs_input_grad[0]) and not fuse:
+                b_first = halves.b_first if halves is not None else _pipeline_split(dz)
+            if b_first:
+                # data-gradient in two halves of the batch: the first waits only for ITS half of dz, and the BatchNorm
+                # backward of the layer below may start on it while the second half is computed (see BWD_PIPELINE)
+                b, h, w_ = dz.shape[0], dz.shape[1], dz.shape[2]
+                co_in = wd.shape[0]
+                split = xin.shape[3] if xin_hi is not None else 0
+                dxn = torch.empty((b, h, w_, split if split else co_in), dtype=dz.dtype, device=dz.device)
+                dxh = torch.empty((b, h, w_, co_in - split), dtype=dz.dtype, device=dz.device) if split else None
+                if halves is not None and halves.first is not None:
+                    main.wait_event(halves.first)
+                conv_fwd(dz[:b_first], wd, split_out=split, out=dxn[:b_first], out_hi=dxh[:b_first] if split else None)
+                first = torch.cuda.Event()
+                first.record(main)
+                if dz_ready is not None:
+                    main.wait_event(dz_ready)
+                conv_fwd(dz[b_first:], wd, split_out=split, out=dxn[b_first:], out_hi=dxh[b_first:] if split else None)
+                if split:
+                    dx, dx_hi = nchw(dxn), nchw(dxh)
                 else:
-                    dx = nchw(conv_fwd(dz, wd))           # gradient w.r.t. the (lazy) input activation
+                    _publish_halves(dxn, b_first, first)
+                    dx = nchw(dxn)
+            else:
+                if dz_ready is not None:
+                    main.wait_event(dz_ready)
+                if xin_hi is not None:
+                    # the data-gradient lands directly in d(skip) and d(up): no concatenated gradient tensor
+                    dx, dx_hi = conv_fwd(dz, wd, split_out=xin.shape[3])
+                    dx, dx_hi = nchw(dx), nchw(dx_hi)
+                elif ctx.needs_input_grad[0]:
+                    if fuse:
+                        # sole consumer of a lazy activation: its BatchNorm-backward sums ride on this data-gradient's epilogue
+                        dx, link.partial = conv_dgrad_bn(dz, wd, link.z, link.ss, link.mi)
+                        dx = nchw(dx)
+                    else:
+                        dx = nchw(conv_fwd(dz, wd))           # gradient w.r.t. the (lazy) input activation
         return dx, dx_hi, dw, None, None, None, None, None, None, None, None
 
 
@@ -543,11 +690,19 @@ class BnReluLazy(torch.autograd.Function):
         zz = nhwc(z)
         link = ctx.link
         partial = link.partial if link is not None else None
+        halves = _take_halves(da)                     # da always completes in the order of the current stream; `first` is a head start
+        dan = nhwc(da, zz.dtype)
         if partial is not None:
             link.partial = None                       # the consumer's data-gradient already reduced g and g*xhat per tile
-            dz, dgamma, dbeta = bn_relu_bwd_from_partial(nhwc(da, zz.dtype), zz, scale_shift, mean_invstd, partial)
+            dz, dgamma, dbeta = bn_relu_bwd_from_partial(dan, zz, scale_shift, mean_invstd, partial)
         else:
-            dz, dgamma, dbeta = bn_relu_bwd(nhwc(da, zz.dtype), zz, scale_shift, mean_invstd)
+            b_first = _pipeline_split(zz) if dan.data_ptr() == da.data_ptr() else 0
+            if b_first and halves is not None:
+                b_first = halves.b_first
+            if b_first:
+                dz, dgamma, dbeta = bn_relu_bwd_pipelined(dan, zz, scale_shift, mean_invstd, halves, b_first)
+            else:
+                dz, dgamma, dbeta = bn_relu_bwd(dan, zz, scale_shift, mean_invstd)
         return nchw(dz), dgamma, dbeta, None, None, None
 
 

@@ -231,6 +231,16 @@ int64_t im2im_bn_bwd_workspace_bytes(int64_t M, int32_t C);
 int im2im_bn_relu_bwd(const void* da, const void* z, const float* scale_shift, const float* mean_invstd,
                       void* dz, float* dgamma, float* dbeta, int64_t M, int32_t C, int32_t dtype,
                       void* ws, int64_t ws_bytes, im2im_stream_t stream);
+/* im2im_bn_relu_bwd cut into phases over row ranges, for a caller that pipelines it against the data-gradient kernels
+ * working on the other half of the batch (nn_ops.BnReluLazy; no reference counterpart -- torch's batch_norm backward is
+ * one call).  phase 1: partial sums of rows [row0,row1), row0 a multiple of im2im_bn_bwd_rows_per_block(M);
+ * phase 2: dgamma, dbeta and the coefficients from all partial rows; phase 4: dz rows [row0,row1).  Same ws, same block
+ * decomposition and therefore bit-identical results to im2im_bn_relu_bwd. */
+int64_t im2im_bn_bwd_rows_per_block(int64_t M);
+int im2im_bn_relu_bwd_phase(const void* da, const void* z, const float* scale_shift, const float* mean_invstd,
+                            void* dz, float* dgamma, float* dbeta, int64_t M, int32_t C, int32_t dtype,
+                            void* ws, int64_t ws_bytes, int32_t phase, int64_t row0, int64_t row1,
+                            im2im_stream_t stream);
 /* im2im_bn_relu_bwd with the reduction already done by im2im_conv_dgrad_bn: partial [R][2][C].
  * ws: im2im_reduce_workspace_bytes(2*C) + 2*C*4 bytes. */
 int im2im_bn_relu_bwd_from_partial(const void* da, const void* z, const float* scale_shift, const float* mean_invstd,

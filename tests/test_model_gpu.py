@@ -581,6 +581,38 @@ def test_train_step_is_bitwise_reproducible_bf16():
             assert torch.equal(runs[0][i][n], runs[1][i][n]), (i, n)
 
 
+@pytest.mark.parametrize("dt,batch", [("bf16", 5), ("fp32", 4), ("bf16", 2)])
+def test_backward_pipelined_over_batch_halves_is_bit_identical(dt, batch, monkeypatch):
+    """nn_ops.BWD_PIPELINE: the data-gradients and the BatchNorm backward run in two halves of the batch on different
+    streams, ordered by events.  Same kernels, same block decomposition -> loss, every gradient and the updated weights
+    equal the sequential schedule bit for bit (odd batch: halves of 2 and 3 images; the reduction split falls inside
+    an image).  Three steps, so that memory handed back between the streams is reused."""
+    from oracle import model as om
+    from im2im_uq_amd import nn_ops
+    monkeypatch.setattr(nn_ops, "BWD_PIPELINE_MIN_BYTES", 0)
+    x, y = om.det_images(batch, 1, 64, 80, salt=21)
+    runs = []
+    for pipelined in (False, True):
+        monkeypatch.setattr(nn_ops, "BWD_PIPELINE", pipelined)
+        model = build(1, dt)
+        model.train()
+        opt = nn_ops.FusedAdam(model.parameters(), lr=1e-3)
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            loss = model.loss_fn(model(x.to(DEV)), y.to(DEV))
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        runs.append((losses, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None},
+                     {n: p.detach().clone() for n, p in model.named_parameters()}))
+        assert (len(nn_ops._bn_streams) > 0) or not pipelined
+    assert runs[0][0] == runs[1][0]
+    for i in (1, 2):
+        for n in runs[0][i]:
+            assert torch.equal(runs[0][i][n], runs[1][i][n]), (i, n)
+
+
 def _g14_block(name):
     from im2im_uq_amd.core.models.trunks import unet_parts as up
     return {"doubleconv": lambda: up.DoubleConv(2, 64, 32), "down": lambda: up.Down(32, 64),
