@@ -97,8 +97,11 @@ __device__ __forceinline__ void merge_moments_f32(float& n, float& m, float& q, 
 //      addresses and accumulate sum(g) and sum(g*xhat), g = da*[z*scale+shift > 0] -- bn_relu_bwd_reduce without its
 //      own pass over da and z.  Compile-time so the 128 values per lane pay only for what
 //      the launch needs (the generic epilogue was ~10 VALU per value; the data-gradient needs ~1).
+// bf16: two workgroups per CU (256 registers per lane each).  fp32: the operand buffers are twice as large (84-94 KB for
+// the 128-wide tiles), so only one workgroup fits a CU anyway -- it may then use the whole 512-entry register file
+// instead of spilling 150-540 registers to scratch as it did under the two-workgroup bound.
 template <typename T, int TB, int TH, int TW, int BN, int WM, int WN, int TAPS, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 || BN < 128) ? 2 : 1) void conv_igemm_kernel(ConvArgs a) {
   constexpr int PAD = (TAPS == 9) ? 1 : 0;
   constexpr int HH = TH + 2 * PAD, HWD = TW + 2 * PAD, HPI = HH * HWD, HPX = TB * HPI;   // halo pixels per image / per tile
   constexpr int MI = TH * TW;                         // output pixels per image in the tile
@@ -356,19 +359,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   // per-value validity test: the test compiled to an exec-mask branch around each of the 128 values (the statistics epilogue
   // was 4,663 instructions against 1,900 for the whole main loop of a 64-channel layer).  Wave-uniform choice, same arithmetic.
   const bool tile_full = (b0 + TB <= a.B) && (y0 + TH <= a.H) && (x0 + TW <= a.W);
-  float cnt = 0.f;
+  static_assert(MT * 16 <= 64, "one validity bit per accumulator row of the lane");
+  unsigned long long okmask = ~0ull;                         // bit mt*16+r: this lane's row (mt, r) is a pixel of the image
+  float cnt = (float)(16 * MT);
   if constexpr (want_stats) {
-    if (tile_full) {
-      cnt = (float)(16 * MT);
-    } else {
+    if (!tile_full) {                                        // overhanging tile: ONE pass over the rows, kept as a bit mask
+      okmask = 0ull;                                         // (64 separately hoisted predicates spilled registers)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = wm * WROWS + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
           const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
-          cnt += (bb < a.B && yy < a.H && xx < a.W) ? 1.f : 0.f;
+          if (bb < a.B && yy < a.H && xx < a.W) okmask |= 1ull << (mt * 16 + r);
         }
+      cnt = (float)__popcll(okmask);
     }
   }
   auto convert_tile = [&](auto full_tag) {
@@ -395,16 +400,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
           const T tv = from_float<T>(v);
           *reinterpret_cast<T*>(wbuf + row * WP + (nt * 32 + l31) * (int)sizeof(T)) = tv;
           if constexpr (want_stats) {
-            bool ok = true;
-            if constexpr (!FULL) {
-              const int m = wm * WROWS + row;
-              const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
-              ok = bb < a.B && yy < a.H && xx < a.W;
-            }
-            if (ok) {
-              const float d = to_float(tv) - K;
-              s += d; sq += d * d;
-            }
+            float d = to_float(tv) - K;
+            if constexpr (!FULL) d = ((okmask >> (mt * 16 + r)) & 1ull) ? d : 0.f;
+            s += d; sq += d * d;
           }
         }
       }
