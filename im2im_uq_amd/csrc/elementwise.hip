@@ -870,11 +870,11 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ de
 template <typename T>
 __global__ __launch_bounds__(256) void upcat_bwd_kernel(const T* __restrict__ dout, T* __restrict__ ddeep,
                                                          T* __restrict__ dskip, int B, int h, int w, int Cd, int H, int W,
-                                                         int Cs, RowVec rvs, RowVec rvd) {
+                                                         int Cs, RowVec rvs, RowVec rvd, int deep_rows) {
   constexpr int N = Vec16<T>::N;
   const int Ct = Cs + Cd;
   const int py = (H - 2 * h) / 2, px = (W - 2 * w) / 2;
-  const int rows_skip = Cs > 0 ? B * H : 0, rows_deep = B * h;
+  const int rows_skip = Cs > 0 ? B * H : 0, rows_deep = deep_rows ? B * h : 0;     // deep_rows == 0: up2x_bwd_tiled_kernel does ddeep
   for (int row = blockIdx.y; row < rows_skip + rows_deep; row += gridDim.y) {
     if (row < rows_skip) {
       const int rowvecs = W * rvs.vpr;
@@ -930,6 +930,239 @@ __global__ __launch_bounds__(256) void upcat_bwd_kernel(const T* __restrict__ do
       }
       Vec16<T>::store(ddeep + (((int64_t)r * w + xi) * (int64_t)Cd) + cv * N, acc);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tiled forms of the two kernels above for the path the training step takes (no skip half in the output: the consumer
+// conv reads skip and upsampled tensor as two operands).  The row-walking kernels spend their time on arithmetic, not on
+// HBM: the forward applies the lazy BatchNorm+ReLU to four source vectors per output vector (each source pixel is
+// transformed ~4 times over) and the backward evaluates 36 candidate taps with their index arithmetic per output vector
+// (1.1 + 1.0 ms per step against a 0.45 + 0.45 ms traffic floor).  Here a workgroup owns a tile x 64 channels:
+//   forward : 4 x 32 output pixels; the <= 4 x 18 source pixels they interpolate between are transformed ONCE into LDS
+//             (fp32, already rounded to the storage type like the materialised activation), then every output vector is
+//             four LDS reads and the same arithmetic as upcat_fwd_kernel -- bit-identical results;
+//   backward: 4 x 16 source pixels; separable: first the vertical sums V[yi][ux] = sum_uy wy * dout[uy][ux] over the
+//             <= 6 candidate rows into LDS, then the horizontal sums over the <= 6 candidate columns (weights in small
+//             LDS tables built once per tile; same candidate sets and weights as upcat_bwd_kernel, different order of
+//             the fp32 additions).
+#ifndef IM2IM_UPB_TR
+#define IM2IM_UPB_TR 2
+#endif
+#ifndef IM2IM_UPF_TR
+#define IM2IM_UPF_TR 8
+#endif
+#ifndef IM2IM_UPF_TC
+#define IM2IM_UPF_TC 16
+#endif
+constexpr int UPF_TR = IM2IM_UPF_TR, UPF_TC = IM2IM_UPF_TC, UPF_SR = UPF_TR / 2 + 2, UPF_SC = UPF_TC / 2 + 2, UP_CC = 64;
+constexpr int UPB_TR = IM2IM_UPB_TR, UPB_TC = 16, UPB_HC = 2 * UPB_TC + 4;       // hi-res columns a tile's sums can touch (ux in [2*x0-2, 2*x0+2*TC+1])
+
+template <typename T>
+__global__ __launch_bounds__(256) void up2x_fwd_tiled_kernel(const T* __restrict__ deep, const float* __restrict__ deep_ss,
+                                                              T* __restrict__ out, int B, int h, int w, int Cd, int H, int W,
+                                                              int Ct, int c_off, int tilesY, int tilesX) {
+  // out: [B][H][W][Ct], the upsampled channels at [c_off, c_off + Cd) (Ct = Cd, c_off = 0 without a skip half)
+  constexpr int N = Vec16<T>::N;
+  constexpr int VPC = UP_CC / N;                      // channel vectors per pixel of the chunk
+  constexpr int PITCH = UP_CC + 8;                    // floats per staged source pixel (+32 B: neighbours start 8 banks apart)
+  __shared__ __attribute__((aligned(16))) float s_src[UPF_SR * UPF_SC * PITCH];
+  __shared__ int s_y0[UPF_TR], s_y1[UPF_TR], s_x0[UPF_TC], s_x1[UPF_TC];
+  __shared__ float s_ly[UPF_TR][2], s_lx[UPF_TC][2];
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int chunk = t % (Cd / UP_CC); t /= (Cd / UP_CC);
+  const int tx_id = t % tilesX; t /= tilesX;
+  const int ty_id = t % tilesY;
+  const int b = t / tilesY;
+  const int yt = ty_id * UPF_TR, xt = tx_id * UPF_TC;
+  const int py = (H - 2 * h) / 2, px = (W - 2 * w) / 2;
+  const int c_base = chunk * UP_CC;
+  // first source row / column any valid output of the tile reads
+  const int uy_first = max(yt - py, 0), ux_first = max(xt - px, 0);
+  int ylo, xlo, dummy_i; float dummy_f0, dummy_f1;
+  bilinear_src(min(uy_first, 2 * h - 1), h, 2 * h, ylo, dummy_i, dummy_f0, dummy_f1);
+  bilinear_src(min(ux_first, 2 * w - 1), w, 2 * w, xlo, dummy_i, dummy_f0, dummy_f1);
+  if (tid < UPF_TR) {
+    const int uy = yt + tid - py;
+    int y0 = 0, y1 = 0; float l0 = 0.f, l1 = 0.f;
+    const bool in = uy >= 0 && uy < 2 * h && yt + tid < H;
+    if (in) bilinear_src(uy, h, 2 * h, y0, y1, l0, l1);
+    s_y0[tid] = in ? y0 - ylo : -1; s_y1[tid] = y1 - ylo; s_ly[tid][0] = l0; s_ly[tid][1] = l1;
+  } else if (tid >= 64 && tid < 64 + UPF_TC) {
+    const int i = tid - 64;
+    const int ux = xt + i - px;
+    int x0 = 0, x1 = 0; float l0 = 0.f, l1 = 0.f;
+    const bool in = ux >= 0 && ux < 2 * w && xt + i < W;
+    if (in) bilinear_src(ux, w, 2 * w, x0, x1, l0, l1);
+    s_x0[i] = in ? x0 - xlo : -1; s_x1[i] = x1 - xlo; s_lx[i][0] = l0; s_lx[i][1] = l1;
+  }
+  // stage the source pixels: lazy BatchNorm+ReLU and the rounding to the storage type happen once per element
+  {
+    const int cv = tid % VPC;
+    const LazySS<N> lz(deep_ss, Cd, c_base + cv * N);
+#pragma unroll
+    for (int i = tid; i < UPF_SR * UPF_SC * VPC; i += 256) {
+      const int sp = i / VPC;
+      const int sy = ylo + sp / UPF_SC, sx = xlo + sp % UPF_SC;
+      float v[N];
+      if (sy < h && sx < w) {
+        Vec16<T>::load(deep + ((((int64_t)b * h + sy) * w + sx) * (int64_t)Cd) + c_base + cv * N, v);
+        if (deep_ss) { lz.apply(v); round_store_type<T, N>(v); }
+      } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = 0.f;
+      }
+      float* d = s_src + sp * PITCH + cv * N;
+#pragma unroll
+      for (int k = 0; k < N; k += 4) *reinterpret_cast<float4*>(d + k) = make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < UPF_TR * UPF_TC * VPC; i += 256) {
+    const int cv = i % VPC, p = i / VPC;
+    const int r = p / UPF_TC, c = p % UPF_TC;
+    const int y = yt + r, x = xt + c;
+    if (y >= H || x >= W) continue;
+    float o[N];
+    const int y0 = s_y0[r], x0 = s_x0[c];
+    if (y0 < 0 || x0 < 0) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) o[k] = 0.f;
+    } else {
+      const int y1 = s_y1[r], x1 = s_x1[c];
+      const float ly0 = s_ly[r][0], ly1 = s_ly[r][1], lx0 = s_lx[c][0], lx1 = s_lx[c][1];
+      const float* p00 = s_src + (y0 * UPF_SC + x0) * PITCH + cv * N;
+      const float* p01 = s_src + (y0 * UPF_SC + x1) * PITCH + cv * N;
+      const float* p10 = s_src + (y1 * UPF_SC + x0) * PITCH + cv * N;
+      const float* p11 = s_src + (y1 * UPF_SC + x1) * PITCH + cv * N;
+#pragma unroll
+      for (int k = 0; k < N; k += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(p00 + k), bq = *reinterpret_cast<const float4*>(p01 + k);
+        const float4 cq = *reinterpret_cast<const float4*>(p10 + k), dq = *reinterpret_cast<const float4*>(p11 + k);
+        o[k] = ly0 * (lx0 * a.x + lx1 * bq.x) + ly1 * (lx0 * cq.x + lx1 * dq.x);
+        o[k + 1] = ly0 * (lx0 * a.y + lx1 * bq.y) + ly1 * (lx0 * cq.y + lx1 * dq.y);
+        o[k + 2] = ly0 * (lx0 * a.z + lx1 * bq.z) + ly1 * (lx0 * cq.z + lx1 * dq.z);
+        o[k + 3] = ly0 * (lx0 * a.w + lx1 * bq.w) + ly1 * (lx0 * cq.w + lx1 * dq.w);
+      }
+    }
+    Vec16<T>::store(out + ((((int64_t)b * H + y) * W + x) * (int64_t)Ct) + c_off + c_base + cv * N, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void up2x_bwd_tiled_kernel(const T* __restrict__ dout, T* __restrict__ ddeep, int B, int h, int w,
+                                                              int Cd, int H, int W, int Ct, int c_off, int tilesY, int tilesX) {
+  constexpr int N = Vec16<T>::N;
+  constexpr int VPC = UP_CC / N;
+  constexpr int PITCH = UP_CC + 8;
+  __shared__ __attribute__((aligned(16))) float s_v[UPB_TR * UPB_HC * PITCH];       // vertical sums, [yi][hi-res column]
+  __shared__ float s_wy[UPB_TR][6], s_wx[UPB_TC][6];
+  __shared__ int s_ys[UPB_TR][6], s_ny[UPB_TR];
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int chunk = t % (Cd / UP_CC); t /= (Cd / UP_CC);
+  const int tx_id = t % tilesX; t /= tilesX;
+  const int ty_id = t % tilesY;
+  const int b = t / tilesY;
+  const int y_t = ty_id * UPB_TR, x_t = tx_id * UPB_TC;
+  const int py = (H - 2 * h) / 2, px = (W - 2 * w) / 2;
+  const int c_base = chunk * UP_CC;
+  const int ux_base = 2 * x_t - 2;                     // hi-res column of s_v[.][0]
+  // weight tables: candidate t of source index i is hi-res index 2*i-2+t (the candidate set of upcat_bwd_kernel)
+  if (tid < UPB_TR) {
+    // the (at most 6, normally 4) hi-res rows with weight for source row yi, compacted to the front in ascending order
+    const int r = tid, yi = y_t + r;
+    int n = 0;
+    for (int tt = 0; tt < 6; ++tt) {
+      const int uy = 2 * yi - 2 + tt;
+      float wv = 0.f; int ys = -1;
+      if (yi < h && uy >= 0 && uy <= 2 * h - 1) {
+        int y0, y1; float l0, l1;
+        bilinear_src(uy, h, 2 * h, y0, y1, l0, l1);
+        wv = (y0 == yi ? l0 : 0.f) + (y1 == yi ? l1 : 0.f);
+        const int y = uy + py;
+        if (wv != 0.f && y >= 0 && y < H) ys = y;
+      }
+      if (ys >= 0) { s_wy[r][n] = wv; s_ys[r][n] = ys; ++n; }
+    }
+    s_ny[r] = n;
+    for (; n < 6; ++n) { s_wy[r][n] = 0.f; s_ys[r][n] = 0; }
+  } else if (tid >= 64 && tid < 64 + UPB_TC * 6) {
+    const int i = tid - 64;
+    const int c = i / 6, u = i % 6;
+    const int xi = x_t + c, ux = 2 * xi - 2 + u;
+    float wv = 0.f;
+    if (xi < w && ux >= 0 && ux <= 2 * w - 1) {
+      int x0, x1; float l0, l1;
+      bilinear_src(ux, w, 2 * w, x0, x1, l0, l1);
+      wv = (x0 == xi ? l0 : 0.f) + (x1 == xi ? l1 : 0.f);
+      const int x = ux + px;
+      if (x < 0 || x >= W) wv = 0.f;
+    }
+    s_wx[c][u] = wv;
+  }
+  __syncthreads();
+  // vertical pass: s_v[r][j] = sum_t wy[r][t] * dout[ys[r][t]][ux_base + j + px]
+  for (int i = tid; i < UPB_TR * UPB_HC * VPC; i += 256) {
+    const int cv = i % VPC, q = i / VPC;
+    const int r = q / UPB_HC, j = q % UPB_HC;
+    const int x = ux_base + j + px;
+    float acc[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] = 0.f;
+    if (x >= 0 && x < W && ux_base + j >= 0 && ux_base + j <= 2 * w - 1) {
+      // all six candidate rows are fetched unconditionally (a row without weight reads row 0 and counts for nothing):
+      // the loads issue back to back instead of each waiting behind a branch
+      // the first four table entries are fetched unconditionally (an entry without weight reads row 0 and counts for
+      // nothing): the loads issue back to back instead of each waiting behind a branch.  A fifth / sixth row only has
+      // weight where float rounding of the source index puts one (weights ~1e-7).
+      uint4 raw[4];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+        raw[tt] = *reinterpret_cast<const uint4*>(dout + ((((int64_t)b * H + s_ys[r][tt]) * W + x) * (int64_t)Ct) + c_off + c_base + cv * N);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const float wv = s_wy[r][tt];
+        float g[N];
+        Vec16<T>::load(reinterpret_cast<const T*>(&raw[tt]), g);
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] += wv * g[k];
+      }
+      for (int tt = 4; tt < s_ny[r]; ++tt) {
+        const float wv = s_wy[r][tt];
+        float g[N];
+        Vec16<T>::load(dout + ((((int64_t)b * H + s_ys[r][tt]) * W + x) * (int64_t)Ct) + c_off + c_base + cv * N, g);
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] += wv * g[k];
+      }
+    }
+    float* d = s_v + q * PITCH + cv * N;
+#pragma unroll
+    for (int k = 0; k < N; k += 4) *reinterpret_cast<float4*>(d + k) = make_float4(acc[k], acc[k + 1], acc[k + 2], acc[k + 3]);
+  }
+  __syncthreads();
+  // horizontal pass
+  for (int i = tid; i < UPB_TR * UPB_TC * VPC; i += 256) {
+    const int cv = i % VPC, q = i / VPC;
+    const int r = q / UPB_TC, c = q % UPB_TC;
+    const int yi = y_t + r, xi = x_t + c;
+    if (yi >= h || xi >= w) continue;
+    float acc[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const float wv = s_wx[c][u];
+      if (wv == 0.f) continue;
+      const float* sp = s_v + (r * UPB_HC + 2 * c + u) * PITCH + cv * N;      // hi-res column 2*xi-2+u = ux_base + 2*c + u
+#pragma unroll
+      for (int k = 0; k < N; k += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(sp + k);
+        acc[k] += wv * a.x; acc[k + 1] += wv * a.y; acc[k + 2] += wv * a.z; acc[k + 3] += wv * a.w;
+      }
+    }
+    Vec16<T>::store(ddeep + ((((int64_t)b * h + yi) * w + xi) * (int64_t)Cd) + c_base + cv * N, acc);
   }
 }
 
@@ -1608,9 +1841,19 @@ extern "C" int im2im_upsample2x_concat_fwd(const void* deep, const float* deep_s
   IM2IM_REQUIRE((Cs > 0) == (skip != nullptr));
   return for_dtype(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
+    const bool tiled = Cd % UP_CC == 0 && Cs % Vec16<T>::N == 0;
+    if (tiled) {
+      const int tilesY = (int)cdiv(H, UPF_TR), tilesX = (int)cdiv(W, UPF_TC);
+      const int64_t nblk = (int64_t)B * tilesY * tilesX * (Cd / UP_CC);
+      IM2IM_REQUIRE(nblk < (1ll << 31));
+      hipLaunchKernelGGL(up2x_fwd_tiled_kernel<T>, dim3((unsigned)nblk), dim3(256), 0, stream, (const T*)deep, deep_scale_shift,
+                         (T*)out, B, h, w, Cd, H, W, Cs + Cd, Cs, tilesY, tilesX);
+      if (int rc = check_launch("up2x_fwd_tiled_kernel")) return rc;
+      if (Cs == 0) return IM2IM_OK;
+    }
     const RowVec rvd = make_rowvec(Cd / Vec16<T>::N), rvs = Cs > 0 ? make_rowvec(Cs / Vec16<T>::N) : rvd;
-    dim3 grid = row_grid(W * std::max(rvs.vpr, rvd.vpr), B * H);
-    grid.z = Cs > 0 ? 2 : 1;
+    dim3 grid = row_grid(W * (tiled ? rvs.vpr : std::max(rvs.vpr, rvd.vpr)), B * H);
+    grid.z = (Cs > 0 && !tiled) ? 2 : 1;            // z == 0: the skip half; z == 1: the upsampled half unless the tiled kernel wrote it
     hipLaunchKernelGGL(upcat_fwd_kernel<T>, grid, dim3(256), 0, stream, (const T*)deep, deep_scale_shift, (const T*)skip, skip_scale_shift, (T*)out, B, h, w, Cd, H, W, Cs, rvs, rvd);
     return check_launch("upcat_fwd_kernel");
   });
@@ -1624,8 +1867,18 @@ extern "C" int im2im_upsample2x_concat_bwd(const void* dout, void* ddeep, void* 
   IM2IM_REQUIRE((Cs > 0) == (dskip != nullptr));
   return for_dtype(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
+    const bool tiled = Cd % UP_CC == 0 && Cs % Vec16<T>::N == 0;
+    if (tiled) {
+      const int tilesY = (int)cdiv(h, UPB_TR), tilesX = (int)cdiv(w, UPB_TC);
+      const int64_t nblk = (int64_t)B * tilesY * tilesX * (Cd / UP_CC);
+      IM2IM_REQUIRE(nblk < (1ll << 31));
+      hipLaunchKernelGGL(up2x_bwd_tiled_kernel<T>, dim3((unsigned)nblk), dim3(256), 0, stream, (const T*)dout, (T*)ddeep, B, h, w,
+                         Cd, H, W, Cs + Cd, Cs, tilesY, tilesX);
+      if (int rc = check_launch("up2x_bwd_tiled_kernel")) return rc;
+      if (Cs == 0) return IM2IM_OK;
+    }
     const RowVec rvd = make_rowvec(Cd / Vec16<T>::N), rvs = Cs > 0 ? make_rowvec(Cs / Vec16<T>::N) : rvd;
-    hipLaunchKernelGGL(upcat_bwd_kernel<T>, row_grid(Cs > 0 ? W * rvs.vpr : w * rvd.vpr, (Cs > 0 ? B * H : 0) + B * h), dim3(256), 0, stream, (const T*)dout, (T*)ddeep, (T*)dskip, B, h, w, Cd, H, W, Cs, rvs, rvd);
+    hipLaunchKernelGGL(upcat_bwd_kernel<T>, row_grid(Cs > 0 ? W * rvs.vpr : w * rvd.vpr, (Cs > 0 ? B * H : 0) + (tiled ? 0 : B * h)), dim3(256), 0, stream, (const T*)dout, (T*)ddeep, (T*)dskip, B, h, w, Cd, H, W, Cs, rvs, rvd, tiled ? 0 : 1);
     return check_launch("upcat_bwd_kernel");
   });
 }
