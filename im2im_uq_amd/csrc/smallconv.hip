@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void smallconv_s2l_kernel(S2LArgs a) {
       for (int p = 0; p < PASSES; ++p) {
         const float xv = s_in[0][qy + p * (PPP / TS) + tap / 3][qx + tap % 3];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) accv[p][k] += xv * wreg[tap][k];
+        for (int k = 0; k < 8; ++k) accv[p][k] = __builtin_fmaf(xv, wreg[tap][k], accv[p][k]);
       }
   } else {
     for (int s = 0; s < a.CS; ++s) {
@@ -110,8 +110,10 @@ __global__ __launch_bounds__(256) void smallconv_s2l_kernel(S2LArgs a) {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
           const float xv = s_in[s][qy + p * (PPP / TS) + tap / 3][qx + tap % 3];
-          accv[p][0] += xv * w0.x; accv[p][1] += xv * w0.y; accv[p][2] += xv * w0.z; accv[p][3] += xv * w0.w;
-          accv[p][4] += xv * w1.x; accv[p][5] += xv * w1.y; accv[p][6] += xv * w1.z; accv[p][7] += xv * w1.w;
+          accv[p][0] = __builtin_fmaf(xv, w0.x, accv[p][0]); accv[p][1] = __builtin_fmaf(xv, w0.y, accv[p][1]);
+          accv[p][2] = __builtin_fmaf(xv, w0.z, accv[p][2]); accv[p][3] = __builtin_fmaf(xv, w0.w, accv[p][3]);
+          accv[p][4] = __builtin_fmaf(xv, w1.x, accv[p][4]); accv[p][5] = __builtin_fmaf(xv, w1.y, accv[p][5]);
+          accv[p][6] = __builtin_fmaf(xv, w1.z, accv[p][6]); accv[p][7] = __builtin_fmaf(xv, w1.w, accv[p][7]);
         }
       }
     }
@@ -656,6 +658,131 @@ __global__ __launch_bounds__(256) void smallconv_wgrad_kernel(SWArgs a) {
   }
 }
 
+// smallconv_wgrad_kernel with VL wide-side channels per thread (the first conv of the network, 1 or 2 input planes): a
+// thread owns VL consecutive channels of one tile row, so the pixel's VL values arrive in ONE LDS read and the three new
+// window values of the small side are shared by VL * 9 fused multiply-adds (the one-channel form issues 4 LDS reads and
+// 19 VALU operations per 9 MACs: 0.48 ms for a 1 GB read).  Lanes sharing a channel group sit 16 apart in a wave: their
+// sums meet by xor-shuffles, the four waves through LDS, in a fixed order.  Partial rows as smallconv_wgrad_kernel.
+template <typename T, int CL, int CSB, int VL>
+__global__ __launch_bounds__(256) void smallconv_wgrad_vec_kernel(SWArgs a) {
+  constexpr int N = Vec16<T>::N;
+  constexpr int LG = CL / VL;                       // lanes per tile row
+  constexpr int G = 256 / LG;                       // tile rows in flight
+  constexpr int RPG = TS / G;
+  static_assert(LG == 16 && G == 16 && RPG == 1, "one tile row per 16-lane group");
+  __shared__ __attribute__((aligned(16))) T s_L[TS * TS][CL];
+  __shared__ float s_S[CSB][HS][HS + 1];
+  __shared__ float s_red[4][CSB * 9 + 1][CL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = tid % LG, ty = tid / LG;           // channel group, tile row
+  float acc[CSB][9][VL];
+  float bsum[CSB];
+#pragma unroll
+  for (int s = 0; s < CSB; ++s) {
+    bsum[s] = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+      for (int k = 0; k < VL; ++k) acc[s][tp][k] = 0.f;
+  }
+  const int ntiles = a.B * a.tilesY * a.tilesX;
+  constexpr int PPR = CL / N;
+  constexpr int L_ROUNDS = TS * TS * PPR / 256;
+  uint4 rl[L_ROUNDS];
+  auto gload_L = [&](int tile) {
+    int t = tile;
+    const int tx_id = t % a.tilesX; t /= a.tilesX;
+    const int ty_id = t % a.tilesY;
+    const int b = t / a.tilesY;
+    const T* Lb = reinterpret_cast<const T*>(a.L) + (size_t)b * a.H * a.W * CL;
+#pragma unroll
+    for (int i = 0; i < L_ROUNDS; ++i) {
+      const int p = i * 256 + tid;
+      const int px = p / PPR, part = p % PPR;
+      const int yy = ty_id * TS + px / TS, xx = tx_id * TS + px % TS;
+      rl[i] = make_uint4(0, 0, 0, 0);
+      if (yy < a.H && xx < a.W) rl[i] = *reinterpret_cast<const uint4*>(Lb + ((size_t)yy * a.W + xx) * CL + part * N);
+    }
+  };
+  if ((int)blockIdx.x < ntiles) gload_L(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int t = tile;
+    const int tx_id = t % a.tilesX; t /= a.tilesX;
+    const int ty_id = t % a.tilesY;
+    const int b = t / a.tilesY;
+    const int y0 = ty_id * TS, x0 = tx_id * TS;
+    const float* Sb = a.S + (size_t)b * a.CS * a.H * a.W;
+    __syncthreads();                                // the previous tile's readers are done
+    for (int i = tid; i < a.CS * HS * HS; i += 256) {
+      const int sidx = i / (HS * HS), r = i % (HS * HS);
+      const int hy = r / HS, hx = r % HS;
+      const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+      s_S[sidx][hy][hx] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? Sb[((size_t)sidx * a.H + yy) * a.W + xx] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < L_ROUNDS; ++i) {
+      const int p = i * 256 + tid;
+      *reinterpret_cast<uint4*>(&s_L[p / PPR][(p % PPR) * N]) = rl[i];
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) gload_L(tile + (int)gridDim.x);   // the next tile's wide side is in flight during the sums
+#pragma unroll
+    for (int s = 0; s < CSB; ++s) {
+      if (s < a.CS) {
+        float w[3][3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) { w[dy][1] = s_S[s][ty + dy][0]; w[dy][2] = s_S[s][ty + dy][1]; }
+#pragma unroll
+        for (int tx = 0; tx < TS; ++tx) {
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) { w[dy][0] = w[dy][1]; w[dy][1] = w[dy][2]; w[dy][2] = s_S[s][ty + dy][tx + 2]; }
+          float lv[VL];
+#pragma unroll
+          for (int k = 0; k < VL; ++k) lv[k] = to_float(s_L[ty * TS + tx][lq * VL + k]);
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+            for (int k = 0; k < VL; ++k) acc[s][tp][k] = __builtin_fmaf(lv[k], w[tp / 3][tp % 3], acc[s][tp][k]);
+          bsum[s] += w[1][1];
+        }
+      }
+    }
+  }
+  // the four tile rows of a wave (lanes lq, lq+16, lq+32, lq+48), then the four waves
+#pragma unroll
+  for (int s = 0; s < CSB; ++s) {
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) {
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int k = 0; k < VL; ++k) acc[s][tp][k] += __shfl_xor(acc[s][tp][k], off, 64);
+      bsum[s] += __shfl_xor(bsum[s], off, 64);
+    }
+  }
+  __syncthreads();
+  if (lane < LG) {
+#pragma unroll
+    for (int s = 0; s < CSB; ++s)
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int k = 0; k < VL; ++k) s_red[wave][s * 9 + tp][lq * VL + k] = acc[s][tp][k];
+    if (lane == 0) {
+#pragma unroll
+      for (int s = 0; s < CSB; ++s) s_red[wave][CSB * 9][s] = bsum[s];
+    }
+  }
+  __syncthreads();
+  const int K = a.CS * 9 * CL + a.CS;
+  float* out = a.partial + (size_t)blockIdx.x * K;
+  for (int i = tid; i < a.CS * 9 * CL; i += 256) {
+    const int row = i / CL, ll = i % CL;                       // row = s*9 + tap
+    out[i] = ((s_red[0][row][ll] + s_red[1][row][ll]) + s_red[2][row][ll]) + s_red[3][row][ll];
+  }
+  if (tid < a.CS) out[(size_t)a.CS * 9 * CL + tid] = ((s_red[0][CSB * 9][tid] + s_red[1][CSB * 9][tid]) + s_red[2][CSB * 9][tid]) + s_red[3][CSB * 9][tid];
+}
+
 // MFMA form of the weight gradients above:  out[s][tap][l] = sum_px L[px][l] * S[s][px + off(tap)]  (+ sum_px S[s][px]).
 // Per tap a GEMM with M = the wide side's channels l, N = the 8 plane slots of the small side, K = pixels.  Both operands
 // live pixel-major in LDS ([px][channels]) but the matrix cores want k (= pixel) contiguous per lane: bf16 fragments are
@@ -943,6 +1070,8 @@ extern "C" int im2im_smallconv_wgrad(const float* S, const void* L, float* dw, f
       }
       hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, stream, a);
     }
+    else if (CS == 1 && !(valu_mask() & 8)) hipLaunchKernelGGL((smallconv_wgrad_vec_kernel<T, CLv, 1, CLv / 16>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
+    else if (CS == 2 && !(valu_mask() & 8)) hipLaunchKernelGGL((smallconv_wgrad_vec_kernel<T, CLv, 2, CLv / 16>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
     else if (CS == 1) hipLaunchKernelGGL((smallconv_wgrad_kernel<T, CLv, 1>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
     else if (CS == 2) hipLaunchKernelGGL((smallconv_wgrad_kernel<T, CLv, 2>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
     else if (CS <= 4) hipLaunchKernelGGL((smallconv_wgrad_kernel<T, CLv, 4>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
