@@ -143,6 +143,11 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict_
 // backward pass 1: per-block partial sums of g = da*[z*scale+shift > 0] and g*xhat.  partial[blk][2][C]
 // A thread keeps one channel vector (256 % (C/N) == 0) and strides rows; per-thread sums are combined through
 // LDS in a fixed order, so the result is deterministic.
+#ifndef IM2IM_STREAM_U
+#define IM2IM_STREAM_U 4
+#endif
+constexpr int STREAM_U = IM2IM_STREAM_U;      // vector loads a thread of the streaming BatchNorm-backward kernels keeps in flight (per operand)
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __restrict__ da, const T* __restrict__ z,
                                                                   const float* __restrict__ scale_shift,
@@ -168,17 +173,30 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
     s1[k] = 0.f; s2[k] = 0.f;
   }
   if (threadIdx.x < (256 / vpr) * vpr) {
-    for (int64_t i = v0 + threadIdx.x; i < v1; i += (256 / vpr) * vpr) {
+    auto one = [&](const uint4& rg, const uint4& rz) {
       float g[N], zz[N];
-      Vec16<T>::load(da + i * N, g);
-      Vec16<T>::load(z + i * N, zz);
+      Vec16<T>::load(reinterpret_cast<const T*>(&rg), g);
+      Vec16<T>::load(reinterpret_cast<const T*>(&rz), zz);
 #pragma unroll
       for (int k = 0; k < N; ++k) {
         const float gg = (zz[k] * sc[k] + sh[k] > 0.f) ? g[k] : 0.f;
         s1[k] += gg;
         s2[k] += gg * ((zz[k] - mu[k]) * is[k]);
       }
+    };
+    const int64_t stride = (256 / vpr) * vpr;
+    int64_t i = v0 + threadIdx.x;
+    for (; i + (STREAM_U - 1) * stride < v1; i += STREAM_U * stride) {      // several pairs in flight, summed in the same order
+      uint4 rg[STREAM_U], rz[STREAM_U];
+#pragma unroll
+      for (int u = 0; u < STREAM_U; ++u) {
+        rg[u] = *reinterpret_cast<const uint4*>(da + (i + u * stride) * N);
+        rz[u] = *reinterpret_cast<const uint4*>(z + (i + u * stride) * N);
+      }
+#pragma unroll
+      for (int u = 0; u < STREAM_U; ++u) one(rg[u], rz[u]);
     }
+    for (; i < v1; i += stride) one(*reinterpret_cast<const uint4*>(da + i * N), *reinterpret_cast<const uint4*>(z + i * N));
   }
 #pragma unroll
   for (int k = 0; k < N; ++k) { s_part[threadIdx.x][k] = s1[k]; s_part[threadIdx.x][N + k] = s2[k]; }
@@ -230,11 +248,10 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restr
     }
   };
   load_coef();
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-    if (!fixed) { c0 = (int)(i % vpr) * N; load_coef(); }
+  auto one = [&](const uint4& rg, const uint4& rz, int64_t i) {
     float g[N], zz[N], o[N];
-    Vec16<T>::load(da + i * N, g);
-    Vec16<T>::load(z + i * N, zz);
+    Vec16<T>::load(reinterpret_cast<const T*>(&rg), g);
+    Vec16<T>::load(reinterpret_cast<const T*>(&rz), zz);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       const float gg = (zz[k] * sc[k] + sh[k] > 0.f) ? g[k] : 0.f;
@@ -242,6 +259,27 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restr
       o[k] = sc[k] * (gg - k1[k] - xhat * k2[k]);
     }
     Vec16<T>::store(dz + i * N, o);
+  };
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (fixed) {
+    // STREAM_U vector pairs in flight per thread: beside the weight-gradient kernels of the second stream this kernel gets
+    // only a few wave slots per CU, and what it then moves is (bytes in flight per wave) / latency -- one pair per
+    // iteration ran 2.3x slower there than alone, although alone (full occupancy) it was at the HBM rate either way
+    for (; i + (STREAM_U - 1) * stride < nvec; i += STREAM_U * stride) {
+      uint4 rg[STREAM_U], rz[STREAM_U];
+#pragma unroll
+      for (int u = 0; u < STREAM_U; ++u) {
+        rg[u] = *reinterpret_cast<const uint4*>(da + (i + u * stride) * N);
+        rz[u] = *reinterpret_cast<const uint4*>(z + (i + u * stride) * N);
+      }
+#pragma unroll
+      for (int u = 0; u < STREAM_U; ++u) one(rg[u], rz[u], i + u * stride);
+    }
+  }
+  for (; i < nvec; i += stride) {
+    if (!fixed) { c0 = (int)(i % vpr) * N; load_coef(); }
+    one(*reinterpret_cast<const uint4*>(da + i * N), *reinterpret_cast<const uint4*>(z + i * N), i);
   }
 }
 
