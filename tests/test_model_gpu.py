@@ -613,6 +613,47 @@ def test_backward_pipelined_over_batch_halves_is_bit_identical(dt, batch, monkey
             assert torch.equal(runs[0][i][n], runs[1][i][n]), (i, n)
 
 
+def test_eval_weight_cache_follows_parameter_updates():
+    """eval-mode forwards reuse the packed weights and folded BatchNorm coefficients of a conv until one of its tensors
+    changes (nn_ops._EVAL_CACHE, keyed by storage + version counter).  Every way the weights change must invalidate it:
+    an optimizer step and BatchNorm's running statistics (written by HIP kernels through raw pointers -> nn_ops.touched),
+    an in-place torch op, load_state_dict."""
+    from oracle import model as om
+    from im2im_uq_amd import nn_ops
+    x, y = om.det_images(2, 1, 48, 48, salt=31)
+    xd, yd = x.to(DEV), y.to(DEV)
+    model = build(1, "bf16")
+
+    def eval_out():
+        model.eval()
+        with torch.no_grad():
+            return model(xd).clone()
+
+    def fresh():
+        nn_ops._EVAL_CACHE.clear()
+        return eval_out()
+
+    y0 = eval_out()
+    assert len(nn_ops._EVAL_CACHE) == 18 and torch.equal(eval_out(), y0)          # second forward: all hits, same bits
+    model.train()
+    opt = nn_ops.FusedAdam(model.parameters(), lr=1e-2)
+    model.loss_fn(model(xd), yd).backward()
+    opt.step()
+    y1 = eval_out()
+    assert not torch.equal(y1, y0) and torch.equal(y1, fresh())                   # Adam + running statistics seen
+    with torch.no_grad():
+        model.baseModel.down2.maxpool_conv[1].double_conv[0].weight.mul_(0.5)
+    y2 = eval_out()
+    assert not torch.equal(y2, y1) and torch.equal(y2, fresh())
+    model.load_state_dict(om.det_state(1, 1), strict=False)
+    y3 = eval_out()
+    assert torch.equal(y3, y0) and torch.equal(y3, fresh())
+    with torch.no_grad():
+        model.baseModel.up3.conv.double_conv[4].running_var.add_(0.25)          # a BatchNorm buffer alone
+    y4 = eval_out()
+    assert not torch.equal(y4, y3) and torch.equal(y4, fresh())
+
+
 def _g14_block(name):
     from im2im_uq_amd.core.models.trunks import unet_parts as up
     return {"doubleconv": lambda: up.DoubleConv(2, 64, 32), "down": lambda: up.Down(32, 64),
