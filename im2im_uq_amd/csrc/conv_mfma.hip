@@ -840,29 +840,49 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
 // and the many-split / few-output case (the 1x1 OutConv) does not serialise on one thread per output.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int Co, int Ci,
                                                             int taps, float* __restrict__ dw) {
-  __shared__ float s_acc[4][64];
-  const size_t total = (size_t)Co * taps * Ci;
+  // thread (ol, sl): FOUR consecutive outputs (one 16-byte load per split slab), the slabs sl, sl+4, ... in ascending order;
+  // the four slab groups are then added as (0+1)+(2+3) -- the order of the one-float-per-thread version it replaces, so the
+  // bits are the same; up to four slabs' loads are in flight per thread.
+  __shared__ float4 s_acc[4][64];
+  const size_t total = (size_t)Co * taps * Ci;            // a multiple of 4 (Ci % 32 == 0)
+  const size_t total4 = total / 4;
+  const float4* __restrict__ p4 = reinterpret_cast<const float4*>(partial);
   const int ol = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
+  for (size_t base = (size_t)blockIdx.x * 64; base < total4; base += (size_t)gridDim.x * 64) {
     const size_t i = base + ol;
-    float s = 0.f;
-    if (i < total)
-      for (int k = sl; k < nsplit; k += 4) s += partial[(size_t)k * total + i];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < total4) {
+      int k = sl;
+      for (; k + 12 < nsplit; k += 16) {
+        const float4 a = p4[(size_t)k * total4 + i], b = p4[(size_t)(k + 4) * total4 + i];
+        const float4 c = p4[(size_t)(k + 8) * total4 + i], d = p4[(size_t)(k + 12) * total4 + i];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+        s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+        s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+      }
+      for (; k < nsplit; k += 4) {
+        const float4 a = p4[(size_t)k * total4 + i];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      }
+    }
     s_acc[sl][ol] = s;
     __syncthreads();
-    if (sl == 0 && i < total) {
-      const float v = (s_acc[0][ol] + s_acc[1][ol]) + (s_acc[2][ol] + s_acc[3][ol]);
-      const int ci = (int)(i % Ci);
-      const size_t r = i / Ci;
+    if (sl == 0 && i < total4) {
+      const float4 a = s_acc[0][ol], b = s_acc[1][ol], c = s_acc[2][ol], d = s_acc[3][ol];
+      const float v[4] = {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w)};
+      const size_t e = i * 4;                               // four consecutive ci of one (co, tap): Ci % 4 == 0
+      const int ci = (int)(e % Ci);
+      const size_t r = e / Ci;
       const int tp = (int)(r % taps);
       const size_t co = r / taps;
-      dw[(co * Ci + ci) * taps + tp] = v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dw[(co * Ci + ci + j) * taps + tp] = v[j];
     }
     __syncthreads();
   }
 }
 
-// w[Co][Ci][taps] fp32 -> wf[Co][taps][Ci] T and (optional) wd[Ci][taps flipped][Co] T
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, int Co, int Ci, int taps,
                                                            T* __restrict__ wf, T* __restrict__ wd) {
@@ -1070,7 +1090,7 @@ int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float
     if (int rc = check_launch("conv_wgrad_kernel")) return rc;
   }
   const size_t total = (size_t)Co * TAPS * Ci;
-  int blocks = (int)std::min<size_t>(cdiv(total, 64), 8192);
+  int blocks = (int)std::min<size_t>(cdiv(total / 4, 64), 8192);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, (int)nsplit, Co, Ci, TAPS, dw);
   return check_launch("wgrad_reduce_kernel");
 }
