@@ -294,17 +294,28 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
   __syncthreads();
   char* wbuf = smem + wave * WBYTES;
   float st_n[NT], st_m[NT], st_q[NT];
-  float cnt = 0.f;
+  // as conv_igemm_kernel: a tile inside the batch and the image needs no per-value validity test (wave-uniform fast path);
+  // an overhanging one keeps one validity bit per accumulator row
+  const bool tile_full = (b0 + TB <= a.B) && (y0 + TH <= a.H) && (x0 + TW <= a.W);
+  static_assert(MT * 16 <= 64, "one validity bit per accumulator row of the lane");
+  unsigned long long okmask = ~0ull;
+  float cnt = (float)(16 * MT);
   if constexpr (want_stats) {
+    if (!tile_full) {
+      okmask = 0ull;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = wm * WROWS + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
-        cnt += (bb < a.B && yy < a.H && xx < a.W) ? 1.f : 0.f;
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int m = wm * WROWS + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
+          if (bb < a.B && yy < a.H && xx < a.W) okmask |= 1ull << (mt * 16 + r);
+        }
+      cnt = (float)__popcll(okmask);
+    }
   }
+  auto convert_tile = [&](auto full_tag) {
+  constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = n0 + (wn * NT + nt) * 32 + l31;
@@ -327,12 +338,9 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
         const T tv = from_float<T>(v);
         *reinterpret_cast<T*>(wbuf + row * WP + (nt * 32 + l31) * 2) = tv;
         if constexpr (want_stats) {
-          const int m = wm * WROWS + row;
-          const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
-          if (bb < a.B && yy < a.H && xx < a.W) {
-            const float d = to_float(tv) - K;
-            s += d; sq += d * d;
-          }
+          float d = to_float(tv) - K;
+          if constexpr (!FULL) d = ((okmask >> (mt * 16 + r)) & 1ull) ? d : 0.f;
+          s += d; sq += d * d;
         }
       }
     }
@@ -341,6 +349,8 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
       st_n[nt] = cnt; st_m[nt] = K + s * inv; st_q[nt] = fmaxf(sq - s * s * inv, 0.f);
     }
   }
+  };
+  if (want_stats && tile_full) convert_tile(std::true_type{}); else convert_tile(std::false_type{});
 #pragma unroll
   for (int pass = 0; pass < PASSES; ++pass) {
     const int row = pass * ROWS_PER_PASS + lane / EPR;
