@@ -20,6 +20,9 @@
 #ifndef IM2IM_SETPRIO
 #define IM2IM_SETPRIO 0
 #endif
+#ifndef IM2IM_IGEMM_XCD_BANDS
+#define IM2IM_IGEMM_XCD_BANDS 1
+#endif
 #ifndef IM2IM_WGRAD_XCD
 #define IM2IM_WGRAD_XCD 1
 #endif
@@ -132,7 +135,18 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 || BN < 128) ? 2 : 1) void con
   const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5, l31 = lane & 31;
 
+#if IM2IM_IGEMM_XCD_BANDS
+  // workgroups go to the 8 XCDs round-robin in dispatch order: give every XCD a contiguous band of tiles, so that the halo
+  // pixels neighbouring tiles share are found in ITS L2 instead of being fetched by eight different ones
+  int tile_id = blockIdx.x;
+  {
+    const int band = (int)gridDim.x >> 3;
+    if (tile_id < band * 8) tile_id = (tile_id & 7) * band + (tile_id >> 3);
+  }
+  const int cob = blockIdx.y;
+#else
   const int tile_id = blockIdx.x, cob = blockIdx.y;
+#endif
   int mt_id = tile_id;
   const int tx_id = mt_id % a.tilesX; mt_id /= a.tilesX;
   const int ty_id = mt_id % a.tilesY;
