@@ -20,6 +20,9 @@
 #ifndef IM2IM_SETPRIO
 #define IM2IM_SETPRIO 0
 #endif
+#ifndef IM2IM_IGEMM_COB_INNER
+#define IM2IM_IGEMM_COB_INNER 1
+#endif
 #ifndef IM2IM_IGEMM_XCD_BANDS
 #define IM2IM_IGEMM_XCD_BANDS 1
 #endif
@@ -138,12 +141,32 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 || BN < 128) ? 2 : 1) void con
 #if IM2IM_IGEMM_XCD_BANDS
   // workgroups go to the 8 XCDs round-robin in dispatch order: give every XCD a contiguous band of tiles, so that the halo
   // pixels neighbouring tiles share are found in ITS L2 instead of being fetched by eight different ones
+#if IM2IM_IGEMM_COB_INNER
+  // 1-D grid over (tile, output-channel block): within an XCD's band the channel blocks of one tile run back to back, so
+  // the tile's input halo comes from HBM once and from that XCD's L2 for the other blocks
+  int tile_id, cob;
+  {
+    const int ncob = a.Co / BN;
+    const int lin = blockIdx.x, total = (int)gridDim.x;
+    const int band = (total >> 3) / ncob;                 // tiles per XCD band
+    if (lin < band * ncob * 8) {
+      const int xcd = lin & 7, j = lin >> 3;
+      tile_id = xcd * band + j / ncob;
+      cob = j % ncob;
+    } else {                                              // leftover tiles: plain order
+      const int r = lin - band * ncob * 8;
+      tile_id = band * 8 + r / ncob;
+      cob = r % ncob;
+    }
+  }
+#else
   int tile_id = blockIdx.x;
   {
     const int band = (int)gridDim.x >> 3;
     if (tile_id < band * 8) tile_id = (tile_id & 7) * band + (tile_id >> 3);
   }
   const int cob = blockIdx.y;
+#endif
 #else
   const int tile_id = blockIdx.x, cob = blockIdx.y;
 #endif
@@ -931,7 +954,11 @@ int launch_conv_epi(const ConvArgs& a_in, hipStream_t stream) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = smem;
   }
+#if IM2IM_IGEMM_XCD_BANDS && IM2IM_IGEMM_COB_INNER
+  dim3 grid((unsigned)((size_t)cdiv(a.B, TB) * a.tilesY * a.tilesX * (a.Co / BN)));
+#else
   dim3 grid((unsigned)((size_t)cdiv(a.B, TB) * a.tilesY * a.tilesX), (unsigned)(a.Co / BN));
+#endif
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, a);
   return check_launch("conv_igemm_kernel");
 }
