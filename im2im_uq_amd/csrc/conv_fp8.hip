@@ -95,7 +95,22 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5, l31 = lane & 31;
-  const int tile_id = blockIdx.x, cob = blockIdx.y;
+  // 1-D grid, tiles dealt to the 8 XCDs in contiguous bands with the channel blocks of a tile back to back (as conv_igemm_kernel)
+  int tile_id, cob;
+  {
+    const int ncob = a.Co / BN;
+    const int lin = blockIdx.x, total = (int)gridDim.x;
+    const int band = (total >> 3) / ncob;
+    if (lin < band * ncob * 8) {
+      const int xcd = lin & 7, j = lin >> 3;
+      tile_id = xcd * band + j / ncob;
+      cob = j % ncob;
+    } else {
+      const int r = lin - band * ncob * 8;
+      tile_id = band * 8 + r / ncob;
+      cob = r % ncob;
+    }
+  }
   int mt_id = tile_id;
   const int tx_id = mt_id % a.tilesX; mt_id /= a.tilesX;
   const int ty_id = mt_id % a.tilesY;
@@ -429,7 +444,7 @@ int launch_fp8(const Fp8ConvArgs& a_in, hipStream_t stream) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = smem;
   }
-  dim3 grid((unsigned)((size_t)cdiv(a.B, TB) * a.tilesY * a.tilesX), (unsigned)(a.Co / BN));
+  dim3 grid((unsigned)((size_t)cdiv(a.B, TB) * a.tilesY * a.tilesX * (a.Co / BN)));
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, a);
   return check_launch("conv_fp8_kernel");
 }
