@@ -131,7 +131,8 @@ def test_split_operand_conv_is_bit_identical_to_concatenated(case, dt):
 
 @pytest.mark.parametrize("dt", [F32, BF16])
 @pytest.mark.parametrize("case", [(2, 9, 7, 64, 19, 15), (1, 20, 20, 128, 40, 40), (2, 33, 17, 64, 67, 36), (1, 1, 1, 64, 2, 2),
-                                  (1, 2, 3, 64, 7, 9), (3, 5, 40, 192, 10, 80), (1, 6, 6, 32, 13, 12)])
+                                  (1, 2, 3, 64, 7, 9), (3, 5, 40, 192, 10, 80), (1, 6, 6, 32, 13, 12),
+                                  (4, 160, 160, 64, 320, 320), (2, 20, 20, 512, 40, 40)])     # the up4 / up1 shapes of the BASELINE network
 def test_upsample2x_alone_matches_concat_kernel_and_torch(dt, case):
     """im2im_upsample2x_concat_* with Cs = 0: bilinear x2 (align_corners) + zero pad without the skip copy.  Channel counts
     that are multiples of 64 take the tiled kernels (up2x_*_tiled_kernel): forward bit-identical to the row-walking kernel,
