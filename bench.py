@@ -357,7 +357,7 @@ def main():
         yc.copy_(torch.rand(M, 1, hw, hw, device=dev, generator=g))
     ds = TensorDataset(xc, yc)
     ds.im2im_local_shard = True
-    ccfg = dict(cfg, batch_size=min(conf["batch"], M))       # the reference forwards the calibration set in config batches (calibrate_model.py:118)
+    ccfg = dict(cfg, batch_size=min(max(conf["batch"], 64), M))   # the reference forwards the calibration set in config batches (calibrate_model.py:118)
 
     def calib_step():
         with contextlib.redirect_stdout(io.StringIO()):
