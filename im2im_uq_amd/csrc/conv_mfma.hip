@@ -628,11 +628,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
   const int t_begin = blockIdx.y * a.tiles_per_split;
   const int t_end = min(t_begin + a.tiles_per_split, a.ntiles);
-  // 1x1 (no halo, 8 pieces per thread): the next tile is fetched into registers while this one's MFMAs run, and only
-  // written to LDS after the barrier that ends them -- the single-buffered loop below spent its time waiting for loads
-  // (OutConv's weight gradient: 0.51 ms for 1.5 GB).  3x3 (fp32 mode only; bf16 uses conv_wgrad_pipe_kernel): 20 pieces
-  // per thread would not fit in registers, so it stages straight into LDS.
-  constexpr bool PREFETCH = (TAPS == 1);
+  // The next tile is fetched into registers while this one's MFMAs run, and only written to LDS after the barrier that ends
+  // them -- the single-buffered loop spent its time waiting for loads (OutConv's 1x1 weight gradient: 0.51 -> 0.35 ms for
+  // 1.5 GB; the fp32 3x3 weight gradients, one workgroup per CU with its 84 KB of LDS: 124 ms of the 305 ms fp32 step).
+  // fp32 3x3 holds 20 pieces = 80 registers: fine, a lone workgroup per CU may use all 512.  bf16 3x3 is
+  // conv_wgrad_pipe_kernel's job; this kernel is only its fallback there and stages straight into LDS.
+  constexpr bool PREFETCH = (TAPS == 1) || !IS_BF16;
   uint4 ra[PREFETCH ? A_ROUNDS : 1], rb[PREFETCH ? B_ROUNDS : 1];
   auto fetch = [&](int t, auto&& put_a, auto&& put_b) {
     int tt = t;
