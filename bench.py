@@ -312,6 +312,15 @@ def main():
                 roof["traffic"] = rec["traffic_bytes_per_launch"]
         except Exception:  # noqa: BLE001
             pass
+        try:
+            # counter-based utilisation from the committed PMC passes (busy MFMA cycles / elapsed SIMD cycles at the clock the chip
+            # actually ran): a second reading beside `frac`, which divides FLOP/s by the nominal-clock peak
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_mfma_busy.json")) as f:
+                busy = json.load(f)
+            if conf["dtype"] == "bf16" and args.config == "fastmri":
+                roof["mfma_busy_cycle_frac_pmc"] = {k: round(v["mfma_busy_frac"], 3) for k, v in busy.items() if isinstance(v, dict) and k.startswith("conv_igemm")}
+        except Exception:  # noqa: BLE001
+            pass
         roof_w = dict(agg(wg), kernel="conv_wgrad_kernel (+ its split-K reduce)")
 
     # ---------------------------------------------------------------- fp32 companion (parity mode, exact-fp32 MFMA)
