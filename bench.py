@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
 """Benchmark of the im2im-uq hot path on MI355X: quantile-regression UNet training + RCPS calibration.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched under torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 needs no launcher: without a rendezvous environment (RANK / WORLD_SIZE) the script re-executes itself under
+`torch.distributed.run` with N ranks, one per GPU over RCCL (im2im_uq_amd/launch.py) -- as the reference uses every GPU
+of the node by itself (core/scripts/train.py:112-115).  Launched under torchrun it is a plain rank.  A world that is not
+the one asked for, or fewer GPUs than ranks, is a non-zero exit, never a silent single-GPU run.
 
 Default workload = BASELINE.json configs[1] (configs[2] when N > 1): fastMRI-shaped synthetic data, 320x320, n_in = 1, the
 reference's 4-level UNet (17.27 M parameters) + quantile head, bf16 compute mode, random-init weights, inputs resident
-in HBM.  `--config` selects the other BASELINE configs (see CONFIGS below); they are parity-test cases, not the bench line.
+in HBM.
   * a train "step" = forward + fused quantile loss + backward + (N > 1: bucketed RCCL all-reduce of the 17.27 M
     gradients, launched from backward hooks) + fused Adam on a per-GPU batch         -> `value` = train imgs/s (whole job)
   * the calibration leg (`calib`) = calibrate_model on the calibration split (3,474 images at N = 1, 3474/N per GPU):
@@ -13,8 +18,12 @@ in HBM.  `--config` selects the other BASELINE configs (see CONFIGS below); they
     host Hoeffding-Bentkus scan that stops mid-grid; plus the scoring kernel alone on that set (5.7 GB >> Infinity Cache).
   * `fp32` = the same train step in the parity mode (exact-fp32 MFMA), so the reference-precision number exists
     beside the bf16 one.
-`--scaling weak` (default) keeps per-GPU work fixed as N grows; `--scaling strong` splits the reference's global batch
-of 78 (and the 3,474 calibration images) over the ranks.  One JSON line is printed by rank 0.
+  * `other_configs` (N = 1 default run): short lines for BASELINE configs[0] / [3] / [4] and the config-faithful per-GPU
+    batch of 78/8 (what 8-GPU strong scaling runs); `fastmri_pipeline`: the k-space -> image transform.
+  * `strong` (N > 1): the reference's GLOBAL batch of 78 split over the ranks (10,10,10,10,10,10,9,9 on 8), beside the
+    weak-scaling `value` (78 per GPU).
+`--scaling weak` (default) keeps per-GPU work fixed as N grows; `--scaling strong` makes the split batch the headline.
+One JSON line is printed by rank 0.
 """
 import argparse
 import contextlib
@@ -131,229 +140,197 @@ def cpu_baseline(hw, legs=((4, 5), (8, 3)), n_cal_e2e=48):
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="fastmri", choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=None, help="per-GPU training batch in weak scaling (default: the config's; 78 = "
-                    "the reference's fastMRI batch_size); the GLOBAL batch with --scaling strong")
-    ap.add_argument("--calib-images", type=int, default=None, help="calibration images per GPU (default: the config's total / N)")
-    ap.add_argument("--size", type=int, default=None)
-    ap.add_argument("--depth", type=int, default=None)
-    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32", "fp8"],
-                    help="bf16 (default) | fp32 (parity mode) | fp8 (bf16 storage, e4m3 operands in the forward 3x3 convs)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 (parity mode) companion number")
-    ap.add_argument("--legs", default="train,calib", help="which legs to run (profiling: --legs train / --legs calib)")
-    ap.add_argument("--uncertainty-type", default="quantiles",
-                    choices=["quantiles", "quantiles_l1", "gaussian", "residual_magnitude", "residual_magnitude_l1", "softmax"],
-                    help="final layer (the headline metric is 'quantiles'; the others are the SURVEY 8f rank-1 rows)")
-    args = ap.parse_args()
-    conf = dict(CONFIGS[args.config])
-    custom = []
-    for key, val in (("size", args.size), ("depth", args.depth), ("dtype", args.dtype)):
-        if val is not None and val != conf[key]:
-            conf[key] = val
-            custom.append(f"{key}={val}")
-    if args.batch is not None:
-        conf["batch"] = args.batch
+class Job:
+    """what every leg shares: the process group, the device, and the barrier + max-over-ranks timer of the contract."""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    import torch.distributed as dist
-    # IM2IM_DIST_BACKEND=gloo lets the N > 1 code path be exercised with several ranks sharing ONE GPU (RCCL refuses
-    # duplicate devices); the measured configuration is always nccl (= RCCL), one rank per GPU
-    backend = os.environ.get("IM2IM_DIST_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend=backend)
+    def __init__(self, dist, rank, world, dev, backend):
+        self.dist, self.rank, self.world, self.dev, self.backend = dist, rank, world, dev, backend
+        self.host_dt = 0.0
 
-    from im2im_uq_amd import hip_ops, nn_ops
-    from im2im_uq_amd.core.calibration.calibrate_model import calibrate_model
-    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
-    from im2im_uq_amd.core.models.trunks.unet import UNet
-    from im2im_uq_amd.core.scripts.train import GlobalBatchSampler, GradSync, broadcast_module_state
-    from torch.utils.data import TensorDataset
-
-    hw, n_in, depth = conf["size"], conf["n_in"], conf["depth"]
-    strong = args.scaling == "strong"
-    if strong:
-        lo, hi = GlobalBatchSampler.share(conf["batch"], rank, world)
-        B, global_batch = hi - lo, conf["batch"]
-    else:
-        B, global_batch = conf["batch"], conf["batch"] * world
-    if B < 1:
-        raise SystemExit("strong scaling: fewer images in the global batch than ranks")
-    lo, hi = GlobalBatchSampler.share(conf["calib_total"], rank, world)
-    M = args.calib_images if args.calib_images is not None else (hi - lo)
-    fwd_flop, train_flop = conv_flops_per_image(hw, n_in, depth)
-
-    nn_ops.set_compute_dtype(conf["dtype"])
-    torch.manual_seed(0)                                                  # same init on every rank (and broadcast below)
-    cfg = dict(PARAMS, device=str(dev), batch_size=B, uncertainty_type=args.uncertainty_type, num_lambdas=conf["num_lambdas"],
-               minimum_lambda=conf["lam"][0], maximum_lambda=conf["lam"][1],
-               num_softmax=50, minimum_lambda_softmax=0, maximum_lambda_softmax=1.2)      # fastmri_test/config.yml
-    two_plane = args.uncertainty_type in ("gaussian", "residual_magnitude", "residual_magnitude_l1")
-    form = {"gaussian": hip_ops.SETS_SQRT, "residual_magnitude": hip_ops.SETS_SCALE,
-            "residual_magnitude_l1": hip_ops.SETS_SCALE, "softmax": hip_ops.SETS_SOFTMAX}.get(args.uncertainty_type, hip_ops.SETS_QUANTILE)
-    calib_bytes_per_img = (12 if two_plane else 16) * hw * hw            # 2 or 3 fp32 output planes + the label, read once
-    model = add_uncertainty(UNet(n_in, 1, depth=depth), cfg).to(dev)
-    broadcast_module_state(model)
-    opt = nn_ops.FusedAdam(model.parameters(), lr=cfg["lr"])
-    sync = GradSync(model.parameters()) if world > 1 else None
-    loss_weight = B / global_batch if strong else 1.0 / world            # summed over ranks = the global-batch mean loss
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    x = torch.randn(B, n_in, hw, hw, device=dev, generator=g)            # input_normalization: standard
-    y = torch.rand(B, 1, hw, hw, device=dev, generator=g)                # output_normalization: min-max
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
         torch.cuda.synchronize()
 
-    def train_step():
-        pred = model(x)
-        loss = model.loss_fn(pred, y)
-        if sync is None:
-            opt.zero_grad()
-            loss.backward()
-        else:
-            sync.zero_grad()
-            (loss * loss_weight).backward()
-            sync.finish()
-        opt.step()
-        return loss
-
-    host_dt = [0.0]
-
-    def timed(fn, steps, warmup):
+    def timed(self, fn, steps, warmup):
         for _ in range(warmup):
             fn()
-        barrier()
+        self.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
-        host_dt[0] = time.perf_counter() - t0        # time the host needed to ENQUEUE the steps (launch-bound when ~ the total)
+        self.host_dt = time.perf_counter() - t0      # time the host needed to ENQUEUE the steps (launch-bound when ~ the total)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        barrier()
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        self.barrier()
+        t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+        if self.dist is not None:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
-    legs = set(args.legs.split(","))
-    peak = PEAK_FP32_TFLOPS if conf["dtype"] == "fp32" else PEAK_BF16_TFLOPS
-    # ---------------------------------------------------------------- train leg
-    model.train()
-    host_train = None
-    if "train" in legs:
-        dt_train = timed(train_step, args.steps, args.warmup)
-        host_train = host_dt[0] / args.steps * 1e3
-    else:
-        dt_train = float("nan")
-        args.no_roofline = True
-    train_ips = global_batch * args.steps / dt_train
 
-    # ---------------------------------------------------------------- roofline leg (HIP events per conv launch)
-    roof = roof_w = per_kernel = roof_dgrad = None
-    if not args.no_roofline:
-        # per-launch durations of the conv kernels, HIP events on the launch stream.  The weight gradients are put back on the
-        # main stream for these two steps: a kernel's roofline is about the kernel alone, not about what it shares the chip with
-        side_stream_was, pipeline_was = nn_ops.WGRAD_SIDE_STREAM, nn_ops.BWD_PIPELINE
-        nn_ops.WGRAD_SIDE_STREAM = nn_ops.BWD_PIPELINE = False
+class Workload:
+    """one BASELINE config on this rank: model, optimizer, gradient exchange, HBM-resident synthetic batch."""
+
+    def __init__(self, job, conf, utype="quantiles", strong=False):
+        from im2im_uq_amd import nn_ops
+        from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+        from im2im_uq_amd.core.models.trunks.unet import UNet
+        from im2im_uq_amd.core.scripts.train import GlobalBatchSampler, GradSync, broadcast_module_state
+        self.job, self.conf, self.utype, self.strong = job, conf, utype, strong
+        self.hw, self.n_in, self.depth = conf["size"], conf["n_in"], conf["depth"]
+        rank, world, dev = job.rank, job.world, job.dev
+        if strong:
+            lo, hi = GlobalBatchSampler.share(conf["batch"], rank, world)
+            self.B, self.global_batch = hi - lo, conf["batch"]
+        else:
+            self.B, self.global_batch = conf["batch"], conf["batch"] * world
+        if self.B < 1:
+            raise SystemExit("strong scaling: fewer images in the global batch than ranks")
+        self.fwd_flop, self.train_flop = conv_flops_per_image(self.hw, self.n_in, self.depth)
+        nn_ops.set_compute_dtype(conf["dtype"])
+        torch.manual_seed(0)                                              # same init on every rank (and broadcast below)
+        self.cfg = dict(PARAMS, device=str(dev), batch_size=self.B, uncertainty_type=utype, num_lambdas=conf["num_lambdas"],
+                        minimum_lambda=conf["lam"][0], maximum_lambda=conf["lam"][1],
+                        num_softmax=50, minimum_lambda_softmax=0, maximum_lambda_softmax=1.2)      # fastmri_test/config.yml
+        self.model = add_uncertainty(UNet(self.n_in, 1, depth=self.depth), self.cfg).to(dev)
+        broadcast_module_state(self.model)
+        self.opt = nn_ops.FusedAdam(self.model.parameters(), lr=self.cfg["lr"])
+        self.sync = GradSync(self.model.parameters()) if world > 1 else None
+        self.loss_weight = self.B / self.global_batch if strong else 1.0 / world   # summed over ranks = the global-batch mean loss
+        self.gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        self.x = torch.randn(self.B, self.n_in, self.hw, self.hw, device=dev, generator=self.gen)   # input_normalization: standard
+        self.y = torch.rand(self.B, 1, self.hw, self.hw, device=dev, generator=self.gen)          # output_normalization: min-max
+        self.allreduce_bytes = int(self.sync.flat.numel() * 4) if self.sync is not None else 0
+
+    def train_step(self):
+        pred = self.model(self.x)
+        loss = self.model.loss_fn(pred, self.y)
+        if self.sync is None:
+            self.opt.zero_grad()
+            loss.backward()
+        else:
+            self.sync.zero_grad()
+            (loss * self.loss_weight).backward()
+            self.sync.finish()
+        self.opt.step()
+        return loss
+
+    def train_leg(self, steps, warmup):
+        self.model.train()
+        dt = self.job.timed(self.train_step, steps, warmup)
+        return {"imgs_per_s": self.global_batch * steps / dt, "ms_per_step": dt / steps * 1e3,
+                "host_enqueue_ms_per_step": self.job.host_dt / steps * 1e3}
+
+    def kernel_rows(self, overlapped):
+        """per-launch durations of the conv kernels over two extra train steps, HIP events on the stream each kernel is
+        launched on.  overlapped=False: the weight gradients are put back on the main stream, so every kernel is timed alone
+        on the chip (a kernel's roofline is about the kernel); True: the step as `value` times it, weight gradients on
+        their own stream sharing the chip with the main stream's kernels."""
+        from im2im_uq_amd import nn_ops
+        self.model.train()
+        was = nn_ops.WGRAD_SIDE_STREAM, nn_ops.BWD_PIPELINE
+        if not overlapped:
+            nn_ops.WGRAD_SIDE_STREAM = nn_ops.BWD_PIPELINE = False
         nn_ops.TIMER = nn_ops.KernelTimer()
         for _ in range(2):
-            train_step()
+            self.train_step()
         rows = nn_ops.TIMER.collect()
         nn_ops.TIMER = None
-        nn_ops.WGRAD_SIDE_STREAM, nn_ops.BWD_PIPELINE = side_stream_was, pipeline_was
-        per_kernel = {k: {"launches": n, "avg_ms": t / n, "tflops": f / t / 1e9} for k, (n, f, t) in sorted(rows.items())}
-        ig = [(n, f, t) for k, (n, f, t) in rows.items() if k.startswith("conv_igemm")]
-        wg = [(n, f, t) for k, (n, f, t) in rows.items() if k.startswith("conv_wgrad")]
+        nn_ops.WGRAD_SIDE_STREAM, nn_ops.BWD_PIPELINE = was
+        return rows
 
-        def agg(v):
-            n, f, t = sum(a for a, _, _ in v), sum(b for _, b, _ in v), sum(c for _, _, c in v)
-            return {"bound": "mfma", "achieved": f / t / 1e9, "peak": peak, "unit": "TFLOP/s", "frac": f / t / 1e9 / peak,
-                    "traffic": None, "launches_per_step": n // 2, "avg_launch_ms": t / n,
-                    "algorithmic_gflop_per_launch": f / n / 1e9}
-        roof = dict(agg(ig), kernel="conv_igemm_kernel (forward + data-gradient launches, all tile variants)")
-        f8 = [(n, f, t) for k, (n, f, t) in rows.items() if k.startswith("conv_fp8")]
-        if f8:                          # fp8 mode: the forward convs run on the block-scaled fp8 MFMA -> priced against ITS peak
-            n8, fl8, t8 = sum(a for a, _, _ in f8), sum(b for _, b, _ in f8), sum(c for _, _, c in f8)
-            roof_fp8 = {"bound": "mfma", "achieved": fl8 / t8 / 1e9, "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s",
-                        "frac": fl8 / t8 / 1e9 / PEAK_FP8_TFLOPS, "traffic": None, "launches_per_step": n8 // 2, "avg_launch_ms": t8 / n8,
-                        "algorithmic_gflop_per_launch": fl8 / n8 / 1e9, "kernel": "conv_fp8_kernel (forward 3x3 convs, e4m3 operands)"}
-            roof = dict(roof, kernel="conv_igemm_kernel (bf16: data-gradient launches + the non-eligible forward convs)")
-            roof, roof_dgrad = roof_fp8, roof
-        else:
-            roof_dgrad = None
-        if conf["dtype"] == "bf16":
-            # second stated peak: what the MFMA pipe sustains on random (non-zero) operands on this power-limited part
-            roof["peak_random_operands"] = MEASURED_BF16_RANDOM_TFLOPS
-            roof["frac_of_random_operand_peak"] = roof["achieved"] / MEASURED_BF16_RANDOM_TFLOPS
-        try:                            # HBM bytes per launch from the committed PMC passes (same batch and size only)
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                rec = json.load(f)["conv_igemm_kernel"]
-            if rec["per_gpu_batch"] == B and rec["hw"] == hw and args.uncertainty_type == "quantiles" and args.config == "fastmri":
-                roof["traffic"] = rec["traffic_bytes_per_launch"]
-        except Exception:  # noqa: BLE001
-            pass
-        try:
-            # counter-based utilisation from the committed PMC passes (busy MFMA cycles / elapsed SIMD cycles at the clock the chip
-            # actually ran): a second reading beside `frac`, which divides FLOP/s by the nominal-clock peak
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_mfma_busy.json")) as f:
-                busy = json.load(f)
-            if conf["dtype"] == "bf16" and args.config == "fastmri":
-                roof["mfma_busy_cycle_frac_pmc"] = {k: round(v["mfma_busy_frac"], 3) for k, v in busy.items() if isinstance(v, dict) and k.startswith("conv_igemm")}
-        except Exception:  # noqa: BLE001
-            pass
-        roof_w = dict(agg(wg), kernel="conv_wgrad_kernel (+ its split-K reduce)")
+    def release(self):
+        from im2im_uq_amd import nn_ops
+        nn_ops.join_side_streams()
+        torch.cuda.synchronize()
+        self.model = self.opt = self.sync = self.x = self.y = None
+        torch.cuda.empty_cache()
 
-    # ---------------------------------------------------------------- fp32 companion (parity mode, exact-fp32 MFMA)
-    fp32 = None
-    if "train" in legs and conf["dtype"] == "bf16" and not args.no_fp32 and world == 1 and args.config == "fastmri":
-        nn_ops.set_compute_dtype("fp32")
-        s32 = max(2, args.steps // 5)
-        dt32 = timed(train_step, s32, 1)
-        nn_ops.set_compute_dtype(conf["dtype"])
-        ips32 = global_batch * s32 / dt32
-        fp32 = {"value": ips32, "unit": "imgs/s", "steps": s32, "warmup": 1, "ms_per_step": dt32 / s32 * 1e3, "dtype": "fp32",
-                "train_tflops": ips32 * train_flop / 1e12, "peak": PEAK_FP32_TFLOPS,
-                "frac_of_fp32_peak_whole_step": ips32 * train_flop / 1e12 / PEAK_FP32_TFLOPS,
-                "note": "same step in the parity mode (v_mfma_f32_32x32x2_f32, fp32 storage): the reference's own precision"}
 
-    if "calib" not in legs:
-        if rank == 0:
-            print(json.dumps({"metric": "train imgs/sec (train leg only)", "value": train_ips, "unit": "imgs/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_train / args.steps * 1e3,
-                              "host_enqueue_ms_per_step": host_train, "dtype": conf["dtype"], "roofline": roof, "roofline_wgrad": roof_w, "fp32": fp32, "per_kernel": per_kernel}))
-        if world > 1:
-            dist.destroy_process_group()
-        return
+def _agg(v, peak):
+    n, f, t = sum(a for a, _, _ in v), sum(b for _, b, _ in v), sum(c for _, _, c in v)
+    return {"bound": "mfma", "achieved": f / t / 1e9, "peak": peak, "unit": "TFLOP/s", "frac": f / t / 1e9 / peak,
+            "traffic": None, "launches_per_step": n // 2, "avg_launch_ms": t / n, "algorithmic_gflop_per_launch": f / n / 1e9}
 
-    # ---------------------------------------------------------------- calibration leg
+
+def roofline_leg(wl, config_name, full=True):
+    """(roofline, roofline_wgrad, per_kernel, roofline of the bf16 igemm in fp8 mode) of one workload."""
+    conf = wl.conf
+    peak = PEAK_FP32_TFLOPS if conf["dtype"] == "fp32" else PEAK_BF16_TFLOPS
+    rows = wl.kernel_rows(overlapped=False)
+    per_kernel = {k: {"launches": n, "avg_ms": t / n, "tflops": f / t / 1e9} for k, (n, f, t) in sorted(rows.items())}
+    ig = [v for k, v in rows.items() if k.startswith("conv_igemm") or k.startswith("conv_ws")]
+    wg = [v for k, v in rows.items() if k.startswith("conv_wgrad")]
+    f8 = [v for k, v in rows.items() if k.startswith("conv_fp8")]
+    roof = dict(_agg(ig, peak), kernel="conv_igemm_kernel + conv_ws_kernel (forward + data-gradient launches, all tile variants)")
+    roof_dgrad = None
+    if f8:                          # fp8 mode: the fp8 convs run on the block-scaled MFMA -> priced against ITS peak
+        roof_fp8 = dict(_agg(f8, PEAK_FP8_TFLOPS), kernel="conv_fp8_kernel (3x3 convs with e4m3 / e5m2 operands)")
+        roof_dgrad = dict(roof, kernel="conv_igemm_kernel (bf16: the launches the fp8 kernels do not cover)")
+        roof = roof_fp8
+    roof_w = dict(_agg(wg, peak), kernel="conv_wgrad_kernel (+ its split-K reduce)") if wg else None
+    if not full:
+        return roof, roof_w, per_kernel, roof_dgrad
+    # second reading: the same kernels inside the step that `value` times (weight gradients on their own stream)
+    rows_o = wl.kernel_rows(overlapped=True)
+    dom = [v for k, v in rows_o.items() if k.startswith("conv_fp8" if f8 else ("conv_igemm", "conv_ws"))]
+    if dom:
+        roof["frac_in_timed_step"] = _agg(dom, roof["peak"])["frac"]
+    wgo = [v for k, v in rows_o.items() if k.startswith("conv_wgrad")]
+    if wgo and roof_w:
+        roof_w["frac_in_timed_step"] = _agg(wgo, peak)["frac"]
+    if conf["dtype"] == "bf16":
+        # second stated peak: what the MFMA pipe sustains on random (non-zero) operands on this power-limited part
+        roof["peak_random_operands"] = MEASURED_BF16_RANDOM_TFLOPS
+        roof["frac_of_random_operand_peak"] = roof["achieved"] / MEASURED_BF16_RANDOM_TFLOPS
+    try:                            # HBM bytes per launch from the committed PMC passes (same batch and size only)
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f)["conv_igemm_kernel"]
+        if rec["per_gpu_batch"] == wl.B and rec["hw"] == wl.hw and wl.utype == "quantiles" and config_name == "fastmri":
+            roof["traffic"] = rec["traffic_bytes_per_launch"]
+            roof["traffic_source"] = "profiles/pmc_traffic.json (replayed: PMC passes of the same command, not measured in this run)"
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        # counter-based utilisation from the committed PMC passes (busy MFMA cycles / elapsed SIMD cycles at the clock the chip
+        # actually ran): a second reading beside `frac`, which divides FLOP/s by the nominal-clock peak
+        name = "r03_pmc_mfma_busy.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_mfma_busy.json")) else "r02_pmc_mfma_busy.json"
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            busy = json.load(f)
+        if conf["dtype"] == "bf16" and config_name == "fastmri":
+            roof["mfma_busy_cycle_frac_pmc"] = {k: round(v["mfma_busy_frac"], 3) for k, v in busy.items()
+                                                if isinstance(v, dict) and k.startswith(("conv_igemm", "conv_ws"))}
+            roof["mfma_busy_cycle_frac_pmc"]["source"] = f"profiles/{name} (replayed)"
+    except Exception:  # noqa: BLE001
+        pass
+    return roof, roof_w, per_kernel, roof_dgrad
+
+
+def calib_leg(wl, steps, calib_images=None, scoring=True):
+    """calibrate_model end to end on this rank's share of the config's calibration split, then the scoring kernel alone."""
+    from im2im_uq_amd import hip_ops
+    from im2im_uq_amd._lib import lib as _abi
+    from im2im_uq_amd.core.calibration.calibrate_model import calibrate_model
+    from im2im_uq_amd.core.scripts.train import GlobalBatchSampler
+    from torch.utils.data import TensorDataset
+    job, conf, dev, g = wl.job, wl.conf, wl.job.dev, wl.gen
+    hw, n_in, utype = wl.hw, wl.n_in, wl.utype
+    lo, hi = GlobalBatchSampler.share(conf["calib_total"], job.rank, job.world)
+    M = calib_images if calib_images is not None else (hi - lo)
+    two_plane = utype in ("gaussian", "residual_magnitude", "residual_magnitude_l1")
+    form = {"gaussian": hip_ops.SETS_SQRT, "residual_magnitude": hip_ops.SETS_SCALE,
+            "residual_magnitude_l1": hip_ops.SETS_SCALE, "softmax": hip_ops.SETS_SOFTMAX}.get(utype, hip_ops.SETS_QUANTILE)
+    calib_bytes_per_img = (12 if two_plane else 16) * hw * hw            # 2 or 3 fp32 output planes + the label, read once
     # Labels are built from the model's own eval outputs (untimed) so that the scan stops mid-grid like a trained model's
     # does: y = pred + s*z*(half-width on that side), z ~ N(0,1)  =>  the miss rate at lambda is P(|z| > lambda/s); with
     # s = mid-grid / 1.96 (5 % missed at mid-grid) the Hoeffding-Bentkus bound crosses alpha = 0.1 below the middle of the grid (~55-60 % visited).
+    model = wl.model
     model.eval()
     xc = torch.randn(M, n_in, hw, hw, device=dev, generator=g)
     yc = torch.empty(M, 1, hw, hw, device=dev)
     s_lab = (conf["lam"][0] + conf["lam"][1]) / 2 / 1.96
-    if args.uncertainty_type == "quantiles":
+    if utype == "quantiles":
         with torch.no_grad():
             for s in range(0, M, 64):
                 o = model(xc[s:s + 64])
@@ -366,35 +343,37 @@ def main():
         yc.copy_(torch.rand(M, 1, hw, hw, device=dev, generator=g))
     ds = TensorDataset(xc, yc)
     ds.im2im_local_shard = True
-    ccfg = dict(cfg, batch_size=min(max(conf["batch"], 64), M))   # the reference forwards the calibration set in config batches (calibrate_model.py:118)
+    ccfg = dict(wl.cfg, batch_size=min(max(conf["batch"], 64), M))   # the reference forwards the calibration set in config batches (calibrate_model.py:118)
 
     def calib_step():
         with contextlib.redirect_stdout(io.StringIO()):
             calibrate_model(model, ds, ccfg)
-    cal_steps = max(1, args.steps // 5)
-    dt_cal = timed(calib_step, cal_steps, 1)
-    calib_ips = M * world * cal_steps / dt_cal
+    dt_cal = job.timed(calib_step, steps, 1)
+    calib_ips = M * job.world * steps / dt_cal
     lhat = float(model.lhat)
     lam_grid = torch.linspace(conf["lam"][0], conf["lam"][1], conf["num_lambdas"])
     visited = int((lam_grid >= lhat - 1e-9).sum())
     del xc, yc, ds
     torch.cuda.empty_cache()
+    L = conf["num_lambdas"]
+    calib = {"value": calib_ips, "unit": "calib imgs/s (end-to-end calibrate_model: eval forward + all-lambda scoring + HB scan)",
+             "ms_per_step": dt_cal / steps * 1e3, "images_per_gpu": M, "num_lambdas": L, "lhat": lhat, "lambdas_visited_by_scan": visited}
+    if not scoring:
+        return calib
     # scoring kernel alone on outputs shaped like SURVEY 8(d): lhat lands mid-grid
     pred = torch.rand(M, 1, hw, hw, device=dev, generator=g)
     if two_plane:
         mag = 0.05 * torch.rand_like(pred)
-        out3 = torch.stack([pred, mag * mag if args.uncertainty_type == "gaussian" else mag], dim=1).contiguous()
-    elif args.uncertainty_type == "softmax":                    # (lower quantile, prediction, upper quantile) bins of 1/50
+        out3 = torch.stack([pred, mag * mag if utype == "gaussian" else mag], dim=1).contiguous()
+    elif utype == "softmax":                    # (lower quantile, prediction, upper quantile) bins of 1/50
         q = torch.round(pred * 50) / 50
         out3 = torch.stack([(q - 0.04).clamp(0, 1), q, (q + 0.04).clamp(0, 1)], dim=1).contiguous()
     else:
         out3 = torch.stack([pred - 0.05 * torch.rand_like(pred), pred, pred + 0.05 * torch.rand_like(pred)], dim=1).contiguous()
     lab = pred + 0.05 * torch.randn(pred.shape, device=dev, generator=g)
-    L = conf["num_lambdas"]
     lam_eff = lam_grid - (lam_grid[1] - lam_grid[0])
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     lam_dev = lam_eff.to(dev)
-    from im2im_uq_amd._lib import lib as _abi
     hist = torch.empty((_abi.im2im_rcps_workspace_bytes(M, hw * hw, L) // 4,), dtype=torch.int32, device=dev)
     table = torch.empty((M, L), dtype=torch.float32, device=dev)
     for _ in range(2):
@@ -407,50 +386,249 @@ def main():
     torch.cuda.synchronize()
     ms_score = e0.elapsed_time(e1) / reps
     score_gbs = M * calib_bytes_per_img / ms_score / 1e6
-    traffic = None                      # HBM bytes per launch from the committed PMC passes (same M and size only)
+    traffic = source = None             # HBM bytes per launch from the committed PMC passes (same M and size only)
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             rec = json.load(f)["rcps_hist_kernel"]
         if rec["images"] == M and rec["hw"] == hw and not two_plane:
             traffic = rec["traffic_bytes_per_launch"]
+            source = "profiles/pmc_traffic.json (replayed: PMC passes of the same command, not measured in this run)"
     except Exception:  # noqa: BLE001
         pass
-    calib = {
-        "value": calib_ips, "unit": "calib imgs/s (end-to-end calibrate_model: eval forward + all-lambda scoring + HB scan)",
-        "ms_per_step": dt_cal / cal_steps * 1e3, "images_per_gpu": M, "num_lambdas": L,
-        "lhat": lhat, "lambdas_visited_by_scan": visited,
-        "scoring_only": {"imgs_per_s": M / ms_score * 1e3, "ms": ms_score,
-                         "roofline": {"bound": "hbm", "achieved": score_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                      "frac": score_gbs / PEAK_HBM_GBS, "traffic": traffic,
-                                      "kernel": "rcps_hist_kernel (+ memset + suffix)",
-                                      "algorithmic_bytes_per_launch": M * calib_bytes_per_img}},
-    }
+    calib["scoring_only"] = {"imgs_per_s": M / ms_score * 1e3, "ms": ms_score,
+                             "roofline": {"bound": "hbm", "achieved": score_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                          "frac": score_gbs / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": source,
+                                          "kernel": "rcps_hist_kernel (+ memset + suffix)",
+                                          "algorithmic_bytes_per_launch": M * calib_bytes_per_img}}
+    del out3, lab, pred, hist, table
+    torch.cuda.empty_cache()
+    return calib
+
+
+def sub_record(job, name, steps=4, warmup=2, dtype=None, batch=None, calib=True):
+    """a short line for another BASELINE config in the same run: train img/s, ms/step, conv roofline fractions, calib img/s."""
+    conf = dict(CONFIGS[name])
+    if dtype:
+        conf["dtype"] = dtype
+    if batch:
+        conf["batch"] = batch
+    wl = Workload(job, conf)
+    tr = wl.train_leg(steps, warmup)
+    roof, roof_w, _, roof_dgrad = roofline_leg(wl, name, full=False)
+    rec = {"workload": conf["label"], "dtype": conf["dtype"], "per_gpu_batch": wl.B, "steps": steps, "warmup": warmup,
+           "value": tr["imgs_per_s"], "unit": "train imgs/s", "ms_per_step": tr["ms_per_step"],
+           "host_enqueue_ms_per_step": tr["host_enqueue_ms_per_step"],
+           "train_tflops": tr["imgs_per_s"] * wl.train_flop / 1e12,
+           "roofline": {k: roof[k] for k in ("achieved", "peak", "frac", "unit", "kernel")},
+           "roofline_wgrad": {k: roof_w[k] for k in ("achieved", "peak", "frac", "unit")} if roof_w else None}
+    if roof_dgrad:
+        rec["roofline_bf16_igemm"] = {k: roof_dgrad[k] for k in ("achieved", "peak", "frac", "unit")}
+    if calib:
+        c = calib_leg(wl, 1, calib_images=min(conf["calib_total"], 128), scoring=False)
+        rec["calib"] = {k: c[k] for k in ("value", "images_per_gpu", "num_lambdas", "lhat", "lambdas_visited_by_scan")}
+    wl.release()
+    return rec
+
+
+def fastmri_pipeline_record(job, batches=(16, 64), reps=5):
+    """the single-coil sample transform (mask x k-space -> centred inverse DFT -> 320x320 crop -> magnitude ->
+    normalise) on 640x368 slices: GPU slices/s, the two GEMMs against the fp32-matrix peak, the reference transform
+    (oracle.fastmri.unet_data_transform, torch-CPU fft) on the host cores beside it."""
+    from im2im_uq_amd.core.datasets.fastmri import masked_ifft2c_abs
+    from oracle import fastmri as ofm
+    dev = job.dev
+    R, C, crop = 640, 368, (320, 320)
+    mask1 = torch.from_numpy(ofm.seeded_mask("equispaced", C, [0.08], [4], (1, 2, 3)))
+    # pruned separable DFT as two dense complex contractions (DESIGN 3.3): T = X * Wc^T (R x C -> R x 320), I = Wr * T (320 x R x 320)
+    flop = 8.0 * (R * C * crop[1] + crop[0] * R * crop[1])
+    out = {"slice": f"{R}x{C} complex k-space -> {crop[0]}x{crop[1]} magnitude image", "gflop_per_slice": flop / 1e9, "gpu": []}
+    for b in batches:
+        ks = torch.randn(b, R, C, 2, device=dev) * 1e-4
+        masks = mask1.unsqueeze(0).repeat(b, 1)
+        for _ in range(2):
+            masked_ifft2c_abs(ks, masks, crop, 0.1, 2.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            masked_ifft2c_abs(ks, masks, crop, 0.1, 2.0)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        io_bytes = b * (R * C * 8 + crop[0] * crop[1] * 4)
+        out["gpu"].append({"batch": b, "ms": ms, "slices_per_s": b / ms * 1e3, "tflops_fp32_matrix": b * flop / ms / 1e9,
+                           "frac_of_fp32_matrix_peak": b * flop / ms / 1e9 / PEAK_FP32_TFLOPS,
+                           "algorithmic_io_gbs": io_bytes / ms / 1e6, "frac_of_hbm_peak_io": io_bytes / ms / 1e6 / PEAK_HBM_GBS})
+        del ks
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    n_cpu = 16
+    ksc = ofm.det_kspace(n_cpu, R, C, salt=2)
+    ofm.unet_data_transform(ksc[0], mask1, crop)
+    t0 = time.perf_counter()
+    for i in range(n_cpu):                               # the reference transforms one slice per __getitem__ (num_workers = 0)
+        ofm.normalize(ofm.unet_data_transform(ksc[i], mask1, crop), 0.1, 2.0)
+    dt = time.perf_counter() - t0
+    out["cpu_reference_transform"] = {"slices_per_s": n_cpu / dt, "cores": cores, "kind": "port",
+                                      "sample": f"{n_cpu} slices one at a time, torch-CPU pocketfft, {cores} threads"}
+    out["vs_cpu"] = max(r["slices_per_s"] for r in out["gpu"]) / (n_cpu / dt)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="fastmri", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU training batch in weak scaling (default: the config's; 78 = "
+                    "the reference's fastMRI batch_size); the GLOBAL batch with --scaling strong")
+    ap.add_argument("--calib-images", type=int, default=None, help="calibration images per GPU (default: the config's total / N)")
+    ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--depth", type=int, default=None)
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32", "fp8"],
+                    help="bf16 (default) | fp32 (parity mode) | fp8 (bf16 storage, e4m3 / e5m2 operands in the 3x3 convs)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 (parity mode) companion number")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short sub-records (other BASELINE configs, batch 10, "
+                    "fastMRI pipeline; N > 1: the strong-scaling companion)")
+    ap.add_argument("--legs", default="train,calib", help="which legs to run (profiling: --legs train / --legs calib)")
+    ap.add_argument("--uncertainty-type", default="quantiles",
+                    choices=["quantiles", "quantiles_l1", "gaussian", "residual_magnitude", "residual_magnitude_l1", "softmax"],
+                    help="final layer (the headline metric is 'quantiles'; the others are the SURVEY 8f rank-1 rows)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    from im2im_uq_amd import launch
+    if args.gpus > 1 and not launch.in_rendezvous_env():
+        # no launcher around us: become one.  The ranks print the JSON line; this process only relays their exit code.
+        sys.exit(launch.spawn_ranks(args.gpus, sys.argv[1:], script=os.path.abspath(__file__)))
+    dist, rank, world, dev, backend = launch.init_distributed(expected_world=args.gpus)
+    job = Job(dist, rank, world, dev, backend)
+
+    conf = dict(CONFIGS[args.config])
+    custom = []
+    for key, val in (("size", args.size), ("depth", args.depth), ("dtype", args.dtype)):
+        if val is not None and val != conf[key]:
+            conf[key] = val
+            custom.append(f"{key}={val}")
+    if args.batch is not None:
+        conf["batch"] = args.batch
+    default_run = (args.config == "fastmri" and not custom and args.batch is None and args.calib_images is None
+                   and args.uncertainty_type == "quantiles" and args.legs == "train,calib" and not args.no_extras)
+
+    from im2im_uq_amd import nn_ops
+    wl = Workload(job, conf, args.uncertainty_type, strong=args.scaling == "strong")
+    hw, B, global_batch = wl.hw, wl.B, wl.global_batch
+    legs = set(args.legs.split(","))
+
+    # ---------------------------------------------------------------- train leg
+    tr = {"imgs_per_s": float("nan"), "ms_per_step": float("nan"), "host_enqueue_ms_per_step": None}
+    if "train" in legs:
+        tr = wl.train_leg(args.steps, args.warmup)
+    else:
+        args.no_roofline = True
+    train_ips = tr["imgs_per_s"]
+
+    # ---------------------------------------------------------------- roofline leg (HIP events per conv launch)
+    roof = roof_w = per_kernel = roof_dgrad = None
+    if not args.no_roofline:
+        roof, roof_w, per_kernel, roof_dgrad = roofline_leg(wl, args.config)
+
+    # ---------------------------------------------------------------- fp32 companion (parity mode, exact-fp32 MFMA)
+    fp32 = None
+    if "train" in legs and conf["dtype"] == "bf16" and not args.no_fp32 and world == 1 and args.config == "fastmri":
+        nn_ops.set_compute_dtype("fp32")
+        s32 = max(2, args.steps // 5)
+        dt32 = job.timed(wl.train_step, s32, 1)
+        nn_ops.set_compute_dtype(conf["dtype"])
+        ips32 = global_batch * s32 / dt32
+        fp32 = {"value": ips32, "unit": "imgs/s", "steps": s32, "warmup": 1, "ms_per_step": dt32 / s32 * 1e3, "dtype": "fp32",
+                "train_tflops": ips32 * wl.train_flop / 1e12, "peak": PEAK_FP32_TFLOPS,
+                "frac_of_fp32_peak_whole_step": ips32 * wl.train_flop / 1e12 / PEAK_FP32_TFLOPS,
+                "note": "same step in the parity mode (v_mfma_f32_32x32x2_f32, fp32 storage): the reference's own precision"}
+
+    dist_info = {"backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else None,
+                 "world_size": world, "allreduce_bytes_per_step": wl.allreduce_bytes,
+                 "gpus_visible": torch.cuda.device_count(), "self_spawned": os.environ.get("TORCHELASTIC_RUN_ID") is not None}
+
+    if "calib" not in legs:
+        if rank == 0:
+            print(json.dumps({"metric": "train imgs/sec (train leg only)", "value": train_ips, "unit": "imgs/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": tr["ms_per_step"],
+                              "host_enqueue_ms_per_step": tr["host_enqueue_ms_per_step"], "dtype": conf["dtype"],
+                              "distributed": dist_info, "roofline": roof, "roofline_wgrad": roof_w, "fp32": fp32, "per_kernel": per_kernel}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # ---------------------------------------------------------------- calibration leg
+    calib = calib_leg(wl, max(1, args.steps // 5), calib_images=args.calib_images)
+    wl.release()
+
+    # ---------------------------------------------------------------- companions in the same run
+    strong = None
+    if world > 1 and args.scaling == "weak" and not args.no_extras and "train" in legs:
+        # the config-faithful reading beside the weak-scaling one: the reference's GLOBAL batch of 78 split over the ranks
+        ws = Workload(job, conf, args.uncertainty_type, strong=True)
+        ts = ws.train_leg(args.steps, args.warmup)
+        strong = {"value": ts["imgs_per_s"], "unit": "train imgs/s", "scaling": "strong", "global_batch": ws.global_batch,
+                  "per_gpu_batch_rank0": ws.B, "ms_per_step": ts["ms_per_step"],
+                  "host_enqueue_ms_per_step": ts["host_enqueue_ms_per_step"], "steps": args.steps, "warmup": args.warmup,
+                  "note": "calibration is always split over the ranks (3,474 images in total), so `calib` is already the strong-scaling reading"}
+        ws.release()
+    others = pipeline = None
+    if default_run and world == 1:
+        others = {}
+        for name, kw in (("batch10", dict(config="fastmri", batch=10, steps=10, warmup=3, calib=False)),
+                         ("denoise32", dict(config="denoise32", steps=5)), ("temca1024", dict(config="temca1024", steps=3)),
+                         ("bsbcm512_fp8", dict(config="bsbcm512", steps=4)), ("bsbcm512_bf16", dict(config="bsbcm512", steps=4, dtype="bf16", calib=False))):
+            try:
+                cname = kw.pop("config")
+                others[name] = sub_record(job, cname, **kw)
+            except Exception as e:  # noqa: BLE001  -- a sub-record must never cost the headline line
+                others[name] = {"error": f"{type(e).__name__}: {e}"}
+        nn_ops.set_compute_dtype(conf["dtype"])
+        try:
+            pipeline = fastmri_pipeline_record(job)
+        except Exception as e:  # noqa: BLE001
+            pipeline = {"error": f"{type(e).__name__}: {e}"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(320)
         if calib and cpu.get("calib_end_to_end"):
-            calib["vs_cpu_end_to_end"] = calib_ips / cpu["calib_end_to_end"]["value"]
+            calib["vs_cpu_end_to_end"] = calib["value"] / cpu["calib_end_to_end"]["value"]
 
     if rank == 0:
         what = "quantile regression" if args.uncertainty_type == "quantiles" else args.uncertainty_type
         line = {
             "metric": f"train imgs/sec (+ calib imgs/sec in `calib`), {hw}x{hw} UNet " + what,
             "value": train_ips, "unit": "imgs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt_train / args.steps * 1e3, "host_enqueue_ms_per_step": host_train, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": conf["dtype"], "data": "synthetic (shaped like the named dataset, random-init weights)",
+            "ms_per_step": tr["ms_per_step"], "host_enqueue_ms_per_step": tr["host_enqueue_ms_per_step"], "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": conf["dtype"],
+            "data": "synthetic (shaped like the named dataset, random-init weights)",
             "config": {"workload": conf["label"] + (f" [overrides: {', '.join(custom)}]" if custom else "") + f", {args.uncertainty_type}",
-                       "per_gpu_batch": B, "global_batch": global_batch, "parallelism": f"dp{world}", "unet_depth": depth,
-                       "n_in": n_in, "gflop_per_image_train": train_flop / 1e9,
-                       "train_tflops": train_ips * train_flop / 1e12},
+                       "per_gpu_batch": B, "global_batch": global_batch, "parallelism": f"dp{world}", "unet_depth": wl.depth,
+                       "n_in": wl.n_in, "gflop_per_image_train": wl.train_flop / 1e9,
+                       "train_tflops": train_ips * wl.train_flop / 1e12},
+            "distributed": dist_info,
             "roofline": roof, "roofline_wgrad": roof_w, "fp32": fp32, "calib": calib, "cpu_baseline": cpu, "per_kernel": per_kernel,
         }
         if roof_dgrad:
             line["roofline_bf16_igemm"] = roof_dgrad
+        if strong:
+            line["strong"] = strong
+        if others:
+            line["other_configs"] = others
+        if pipeline:
+            line["fastmri_pipeline"] = pipeline
         if cpu:
             line["vs_cpu_train"] = train_ips / cpu["value"]
         print(json.dumps(line))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

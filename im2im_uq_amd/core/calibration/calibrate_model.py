@@ -25,7 +25,7 @@ from torch.utils.data import DataLoader, Subset, TensorDataset
 from .. import _pkg  # noqa: F401
 from ... import hip_ops
 from ..models.add_uncertainty import calibration_repr, sets_form
-from .bounds import HB_mu_plus
+from .bounds import HB_mu_plus  # noqa: F401  (re-exported: the reference's module exposes it here too)
 
 
 # ------------------------------------------------------------------ distributed helpers
@@ -266,25 +266,19 @@ def scan_loss_table(table, lambdas, alpha, delta):
     """Host half of the reference's lambda loop (:130-144) over a full [N,L] table (on any device) whose column j holds
     the losses at lambdas[j] - dlambda.  Returns (lhat, calib_loss_table with unvisited columns zero, trace).
 
-    Per visited lambda the loop does what the reference's does to decide -- the mean of a contiguous [N] fp32 vector (so
-    the sum has the reference's order) and one Hoeffding-Bentkus solve, ~20 us -- and nothing else: the transpose that
-    makes the columns contiguous runs where the table lives, and the visited columns are copied into the result in
-    one piece afterwards (a column-by-column strided write cost 5x the solve)."""
+    The scan itself is the C library's `im2im_rcps_scan` (csrc/hb_bound.cpp): per visited lambda the mean of a contiguous
+    [N] fp32 column and one Hoeffding-Bentkus solve, with the reference's stop rule and default -- so a non-Python caller
+    of the library lands on the same lambda-hat.  The transpose that makes the columns contiguous runs where the table
+    lives, and the visited columns are copied into the result in one piece afterwards."""
     n, L = table.shape
-    dlambda = lambdas[1] - lambdas[0]
-    lhat = lambdas[-1] + dlambda - 1e-9
     cols = table.t().contiguous().cpu()                       # row j = contiguous [N] losses, as torch.cat builds them
-    trace = []
-    stop = L                                                  # first visited column
-    for j in range(L - 1, -1, -1):
-        lam = lambdas[j]
-        Rhat = cols[j].mean()
-        RhatPlus = HB_mu_plus(Rhat.item(), n, delta)
-        trace.append((j, Rhat.item(), RhatPlus))
-        stop = j
-        if Rhat >= alpha or RhatPlus > alpha:
-            lhat = lam
-            break
+    stop, stopped, lhat_f, trace = hip_ops.rcps_scan(cols, lambdas, alpha, delta)
+    if stopped:
+        lhat = lambdas[stop]                                  # the grid point itself (a 0-dim fp32 tensor, as the reference keeps it)
+    else:
+        dlambda = lambdas[1] - lambdas[0]
+        lhat = lambdas[-1] + dlambda - 1e-9
+        assert float(lhat) == lhat_f
     if table.is_cuda:
         visited = torch.zeros_like(table)
         visited[:, stop:] = table[:, stop:]

@@ -8,6 +8,7 @@ import random
 import xml.etree.ElementTree as etree
 from pathlib import Path
 
+import numpy as np
 import torch
 from torch.utils.data import Dataset
 
@@ -89,10 +90,12 @@ class FastMRIDataset(_NormalisedSlices):
         fname, dataslice, metadata = self.examples[idx]
         with self.h5py.File(fname, "r") as hf:
             kspace = hf["kspace"][dataslice]
+            # test / challenge volumes are already sub-sampled and carry their mask: the transform then applies none (reference :136)
+            mask = np.asarray(hf["mask"]) if "mask" in hf else None
             target = hf[self.recons_key][dataslice] if self.recons_key in hf else None
             attrs = dict(hf.attrs)
             attrs.update(metadata)
-        image, target = self.transform(kspace, None, target, attrs, fname.name, dataslice)[:2]
+        image, target = self.transform(kspace, mask, target, attrs, fname.name, dataslice)[:2]
         sub, div = self._affine("input", self.normalize_input)
         tsub, tdiv = self._affine("output", self.normalize_output)
         return ((image - sub) / div).unsqueeze(0), ((target - tsub) / tdiv).unsqueeze(0)

@@ -5,7 +5,11 @@ loss_table_*.pth -> get_images -> eval_set_metrics -> results_*.pkl, with the re
 The reference is driven by `wandb sweep`; offline this module expands the same sweep YAML itself:
 
     python -m im2im_uq_amd.core.scripts.router --config experiments/synthetic_fastmri/config.yml
-    torchrun --nproc-per-node 8 -m im2im_uq_amd.core.scripts.router --config ...      (one process per GPU, RCCL)
+
+Like the reference (`if torch.cuda.device_count() > 1: net = DataParallelPassthrough(net)`, train.py:112-115) the entry point
+uses every GPU of the node by itself: with more than one GPU visible and no rendezvous environment it re-executes itself
+under torch.distributed.run, one process per GPU over RCCL (`--gpus N` picks another count, `--gpus 1` stays single).
+Under torchrun (`torchrun --nproc-per-node 8 -m im2im_uq_amd.core.scripts.router --config ...`) it is a plain rank.
 """
 import argparse
 import itertools
@@ -128,21 +132,23 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", required=True, help="wandb-sweep style YAML (experiments/*/config.yml) or a flat YAML")
     ap.add_argument("--set", nargs="*", default=[], help="overrides key=value (yaml-parsed)")
+    ap.add_argument("--gpus", type=int, default=None, help="processes (one per GPU); default: every visible GPU, as the reference")
     args = ap.parse_args()
     with open(args.config) as f:
         doc = yaml.safe_load(f)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch.distributed as dist
-        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from ... import launch
+    if not launch.in_rendezvous_env():
+        want = args.gpus if args.gpus is not None else torch.cuda.device_count()
+        if want > 1:
+            import sys
+            sys.exit(launch.spawn_ranks(want, sys.argv[1:], module="im2im_uq_amd.core.scripts.router"))
+    _dist, _rank, world, _dev, _backend = launch.init_distributed(expected_world=args.gpus if launch.in_rendezvous_env() and args.gpus else None)
     for params in expand_sweep(doc):
         for kv in args.set:
             k, v = kv.split("=", 1)
             params[k] = yaml.safe_load(v)
         if world > 1:
-            params["device"] = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+            params["device"] = str(_dev)
         run_experiment(params)
 
 

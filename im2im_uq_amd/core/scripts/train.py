@@ -90,6 +90,8 @@ class GradSync:
         self.seen = [0] * len(self.buckets)
         self.fired = set()
         self.launched = [None] * len(self.buckets)
+        self.ready = [False] * len(self.buckets)
+        self.next_bucket = 0                    # buckets [0, next_bucket) are launched
         if self.dist is not None:
             for i, p in enumerate(self.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
@@ -99,8 +101,13 @@ class GradSync:
             b = self.bucket_of[i]
             self.fired.add(i)
             self.seen[b] += 1
-            if self.expected is not None and self.seen[b] == self.expected[b] and self.launched[b] is None:
-                self._launch(b)
+            if self.expected is not None and self.seen[b] == self.expected[b]:
+                self.ready[b] = True
+                # drain in index order; a bucket that is not complete yet (or whose parameters got no gradient on the
+                # learning step, expected == -1) holds back the later ones until it completes / until finish()
+                while self.next_bucket < len(self.buckets) and self.ready[self.next_bucket]:
+                    self._launch(self.next_bucket)
+                    self.next_bucket += 1
         return hook
 
     def _pack(self, b):
@@ -111,7 +118,7 @@ class GradSync:
             if g is None:
                 self.views[m].zero_()
             elif g.data_ptr() != self.views[m].data_ptr():
-                src.append(g if g.dtype == torch.float32 else g.to(torch.float32))
+                src.append(g)                                       # _foreach_copy_ converts a non-fp32 gradient on the way
                 dst.append(self.views[m])
         if src:
             torch._foreach_copy_(dst, src)
@@ -139,9 +146,8 @@ class GradSync:
     def finish(self):
         """call after backward(): every bucket reduced, visible to the current stream, and p.grad = its flat slice."""
         if self.dist is not None:
-            for b in range(len(self.buckets)):  # buckets no hook completed (first step, unused parameters, no local images)
-                if self.launched[b] is None:
-                    self._launch(b)
+            for b in range(self.next_bucket, len(self.buckets)):  # what the hooks did not launch (first step, unused parameters,
+                self._launch(b)                                    # no local images) -- still in index order
             for h in self.launched:
                 h.wait()
             if self.expected is None:
@@ -152,6 +158,8 @@ class GradSync:
             self.seen = [0] * len(self.buckets)
             self.fired = set()
             self.launched = [None] * len(self.buckets)
+            self.ready = [False] * len(self.buckets)
+            self.next_bucket = 0
         else:
             for b in range(len(self.buckets)):
                 self._pack(b)

@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void head_act_fwd_kernel(float* __restrict__ o
     float* o = out + b * img_stride + plane_off + p;
     const float v = *o;
     pre[i] = v;
-    *o = kind == 0 ? fmaxf(v, 0.f) : fabsf(v);
+    *o = kind == 0 ? (v < 0.f ? 0.f : v) : fabsf(v);          // torch's relu: NaN stays NaN (fmaxf would turn it into 0)
   }
 }
 __global__ __launch_bounds__(256) void head_act_bwd_kernel(float* __restrict__ dout, const float* __restrict__ pre, int64_t B, int64_t P,

@@ -126,6 +126,25 @@ def hb_mu_plus(muhat: float, n: int, delta: float, maxiters: int = 1000) -> floa
     return float(lib.im2im_hb_mu_plus(float(muhat), int(n), float(delta), int(maxiters)))
 
 
+def rcps_scan(cols: torch.Tensor, lambdas: torch.Tensor, alpha: float, delta: float, maxiters: int = 1000):
+    """the reference's descending lambda scan (calibrate_model.py:130-144) in the C library: `cols` [L, N] fp32 host tensor
+    whose row j holds the N losses at lambdas[j] - dlambda.  Returns (stop_index, stopped, lhat, trace) with trace =
+    [(j, Rhat, RhatPlus)] in visiting order."""
+    import ctypes
+    cols = cols.to(torch.float32).contiguous().cpu()
+    lam = lambdas.to(torch.float32).contiguous().cpu()
+    L, n = cols.shape
+    stop, stopped, visited = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+    lhat = ctypes.c_float(0.0)
+    rhat = torch.zeros((L,), dtype=torch.float32)
+    rplus = torch.zeros((L,), dtype=torch.float64)
+    check(lib.im2im_rcps_scan(cols.data_ptr(), int(n), int(L), 1, int(n), lam.data_ptr(), float(alpha), float(delta), int(maxiters),
+                              ctypes.byref(stop), ctypes.byref(stopped), ctypes.byref(lhat), ctypes.byref(visited), rhat.data_ptr(),
+                              rplus.data_ptr()), "im2im_rcps_scan")
+    trace = [(j, float(rhat[j]), float(rplus[j])) for j in range(L - 1, stop.value - 1, -1)]
+    return stop.value, bool(stopped.value), lhat.value, trace
+
+
 def hb_mu_plus_batch(muhat: torch.Tensor, n: int, delta: float, maxiters: int = 1000) -> torch.Tensor:
     """float64 [count] Hoeffding-Bentkus bounds of a vector of float32 empirical risks (host, multi-threaded)."""
     m = muhat.detach().to("cpu", F32).contiguous().reshape(-1)

@@ -1,0 +1,78 @@
+"""One process per GPU without an external launcher.
+
+The reference goes multi-GPU by itself: `if torch.cuda.device_count() > 1: net = DataParallelPassthrough(net)`
+(core/scripts/train.py:112-115) -- a user types `python router.py` and every GPU of the node is used.  Here data
+parallelism is one process per GPU over RCCL, so the entry points (bench.py, core/scripts/router.py) re-execute
+themselves under `torch.distributed.run` when they are asked for N > 1 GPUs and find no rendezvous environment:
+`python bench.py --gpus 8` is then the same job as `torchrun --nproc-per-node 8 bench.py --gpus 8`.
+"""
+from __future__ import annotations
+
+import os
+import socket
+import subprocess
+import sys
+
+
+def in_rendezvous_env() -> bool:
+    """True inside a torch.distributed.run / torchrun worker (RANK and WORLD_SIZE exported)."""
+    return "WORLD_SIZE" in os.environ and "RANK" in os.environ
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(nproc: int, argv, module: str | None = None, script: str | None = None, env=None) -> int:
+    """run `python -m torch.distributed.run --nnodes=1 --nproc-per-node nproc <script | -m module> argv...` on 127.0.0.1 and
+    return its exit code (non-zero when any rank failed).  stdout / stderr are inherited, so the one JSON line rank 0
+    prints is this process's output too."""
+    if nproc < 2:
+        raise ValueError("spawn_ranks is for N > 1")
+    if (module is None) == (script is None):
+        raise ValueError("give exactly one of module / script")
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver only supports dmabuf IPC (RCCL needs it)
+    e.setdefault("MASTER_ADDR", "127.0.0.1")
+    e.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port())]
+    cmd += (["-m", module] if module else [script]) + list(argv)
+    return subprocess.call(cmd, env=e)
+
+
+def init_distributed(expected_world: int | None = None):
+    """rendezvous of one rank: device = LOCAL_RANK, backend nccl (= RCCL over xGMI) unless IM2IM_DIST_BACKEND says gloo
+    (several ranks sharing one GPU in tests; RCCL refuses duplicate devices).  Returns (dist or None, rank, world, device,
+    backend).  Fails loudly when the world is not the one the caller asked for or the node has fewer GPUs than ranks."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("IM2IM_DIST_BACKEND", "nccl")
+    if expected_world is not None and world != expected_world:
+        raise SystemExit(f"asked for {expected_world} ranks but WORLD_SIZE={world}")
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("no GPU visible: the HIP path has no CPU fallback")
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks over RCCL need {world} GPUs, this node shows {ndev} "
+                         f"(IM2IM_DIST_BACKEND=gloo lets ranks share a GPU for functional tests)")
+    dev_index = local_rank if backend == "nccl" else local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world == 1:
+        return None, 0, 1, dev, None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        dist.init_process_group(backend="nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend=backend)
+    if dist.get_world_size() != world:
+        raise SystemExit(f"process group has {dist.get_world_size()} ranks, expected {world}")
+    return dist, rank, world, dev, backend

@@ -628,7 +628,9 @@ class ConvStats(torch.autograd.Function):
             # the weight gradient goes to the second stream (see _on_side_stream) unless autograd is about to ACCUMULATE it into
             # an existing .grad on this stream the moment we return (gradient accumulation over several backward passes)
             w_ref = ctx.weight_ref() if ctx.weight_ref is not None else None
-            if WGRAD_SIDE_STREAM and not torch.is_grad_enabled() and w_ref is not None and w_ref.grad is None:
+            # ... or a tensor hook on the weight (wandb.watch, a user's register_hook) would read dW on THIS stream right away
+            if (WGRAD_SIDE_STREAM and not torch.is_grad_enabled() and w_ref is not None and w_ref.grad is None
+                    and not getattr(w_ref, "_backward_hooks", None)):
                 dw = torch.empty((dz.shape[3], ci, 9), dtype=F32, device=dz.device)     # owned by the current stream's pool
                 _on_side_stream(dz.device, (xin, dz, in_ss, xin_hi, in_ss_hi, dw),
                                 lambda: conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi, scratch_key="side", out=dw),

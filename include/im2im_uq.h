@@ -109,6 +109,20 @@ double im2im_hb_mu_plus(double muhat, int64_t n, double delta, int32_t maxiters)
  * floor(n * muhat) is taken on the fp32 product like np.floor(n * muhat) on a 0-dim fp32 tensor.  out [count] float64. */
 int im2im_hb_mu_plus_batch(const float* muhat, int64_t count, int64_t n, double delta, int32_t maxiters, double* out);
 
+/* The descending lambda scan that turns a loss table into lambda-hat (SURVEY K14, section 8(b) `rcps_scan`); replaces the
+ * loop of calibrate_model, core/calibration/calibrate_model.py:130-144, with its quirks: column j of the table holds the
+ * losses at lambdas[j] - dlambda (Q1), columns left of the stop are never visited (Q2), Rhat == 0 gives RhatPlus = 1.0
+ * (Q3), the stop test is `Rhat >= alpha or RhatPlus > alpha` and, when nothing stops the scan, lhat =
+ * lambdas[L-1] + dlambda - 1e-9 evaluated in fp32 (Q4).  Host function (the table is on the host; <= L scalar solves).
+ *   table     fp32, element (image i, lambda j) at table[i*row_stride + j*col_stride]
+ *   lambdas   [L] fp32 ascending grid (torch.linspace(minimum_lambda, maximum_lambda, num_lambdas))
+ *   outputs   *stop_index: first visited column; *stopped: 0 when the scan ran off the grid; *lhat; *visited: columns
+ *             evaluated; rhat [L] fp32 / rhat_plus [L] float64 (either may be NULL): the visited columns' values.
+ * Rhat is the correctly rounded fp32 mean of a column (float64 accumulation). */
+int im2im_rcps_scan(const float* table, int64_t N, int32_t L, int64_t row_stride, int64_t col_stride,
+                    const float* lambdas, double alpha, double delta, int32_t maxiters, int32_t* stop_index,
+                    int32_t* stopped, float* lhat, int32_t* visited, float* rhat, double* rhat_plus);
+
 /* ---------------------------------------------------------------------------------------------
  * Convolution by MFMA implicit GEMM.  Activations are NHWC, element type `dtype`.
  * Replaces nn.Conv2d 3x3 pad 1 (core/models/trunks/unet_parts.py:16,19) and 1x1 (:90) and their

@@ -40,3 +40,34 @@ def test_bench_strong_scaling_splits_the_global_batch_unevenly():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 5 and d["config"]["per_gpu_batch"] == 3 and d["scaling"] == "strong"
     assert d["value"] > 0 and d["calib"]["value"] > 0
+
+
+def test_bench_gpus_2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` exactly as the driver types it -- no torch.distributed.run around it: the script spawns the
+    two ranks itself (they share the one GPU over gloo here; on an N-GPU node the default backend is nccl = RCCL) and the
+    line proves it: n_gpus, world_size, the all-reduced bytes, and the strong-scaling companion."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["IM2IM_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "5",
+           "--size", "64", "--calib-images", "8", "--no-roofline", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["distributed"]["world_size"] == 2 and d["distributed"]["backend"] == "gloo"
+    assert d["distributed"]["allreduce_bytes_per_step"] == 17269123 * 4
+    assert d["config"]["global_batch"] == 10 and d["scaling"] == "weak"
+    assert d["strong"]["global_batch"] == 5 and d["strong"]["per_gpu_batch_rank0"] == 3 and d["strong"]["value"] > 0
+
+
+def test_bench_gpus_2_over_rccl_needs_two_gpus():
+    """default backend (nccl = RCCL): two ranks on a one-GPU box must be a non-zero exit that says why, never n_gpus 1."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has two GPUs: the RCCL path itself runs (driver's scaling bench)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "IM2IM_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode != 0 and "need 2 GPUs" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -48,3 +48,39 @@ def test_scan_quirks_on_host_table():
     table2 = torch.full((n, 13), 0.01)
     lhat2, out2, trace2 = scan_loss_table(table2, lambdas, alpha=0.5, delta=0.5)
     assert len(trace2) == 13 and float(lhat2) == float(lambdas[-1] + (lambdas[1] - lambdas[0]) - 1e-9)  # Q4
+
+
+@pytest.mark.parametrize("case", ["mid", "n130", "zero_risk", "no_stop", "c2"])
+def test_rcps_scan_c_abi_on_reference_tables_g7(case):
+    """im2im_rcps_scan through ctypes on the reference's own loss tables (fixtures G7, calibrate_model.py:130-144 run by the
+    imported reference): same stop column, same lambda-hat bit for bit, same number of visited lambdas; Rhat within one fp32
+    ulp of torch's mean (the C scan rounds the exact column mean once), RhatPlus accordingly."""
+    import ctypes
+    import torch
+    from im2im_uq_amd._lib import lib
+    g = load_golden("g7_calibrate_" + case)
+    alpha, delta, L, lo, hi = float(g["cfg"][0]), float(g["cfg"][1]), int(g["cfg"][2]), float(g["cfg"][3]), float(g["cfg"][4])
+    table = np.ascontiguousarray(g["table"], dtype=np.float32)            # [N][L] row-major, zero left of the stop (never visited)
+    n = table.shape[0]
+    lambdas = torch.linspace(lo, hi, L).numpy()
+    stop, stopped, visited = ctypes.c_int32(-1), ctypes.c_int32(-1), ctypes.c_int32(-1)
+    lhat = ctypes.c_float(0.0)
+    rhat = np.zeros(L, np.float32)
+    rplus = np.zeros(L, np.float64)
+    rc = lib.im2im_rcps_scan(table.ctypes.data, n, L, L, 1, lambdas.ctypes.data, alpha, delta, 1000, ctypes.byref(stop),
+                             ctypes.byref(stopped), ctypes.byref(lhat), ctypes.byref(visited), rhat.ctypes.data, rplus.ctypes.data)
+    assert rc == 0
+    ref = g["trace"]
+    assert visited.value == len(ref) and stop.value == int(ref[-1][0])
+    assert np.float32(lhat.value) == np.float32(g["lhat"])
+    assert bool(stopped.value) == (case != "no_stop")
+    for j, r, rp in ref:
+        j = int(j)
+        assert abs(float(rhat[j]) - r) <= 1.2e-7 * max(abs(r), 1e-30), (j, rhat[j], r)
+        assert rplus[j] == pytest.approx(rp, abs=2e-6)
+    # strided form: the transposed copy calibrate_model hands over
+    cols = np.ascontiguousarray(table.T)
+    stop2, lhat2 = ctypes.c_int32(-1), ctypes.c_float(0.0)
+    assert lib.im2im_rcps_scan(cols.ctypes.data, n, L, 1, n, lambdas.ctypes.data, alpha, delta, 1000, ctypes.byref(stop2), None,
+                               ctypes.byref(lhat2), None, None, None) == 0
+    assert stop2.value == stop.value and lhat2.value == lhat.value

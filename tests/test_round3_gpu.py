@@ -1,0 +1,150 @@
+"""Round-3 behaviours that need the GPU: the fixes for the round-2 advisor findings (NaN through the Gaussian head's ReLU,
+tensor hooks on conv weights vs the weight-gradient stream, fastMRI volumes that carry their own mask) and the C-ABI
+lambda scan driven by calibrate_model."""
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = torch.from_numpy
+
+
+def test_head_relu_propagates_nan_like_torch():
+    """finallayers/gaussian_layer.py:15-17 applies nn.ReLU to the variance head: torch's relu keeps NaN (a diverged head
+    must surface as a NaN loss, not as var = 0)."""
+    from im2im_uq_amd._lib import check, dptr, lib, stream_ptr
+    b, k, p = 2, 2, 96
+    out = torch.randn(b, k, p, device=DEV)
+    out[0, 1, 5] = float("nan")
+    out[1, 1, 7] = -3.0
+    want = out.clone()
+    want[:, 1] = torch.relu(want[:, 1])
+    pre = torch.empty(b, p, device=DEV)
+    check(lib.im2im_head_activation_fwd(dptr(out), dptr(pre), b, p, k * p, p, 0, stream_ptr(out.device)), "im2im_head_activation_fwd")
+    torch.cuda.synchronize()
+    assert torch.isnan(out[0, 1, 5]) and float(out[1, 1, 7]) == 0.0
+    assert torch.equal(torch.nan_to_num(out, nan=123.0), torch.nan_to_num(want, nan=123.0))
+
+
+def test_tensor_hook_on_conv_weight_sees_the_finished_weight_gradient():
+    """a hook registered on a conv weight (wandb.watch(net) does that, reference train.py:122) reads dW the moment autograd
+    hands it over on the main stream; the weight gradient must then not still be in flight on the side stream."""
+    from im2im_uq_amd import nn_ops
+    from im2im_uq_amd.core.models.trunks.unet_parts import DoubleConv
+    nn_ops.set_compute_dtype("fp32")
+    try:
+        torch.manual_seed(0)
+        blk = DoubleConv(64, 64).to(DEV).train()
+        x = torch.randn(4, 64, 96, 96, device=DEV)
+
+        def run(with_hook):
+            seen = {}
+            handles = []
+            if with_hook:
+                for name, p in blk.named_parameters():
+                    if p.dim() == 4:
+                        handles.append(p.register_hook(lambda g, name=name: seen.__setitem__(name, g.detach().clone())))
+            for p in blk.parameters():
+                p.grad = None
+            blk(x).square().mean().backward()
+            nn_ops.join_side_streams()
+            torch.cuda.synchronize()
+            for h in handles:
+                h.remove()
+            return seen, {n: p.grad.clone() for n, p in blk.named_parameters() if p.dim() == 4}
+        _, ref = run(False)
+        for _ in range(3):                                    # a race would not show every time
+            seen, got = run(True)
+            assert set(seen) == set(ref)
+            for n in ref:
+                assert torch.equal(seen[n], ref[n]) and torch.equal(got[n], ref[n]), n
+    finally:
+        nn_ops.set_compute_dtype("bf16")
+
+
+class _FakeH5File(dict):
+    """the slice of h5py.File the dataset uses: item access, `in`, .attrs, context manager."""
+
+    def __init__(self, items, attrs):
+        super().__init__(items)
+        self.attrs = attrs
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_HEADER = """<ismrmrdHeader xmlns="http://www.ismrm.org/ISMRMRD"><encoding>
+<encodedSpace><matrixSize><x>96</x><y>72</y><z>1</z></matrixSize></encodedSpace>
+<reconSpace><matrixSize><x>48</x><y>40</y><z>1</z></matrixSize></reconSpace>
+<encodingLimits><kspace_encoding_step_1><minimum>0</minimum><maximum>71</maximum><center>36</center></kspace_encoding_step_1></encodingLimits>
+</encoding></ismrmrdHeader>"""
+
+
+def test_fastmri_dataset_reads_volumes_and_honours_a_mask_stored_in_the_file(tmp_path, monkeypatch):
+    """FastMRIDataset against an in-memory stand-in for h5py (the image has none): train volumes get a fresh mask from
+    mask_func; test / challenge volumes are already sub-sampled, carry `mask`, and must NOT be masked a second time
+    (reference FastMRIDataset.py:136 passes hf['mask'] to the transform, transforms.py:286-292 then skips mask_func)."""
+    from oracle import fastmri as ofm
+    ks = ofm.det_kspace(4, 96, 72, salt=3)
+    kc = (ks[..., 0] + 1j * ks[..., 1]).numpy()
+    stored_mask = ofm.seeded_mask("random", 72, [0.1], [3], 7)
+    pre_masked = kc * stored_mask.reshape(1, 1, -1)
+    recon = ofm.unet_data_transform(ks, torch.ones(72), (48, 40)).numpy()
+    files = {
+        "train_vol.h5": _FakeH5File({"kspace": kc, "reconstruction_esc": recon, "ismrmrd_header": np.array(_HEADER.encode())}, {"max": 1.0}),
+        "test_vol.h5": _FakeH5File({"kspace": pre_masked, "mask": stored_mask, "reconstruction_esc": recon,
+                                    "ismrmrd_header": np.array(_HEADER.encode())}, {"max": 1.0}),
+    }
+    for name in files:
+        (tmp_path / name).write_bytes(b"")
+    fake = types.ModuleType("h5py")
+    fake.File = lambda fname, mode="r": files[str(fname).rsplit("/", 1)[-1]]
+    monkeypatch.setitem(sys.modules, "h5py", fake)
+    from im2im_uq_amd.core.datasets.fastmri.FastMRIDataset import FastMRIDataset
+    ds = FastMRIDataset(str(tmp_path), "standard", "min-max", {"type": "equispaced", "center_fraction": [0.08], "acceleration": [4]},
+                        slice_sample_period=1, device=DEV)
+    assert len(ds) == 8
+    n_test = 0
+    for i in range(len(ds)):
+        fname, sl, _ = ds.examples[i]
+        x, y = ds[i]
+        assert x.shape == (1, 48, 40) and y.shape == (1, 48, 40)
+        np.testing.assert_allclose(y[0].cpu().numpy(), recon[sl], rtol=0, atol=1e-6)
+        if fname.name == "test_vol.h5":
+            n_test += 1
+            want = ofm.unet_data_transform(T(np.stack([pre_masked[sl].real, pre_masked[sl].imag], -1).astype(np.float32)),
+                                           torch.ones(72), (48, 40))
+            assert float((x[0].cpu() - want).abs().max()) <= 2e-5 * float(want.max())
+    assert n_test == 4
+
+
+@pytest.mark.parametrize("case", ["mid", "no_stop"])
+def test_calibrate_model_runs_the_c_abi_scan(case, monkeypatch):
+    """calibrate_model -> scan_loss_table -> im2im_rcps_scan: the lambda-hat the Python driver sets is the C library's, and
+    equals the reference's (fixture G7)."""
+    import torch.nn as nn
+    from torch.utils.data import TensorDataset
+    from im2im_uq_amd import hip_ops
+    from im2im_uq_amd.core.calibration.calibrate_model import calibrate_model
+    from im2im_uq_amd.core.models.add_uncertainty import ModelWithUncertainty
+    from im2im_uq_amd.core.models.finallayers.quantile_layer import quantile_regression_nested_sets_from_output
+    g = load_golden("g7_calibrate_" + case)
+    v = g["cfg"]
+    cfg = dict(alpha=float(v[0]), delta=float(v[1]), num_lambdas=int(v[2]), minimum_lambda=float(v[3]), maximum_lambda=float(v[4]),
+               batch_size=int(v[5]), rcps_loss="fraction_missed", device=DEV, uncertainty_type="quantiles", dataset="synthetic")
+    calls = []
+    real = hip_ops.rcps_scan
+    monkeypatch.setattr(hip_ops, "rcps_scan", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    ident = ModelWithUncertainty(nn.Identity(), nn.Identity(), None, quantile_regression_nested_sets_from_output, dict(cfg))
+    ident, table = calibrate_model(ident, TensorDataset(T(g["output"]).clone(), T(g["label"]).clone()), cfg)
+    assert calls == [1]
+    assert np.array_equal(table.numpy(), g["table"]) and np.float32(float(ident.lhat)) == np.float32(g["lhat"])
