@@ -41,6 +41,7 @@ SIGNATURES = {
     "im2im_fraction_missed": (_i32, [_ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr]),
     "im2im_hb_mu_plus": (_f64, [_f64, _i64, _f64, _i32]),
     "im2im_hb_mu_plus_batch": (_i32, [_ptr, _i64, _i64, _f64, _i32, _ptr]),
+    "im2im_set_option": (_i32, [ctypes.c_char_p, _i32]),
     "im2im_rcps_scan": (_i32, [_ptr, _i64, _i32, _i64, _i64, _ptr, _f64, _f64, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "im2im_pack_conv_weight": (_i32, [_ptr, _i32, _i32, _i32, _i32, _ptr, _ptr, _ptr]),
     "im2im_conv_stats_rows": (_i64, [_i32, _i32, _i32, _i32]),

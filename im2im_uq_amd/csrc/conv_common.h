@@ -1,0 +1,91 @@
+// Shared pieces of the MFMA implicit-GEMM convolution kernels (conv_mfma.hip: the 4-wave kernel; conv_pp.hip: the 8-wave
+// ping-pong kernel): argument block, operand-fragment traits, moment merging, tile choice.
+#pragma once
+#include "common.h"
+#include "dtypes.h"
+
+namespace im2im {
+
+struct ConvArgs {
+  const void* x;        // [B][H][W][Ci]  T
+  const void* w;        // [Co][TAPS][Ci] T
+  const float* bias;    // [Co] or null
+  const float* scale;   // [Co] or null  (mode affine)
+  const float* shift;   // [Co] or null
+  void* y;              // [B][H][W][Co]  T
+  float* stats;         // [mtiles][3][Co] or null: per-tile (mean, M2, count) of the stored values
+  int B, H, W, Ci, Co, tilesY, tilesX;
+  int relu;             // apply ReLU after affine
+  const float* center;  // [Co] or null: subtracted from the stored output (see im2im_conv_fwd)
+  const float* in_ss;   // [2][Ci] or null: x holds the producer's PRE-BatchNorm output z; the operand staging applies
+                        // a = max(z*scale + shift, 0) on the fly (the BatchNorm+ReLU pass is never materialised)
+  // channel-split operands (the Up block's torch.cat([skip, up], 1) is never materialised, unet_parts.py:68):
+  const void* x_hi;     // null, or: input channels [Ci_lo, Ci) live here (pixel stride Ci - Ci_lo == Ci_lo), [0, Ci_lo) in x
+  const float* in_ss_hi;// [2][Ci - Ci_lo] or null: lazy BatchNorm+ReLU of x_hi (in_ss then describes x's Ci_lo channels)
+  int Ci_lo;
+  void* y_hi;           // null, or: output channels [Co_lo, Co) go here (pixel stride Co - Co_lo), [0, Co_lo) to y
+  int Co_lo;
+  // EPI 3 (data-gradient whose result is the gradient of a lazy BatchNorm+ReLU activation): the producer's pre-BN
+  // output, its BatchNorm coefficients, and where this tile's partial sums of g and g*xhat go ([tiles][2][Co])
+  const void* bn_z;
+  const float* bn_ss;   // [2][Co] scale, shift
+  const float* bn_mi;   // [2][Co] mean, invstd
+  float* bn_partial;
+  // GroupNorm producers have one (scale, shift) pair per IMAGE and channel: in_ss then points at [B][2][Ci] and this is the
+  // stride between images (2*Ci); 0 = one pair per channel for the whole batch (BatchNorm).  Needs one image per tile.
+  int in_ss_img;
+  // conv_pp.hip (8-wave ping-pong kernel), filled by its launcher: LDS bytes per group, number of pixel tiles
+  int pp_group_bytes, pp_ntiles, pp_flags;
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> {
+  using AB = short8;
+  static constexpr int KSTEPS = 2;            // 32 channels / 16 per MFMA
+  static __device__ __forceinline__ AB load(const char* base, int ks, int half) {
+    return *reinterpret_cast<const AB*>(base + ks * 32 + half * 16);
+  }
+  static __device__ __forceinline__ f32x16 mfma(AB a, AB b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
+  }
+};
+template <> struct Frag<float> {
+  using AB = float;
+  static constexpr int KSTEPS = 16;           // 32 channels / 2 per MFMA
+  static __device__ __forceinline__ AB load(const char* base, int ks, int half) {
+    return *reinterpret_cast<const float*>(base + (ks * 2 + half) * 4);
+  }
+  static __device__ __forceinline__ f32x16 mfma(AB a, AB b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+};
+
+// (count, mean, M2) of a union of two sample sets (Chan et al.); symmetric, so both partners of a shuffle agree
+__device__ __forceinline__ void merge_moments_f32(float& n, float& m, float& q, float n2, float m2, float q2) {
+  const float nn = n + n2;
+  const float inv = nn > 0.f ? 1.f / nn : 0.f;
+  const float d = m2 - m;
+  q = q + q2 + d * d * (n * n2 * inv);
+  m = (n * m + n2 * m2) * inv;
+  n = nn;
+}
+
+
+// pixel-tile shape per problem: 16x16 for the large-extent levels, 8x8 patches of FOUR consecutive images for the deep,
+// small-extent ones (40x40, 20x20) so that little of a tile hangs over the image edge while a weight tile is still
+// amortised over 256 output pixels.
+struct TileChoice { int tb, th, tw, bn; };
+inline TileChoice pick_tile(int H, int W, int Co, bool per_image = false) {
+  const bool small = (H < 64 || W < 64) && !per_image;       // per_image: every tile (and its statistics row) lies in ONE image
+  const int bn = (Co % 128 == 0) ? 128 : (Co % 64 == 0) ? 64 : 32;
+  if (!small) return {1, 16, 16, bn};
+  return TileChoice{4, 8, 8, bn};
+}
+
+// conv_pp.hip: the 8-wave ping-pong kernel; returns IM2IM_OK / an error, or 1 when the problem is not one of its shapes
+// (the caller then launches the 4-wave kernel)
+int launch_conv_pp(const ConvArgs& a, hipStream_t stream);
+int conv_pp_mode();
+void set_conv_pp_mode(int mode);
+
+}  // namespace im2im

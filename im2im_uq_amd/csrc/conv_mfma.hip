@@ -15,8 +15,7 @@
 //   * epilogue: + bias, optional folded-BN affine + ReLU (eval), store, and per-channel partial
 //     sums / sums of squares for train-mode BatchNorm (deterministic, no atomics).
 // LDS rows are padded by 16 B so ds_read_b128 operand fetches are (nearly) conflict free.
-#include "common.h"
-#include "dtypes.h"
+#include "conv_common.h"
 #ifndef IM2IM_SETPRIO
 #define IM2IM_SETPRIO 0
 #endif
@@ -29,73 +28,12 @@
 #ifndef IM2IM_WGRAD_XCD
 #define IM2IM_WGRAD_XCD 1
 #endif
+#include <string>
 #include <type_traits>
 
 namespace {
 
 using namespace im2im;
-
-struct ConvArgs {
-  const void* x;        // [B][H][W][Ci]  T
-  const void* w;        // [Co][TAPS][Ci] T
-  const float* bias;    // [Co] or null
-  const float* scale;   // [Co] or null  (mode affine)
-  const float* shift;   // [Co] or null
-  void* y;              // [B][H][W][Co]  T
-  float* stats;         // [mtiles][3][Co] or null: per-tile (mean, M2, count) of the stored values
-  int B, H, W, Ci, Co, tilesY, tilesX;
-  int relu;             // apply ReLU after affine
-  const float* center;  // [Co] or null: subtracted from the stored output (see im2im_conv_fwd)
-  const float* in_ss;   // [2][Ci] or null: x holds the producer's PRE-BatchNorm output z; the operand staging applies
-                        // a = max(z*scale + shift, 0) on the fly (the BatchNorm+ReLU pass is never materialised)
-  // channel-split operands (the Up block's torch.cat([skip, up], 1) is never materialised, unet_parts.py:68):
-  const void* x_hi;     // null, or: input channels [Ci_lo, Ci) live here (pixel stride Ci - Ci_lo == Ci_lo), [0, Ci_lo) in x
-  const float* in_ss_hi;// [2][Ci - Ci_lo] or null: lazy BatchNorm+ReLU of x_hi (in_ss then describes x's Ci_lo channels)
-  int Ci_lo;
-  void* y_hi;           // null, or: output channels [Co_lo, Co) go here (pixel stride Co - Co_lo), [0, Co_lo) to y
-  int Co_lo;
-  // EPI 3 (data-gradient whose result is the gradient of a lazy BatchNorm+ReLU activation): the producer's pre-BN
-  // output, its BatchNorm coefficients, and where this tile's partial sums of g and g*xhat go ([tiles][2][Co])
-  const void* bn_z;
-  const float* bn_ss;   // [2][Co] scale, shift
-  const float* bn_mi;   // [2][Co] mean, invstd
-  float* bn_partial;
-  // GroupNorm producers have one (scale, shift) pair per IMAGE and channel: in_ss then points at [B][2][Ci] and this is the
-  // stride between images (2*Ci); 0 = one pair per channel for the whole batch (BatchNorm).  Needs one image per tile.
-  int in_ss_img;
-};
-
-template <typename T> struct Frag;
-template <> struct Frag<bf16_t> {
-  using AB = short8;
-  static constexpr int KSTEPS = 2;            // 32 channels / 16 per MFMA
-  static __device__ __forceinline__ AB load(const char* base, int ks, int half) {
-    return *reinterpret_cast<const AB*>(base + ks * 32 + half * 16);
-  }
-  static __device__ __forceinline__ f32x16 mfma(AB a, AB b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
-  }
-};
-template <> struct Frag<float> {
-  using AB = float;
-  static constexpr int KSTEPS = 16;           // 32 channels / 2 per MFMA
-  static __device__ __forceinline__ AB load(const char* base, int ks, int half) {
-    return *reinterpret_cast<const float*>(base + (ks * 2 + half) * 4);
-  }
-  static __device__ __forceinline__ f32x16 mfma(AB a, AB b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-  }
-};
-
-// (count, mean, M2) of a union of two sample sets (Chan et al.); symmetric, so both partners of a shuffle agree
-__device__ __forceinline__ void merge_moments_f32(float& n, float& m, float& q, float n2, float m2, float q2) {
-  const float nn = n + n2;
-  const float inv = nn > 0.f ? 1.f / nn : 0.f;
-  const float d = m2 - m;
-  q = q + q2 + d * d * (n * n2 * inv);
-  m = (n * m + n2 * m2) * inv;
-  n = nn;
-}
 
 // EPI: 0 = (+bias) store only [data-gradient, 1x1 conv]; 1 = +bias, store, BatchNorm partial statistics [train forward];
 //      2 = folded BatchNorm affine + ReLU [eval forward];  3 = data-gradient that also starts the BatchNorm+ReLU backward
@@ -1015,20 +953,14 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
   return launch_conv_epi<T, TB, TH, TW, BN, WM, WN, TAPS, 0>(a, stream);
 }
 
-// pixel-tile shape per problem: 16x16 for the large-extent levels, 8x8 (8x16 when Cout == 32) for the
-// deep, small-extent ones (40x40, 20x20) so that little of a tile hangs over the image edge.
-struct TileChoice { int tb, th, tw, bn; };
-inline TileChoice pick_tile(int H, int W, int Co, bool per_image = false) {
-  const bool small = (H < 64 || W < 64) && !per_image;       // per_image: every tile (and its statistics row) lies in ONE image
-  const int bn = (Co % 128 == 0) ? 128 : (Co % 64 == 0) ? 64 : 32;
-  if (!small) return {1, 16, 16, bn};
-  // small extents: an 8x8 patch of FOUR consecutive images per tile, so a weight tile is still amortised over
-  // 256 output pixels (M = 256) while little of a tile hangs over the 40x40 / 20x20 image edge
-  return TileChoice{4, 8, 8, bn};
-}
-
 template <typename T, int TAPS>
 int dispatch_conv(const ConvArgs& a, hipStream_t stream, bool per_image = false) {
+  if constexpr (std::is_same<T, bf16_t>::value && TAPS == 9) {
+    if (!per_image) {                                        // the 8-wave ping-pong kernel takes the shapes it covers
+      const int rc = launch_conv_pp(a, stream);
+      if (rc != 1) return rc;
+    }
+  }
   const TileChoice t = pick_tile(a.H, a.W, a.Co, per_image);
   if (t.tb == 1) {
     if (t.bn == 128) return launch_conv<T, 1, 16, 16, 128, 2, 2, TAPS>(a, stream);
@@ -1236,4 +1168,12 @@ extern "C" int im2im_pack_conv_weight(const float* w, int32_t Co, int32_t Ci, in
   else
     hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, stream, w, Co, Ci, taps, (float*)wf, (float*)wd);
   return im2im::check_launch("pack_weight_kernel");
+}
+
+// run-time switches for within-process A/B measurements (tools/, bench): "conv_pp" = bit 0: ping-pong kernel for the
+// 128-wide tiles, bit 1: for the 64-wide tiles.  Not a reference interface.
+extern "C" int im2im_set_option(const char* key, int32_t value) {
+  IM2IM_REQUIRE(key != nullptr);
+  if (std::string(key) == "conv_pp") { im2im::set_conv_pp_mode(value); return IM2IM_OK; }
+  return im2im::fail_invalid("unknown option");
 }

@@ -126,6 +126,11 @@ def hb_mu_plus(muhat: float, n: int, delta: float, maxiters: int = 1000) -> floa
     return float(lib.im2im_hb_mu_plus(float(muhat), int(n), float(delta), int(maxiters)))
 
 
+def set_option(key: str, value: int) -> None:
+    """run-time A/B switch of a kernel variant (include/im2im_uq.h im2im_set_option)."""
+    check(lib.im2im_set_option(key.encode(), int(value)), "im2im_set_option")
+
+
 def rcps_scan(cols: torch.Tensor, lambdas: torch.Tensor, alpha: float, delta: float, maxiters: int = 1000):
     """the reference's descending lambda scan (calibrate_model.py:130-144) in the C library: `cols` [L, N] fp32 host tensor
     whose row j holds the N losses at lambdas[j] - dlambda.  Returns (stop_index, stopped, lhat, trace) with trace =

@@ -123,6 +123,10 @@ int im2im_rcps_scan(const float* table, int64_t N, int32_t L, int64_t row_stride
                     const float* lambdas, double alpha, double delta, int32_t maxiters, int32_t* stop_index,
                     int32_t* stopped, float* lhat, int32_t* visited, float* rhat, double* rhat_plus);
 
+/* Run-time switch for within-process A/B measurements of kernel variants (tools/, bench.py); no reference counterpart.
+ * "conv_pp": bit 0 = 8-wave ping-pong conv kernel for the 128-channel-wide tiles (default on), bit 1 = for the 64-wide. */
+int im2im_set_option(const char* key, int32_t value);
+
 /* ---------------------------------------------------------------------------------------------
  * Convolution by MFMA implicit GEMM.  Activations are NHWC, element type `dtype`.
  * Replaces nn.Conv2d 3x3 pad 1 (core/models/trunks/unet_parts.py:16,19) and 1x1 (:90) and their
