@@ -57,6 +57,9 @@ __device__ __forceinline__ void wg_barrier() {
   // fences keep the compiler from sliding MFMAs / LDS reads across the phase boundary (MFMAs are register-only
   // instructions, a plain barrier does not order them)
   __builtin_amdgcn_sched_barrier(0);
+#ifdef IM2IM_PP_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
   __syncthreads();
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -278,6 +281,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
     for (int nt = 0; nt < NT; ++nt) fb[nt] = *reinterpret_cast<const short8*>(smem + pb + nt * 32 * ROWB);
   };
   auto mfmas = [&]() __attribute__((always_inline)) {
+#ifdef IM2IM_PP_PRIO
+    __builtin_amdgcn_s_setprio(2);                     // A/B build: this wave's priority up for the length of its M phase (guide T5)
+#endif
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
