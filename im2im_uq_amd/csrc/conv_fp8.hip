@@ -17,7 +17,12 @@
 //     cycles per wave, which covers the load latency and the ~30 VALU of a piece's BatchNorm + conversion, and only two
 //     16-byte pieces are ever in flight per thread (the bf16 kernel holds a whole halo in registers).
 // fp32 accumulation; bf16 output; the epilogue (bias / BatchNorm partial statistics / folded affine + ReLU) is the
-// bf16 kernel's.  The backward pass stays bf16 (gradients need range more than throughput).
+// bf16 kernel's.
+// [r3] The DATA-GRADIENT runs on the same kernel (GRAD = true): dx = conv(dz, flipped weights).  Gradients need range more
+// than precision, so dz is staged as e5m2 ("bf8", the MFMA's A format 1) under a per-tensor power-of-two scale taken from
+// the tensor's amax of the PREVIOUS step (delayed scaling: the kernel that consumes dz also records max|dz| for the next
+// step while it converts, one atomic per wave, no extra pass over the tensor); the weights are e4m3 with one scale per
+// output (= the layer's input) channel; both scales are undone in the epilogue.  The weight gradient stays bf16.
 #include "common.h"
 #include "dtypes.h"
 #include <type_traits>
@@ -44,6 +49,12 @@ struct Fp8ConvArgs {
   bf16_t* y;             // [B][H][W][Co]
   float* stats;          // [tiles][3][Co] or null
   int B, H, W, Ci, Co, Ci_lo, tilesY, tilesX, relu;
+  // [r3] channel-split result (the Up block's data-gradient: d(skip) and d(up) are separate tensors) and the gradient form
+  bf16_t* y_hi;          // null, or: output channels [Co_lo, Co) go here (pixel stride Co - Co_lo), [0, Co_lo) to y
+  int Co_lo;
+  const float* amax_in;  // GRAD: max |x| of this tensor at the previous step (device scalar) -> the staging scale
+  float* amax_out;       // GRAD: receives max |x| of this launch (atomic max of the bit pattern; zeroed by the launch before)
+  float* amax_zero;      // GRAD: slot the NEXT launch will accumulate into, zeroed here
 };
 
 __device__ __forceinline__ void merge_moments_f32(float& n, float& m, float& q, float n2, float m2, float q2) {
@@ -67,8 +78,30 @@ __device__ __forceinline__ uint2 to_fp8x8(const float (&v)[8]) {
   return make_uint2((unsigned)lo, (unsigned)hi);
 }
 
+constexpr float BF8_MAX = 57344.f;
+// 8 floats -> 8 e5m2 bytes (saturating)
+__device__ __forceinline__ uint2 to_bf8x8(const float (&v)[8]) {
+  float c[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) c[k] = __builtin_amdgcn_fmed3f(v[k], -BF8_MAX, BF8_MAX);
+  int lo = __builtin_amdgcn_cvt_pk_bf8_f32(c[0], c[1], 0, false);
+  lo = __builtin_amdgcn_cvt_pk_bf8_f32(c[2], c[3], lo, true);
+  int hi = __builtin_amdgcn_cvt_pk_bf8_f32(c[4], c[5], 0, false);
+  hi = __builtin_amdgcn_cvt_pk_bf8_f32(c[6], c[7], hi, true);
+  return make_uint2((unsigned)lo, (unsigned)hi);
+}
+// staging scale of a gradient tensor from its (previous) amax: amax * scale lands in [2^13, 2^14), a factor 3.5 under
+// e5m2's largest finite value, so a step-to-step growth of the gradients by that much still does not saturate
+__device__ __forceinline__ float grad_scale(float amax) {
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+  int e;
+  frexpf(amax, &e);                                  // amax = f * 2^e, f in [0.5, 1)
+  return ldexpf(1.f, 14 - e);
+}
+
 // EPI: 0 = (+bias) store; 1 = +bias, store, BatchNorm partial statistics; 2 = folded BatchNorm affine (+ReLU)
-template <int TB, int TH, int TW, int BN, int WM, int WN, int EPI>
+// GRAD: data-gradient form (e5m2 operand under a run-time scale, amax bookkeeping, optional split result)
+template <int TB, int TH, int TW, int BN, int WM, int WN, int EPI, bool GRAD>
 __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
   using T = bf16_t;
   constexpr int HH = TH + 2, HWD = TW + 2, HPI = HH * HWD, HPX = TB * HPI;
@@ -145,6 +178,11 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
     __syncthreads();
   }
 
+  float xs = XSCALE, amax_seen = 0.f;
+  if constexpr (GRAD) {
+    xs = grad_scale(*a.amax_in);
+    if (a.amax_zero && blockIdx.x == 0 && tid == 0) *a.amax_zero = 0.f;
+  }
   // ---- halo staging, one 16-byte piece (pixel, 8 channels) at a time.  part = tid % 8 is the same for all of a thread's pieces.
   const int part = tid & 7;
   const T* __restrict__ xg_tile = a.x + (size_t)b0 * a.H * a.W * xstride;
@@ -184,10 +222,14 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] * sc[k] + sh[k], 0.f);
       } else {
+        if constexpr (GRAD) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] *= XSCALE;
+          for (int k = 0; k < 8; ++k) amax_seen = fmaxf(amax_seen, fabsf(v[k]));
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= xs;
       }
-      q = to_fp8x8(v);
+      if constexpr (GRAD) q = to_bf8x8(v); else q = to_fp8x8(v);
     }
     *reinterpret_cast<uint2*>(dst + loff) = q;
   };
@@ -231,7 +273,10 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
       const i32x8 fa = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb[nt], acc[mt][nt], 0, 0, 0, XSCALE_E8M0, 0, 127);
+        if constexpr (GRAD)      // A = e5m2 (format 1), neutral block scales: the run-time tensor scale is undone in the epilogue
+          acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb[nt], acc[mt][nt], 1, 0, 0, 127, 0, 127);
+        else
+          acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb[nt], acc[mt][nt], 0, 0, 0, XSCALE_E8M0, 0, 127);
     }
   };
 
@@ -304,8 +349,18 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
   constexpr int ROWS_PER_PASS = 64 / EPR;
   constexpr int PASSES = WROWS / ROWS_PER_PASS;
   const int ncol = n0 + wn * WCOLS;
-  T* __restrict__ yg = a.y + ncol;
+  const bool to_hi = a.y_hi != nullptr && ncol >= a.Co_lo;
+  T* __restrict__ yg = (to_hi ? a.y_hi : a.y) + (to_hi ? ncol - a.Co_lo : ncol);
+  const int ystride = a.y_hi == nullptr ? a.Co : (to_hi ? a.Co - a.Co_lo : a.Co_lo);
   constexpr bool want_stats = (EPI == 1);
+  if constexpr (GRAD) {
+    if (a.amax_out) {                                  // max over the wave, one atomic per wave (positive floats order like their bits)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) amax_seen = fmaxf(amax_seen, __shfl_xor(amax_seen, off, 64));
+      if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(a.amax_out), __float_as_uint(amax_seen));
+    }
+  }
+  const float inv_xs = GRAD ? 1.f / xs : 1.f;          // exact: xs is a power of two
   __syncthreads();
   char* wbuf = smem + wave * WBYTES;
   float st_n[NT], st_m[NT], st_q[NT];
@@ -334,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = n0 + (wn * NT + nt) * 32 + l31;
-    const float ws = a.wscale[n];
+    const float ws = a.wscale[n] * inv_xs;
     const float bias_v = a.bias ? a.bias[n] : 0.f;
     float sc2 = 1.f, sh2 = 0.f;
     if constexpr (EPI == 2) { sc2 = a.scale[n]; sh2 = a.shift[n]; }
@@ -374,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
     const int m = wm * WROWS + row;
     const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
     if (bb < a.B && yy < a.H && xx < a.W)
-      *reinterpret_cast<uint4*>(yg + (((size_t)bb * a.H + yy) * a.W + xx) * a.Co + piece * EPP) = v;
+      *reinterpret_cast<uint4*>(yg + (((size_t)bb * a.H + yy) * a.W + xx) * ystride + piece * EPP) = v;
   }
   if (want_stats) {
     __syncthreads();
@@ -428,7 +483,36 @@ __global__ __launch_bounds__(256) void pack_weight_fp8_kernel(const float* __res
   }
 }
 
-template <int TB, int TH, int TW, int BN, int WM, int WN, int EPI>
+// data-gradient operand: w [Co][Ci][9] fp32 -> wq [Ci][9 taps, reversed][Co] e4m3 with one power-of-two scale per INPUT channel
+// (the data-gradient's output channel): block = one ci
+__global__ __launch_bounds__(256) void pack_weight_fp8_dgrad_kernel(const float* __restrict__ w, int Co, int Ci, int taps,
+                                                                     unsigned char* __restrict__ wq, float* __restrict__ wscale) {
+  __shared__ float s_max[256];
+  const int ci = blockIdx.x;
+  const int per = Co * taps;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < per; i += 256) { const int co = i / taps, tp = i % taps; m = fmaxf(m, fabsf(w[((size_t)co * Ci + ci) * taps + tp])); }
+  s_max[threadIdx.x] = m;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + off]);
+    __syncthreads();
+  }
+  const float amax = s_max[0];
+  int e = 0;
+  if (amax > 0.f) { frexpf(amax, &e); }
+  const float scale = amax > 0.f ? ldexpf(1.f, e - 8) : 1.f;
+  const float inv = 1.f / scale;
+  if (threadIdx.x == 0) wscale[ci] = scale;
+  for (int i = threadIdx.x; i < per; i += 256) {
+    const int tp = i / Co, co = i % Co;                     // destination order (tap, co): coalesced bytes
+    const float v = fminf(fmaxf(w[((size_t)co * Ci + ci) * taps + tp] * inv, -FP8_MAX), FP8_MAX);
+    const int q = __builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false);
+    wq[((size_t)ci * taps + (taps - 1 - tp)) * Co + co] = (unsigned char)(q & 0xff);
+  }
+}
+
+template <int TB, int TH, int TW, int BN, int WM, int WN, int EPI, bool GRAD = false>
 int launch_fp8(const Fp8ConvArgs& a_in, hipStream_t stream) {
   Fp8ConvArgs a = a_in;
   a.tilesY = (int)cdiv(a.H, TH);
@@ -438,7 +522,7 @@ int launch_fp8(const Fp8ConvArgs& a_in, hipStream_t stream) {
   constexpr size_t smem_epi = (size_t)4 * (TB * TH * TW / WM) * ((BN / WN) * 2 + 16);
   const size_t smem_in = smem_main + ((a.in_ss || a.in_ss_hi) ? (size_t)2 * a.Ci * sizeof(float) : 0);
   const size_t smem = smem_in > smem_epi ? smem_in : smem_epi;
-  auto kern = conv_fp8_kernel<TB, TH, TW, BN, WM, WN, EPI>;
+  auto kern = conv_fp8_kernel<TB, TH, TW, BN, WM, WN, EPI, GRAD>;
   static size_t attr_set = 0;
   if (smem > 64 * 1024 && smem > attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -451,6 +535,7 @@ int launch_fp8(const Fp8ConvArgs& a_in, hipStream_t stream) {
 
 template <int TB, int TH, int TW, int BN, int WM, int WN>
 int launch_fp8_epi(const Fp8ConvArgs& a, hipStream_t stream) {
+  if (a.amax_in) return launch_fp8<TB, TH, TW, BN, WM, WN, 0, true>(a, stream);
   if (a.stats) return launch_fp8<TB, TH, TW, BN, WM, WN, 1>(a, stream);
   if (a.scale) return launch_fp8<TB, TH, TW, BN, WM, WN, 2>(a, stream);
   return launch_fp8<TB, TH, TW, BN, WM, WN, 0>(a, stream);
@@ -463,6 +548,15 @@ int launch_fp8_epi(const Fp8ConvArgs& a, hipStream_t stream) {
 #ifndef IM2IM_FP8_SMALL_TB
 #define IM2IM_FP8_SMALL_TB 2
 #endif
+namespace {
+int dispatch_fp8(const Fp8ConvArgs& a, hipStream_t stream) {
+  const bool small = (a.H < 64 || a.W < 64);
+  const bool wide = a.Co % 128 == 0;
+  if (!small) return wide ? launch_fp8_epi<1, 16, 16, 128, 2, 2>(a, stream) : launch_fp8_epi<1, 16, 16, 64, 4, 1>(a, stream);
+  return wide ? launch_fp8_epi<IM2IM_FP8_SMALL_TB, 8, 8, 128, 2, 2>(a, stream) : launch_fp8_epi<IM2IM_FP8_SMALL_TB, 8, 8, 64, (IM2IM_FP8_SMALL_TB == 4 ? 4 : 2), (IM2IM_FP8_SMALL_TB == 4 ? 1 : 2)>(a, stream);
+}
+}  // namespace
+
 extern "C" int64_t im2im_conv_fp8_stats_rows(int32_t B, int32_t H, int32_t W) {
   const bool small = (H < 64 || W < 64);
   return small ? im2im::cdiv(B, IM2IM_FP8_SMALL_TB) * im2im::cdiv(H, 8) * im2im::cdiv(W, 8) : (int64_t)B * im2im::cdiv(H, 16) * im2im::cdiv(W, 16);
@@ -494,9 +588,30 @@ extern "C" int im2im_conv_fwd_fp8(const void* x, const float* in_scale_shift, co
   IM2IM_REQUIRE((scale == nullptr) == (shift == nullptr));
   IM2IM_REQUIRE(!(stats && scale));
   Fp8ConvArgs a{(const bf16_t*)x, (const bf16_t*)x_hi, in_scale_shift, in_scale_shift_hi, (const unsigned char*)wq, wscale, bias,
-                scale, shift, (bf16_t*)y, stats, B, H, W, Ci, Co, Ci_lo, 0, 0, relu};
-  const bool small = (H < 64 || W < 64);
-  const bool wide = Co % 128 == 0;
-  if (!small) return wide ? launch_fp8_epi<1, 16, 16, 128, 2, 2>(a, stream) : launch_fp8_epi<1, 16, 16, 64, 4, 1>(a, stream);
-  return wide ? launch_fp8_epi<IM2IM_FP8_SMALL_TB, 8, 8, 128, 2, 2>(a, stream) : launch_fp8_epi<IM2IM_FP8_SMALL_TB, 8, 8, 64, (IM2IM_FP8_SMALL_TB == 4 ? 4 : 2), (IM2IM_FP8_SMALL_TB == 4 ? 1 : 2)>(a, stream);
+                scale, shift, (bf16_t*)y, stats, B, H, W, Ci, Co, Ci_lo, 0, 0, relu, nullptr, Co, nullptr, nullptr, nullptr};
+  return dispatch_fp8(a, stream);
+}
+
+extern "C" int im2im_pack_conv_weight_fp8_dgrad(const float* w, int32_t Co, int32_t Ci, int32_t taps, void* wq, float* wscale,
+                                                im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(w && wq && wscale && Co > 0 && Ci > 0 && taps > 0);
+  hipLaunchKernelGGL(pack_weight_fp8_dgrad_kernel, dim3((unsigned)Ci), dim3(256), 0, stream, w, (int)Co, (int)Ci, (int)taps,
+                     (unsigned char*)wq, wscale);
+  return im2im::check_launch("pack_weight_fp8_dgrad_kernel");
+}
+
+extern "C" int im2im_conv_dgrad_fp8(const void* dz, const void* wq_d, const float* wscale_d, void* dx, void* dx_hi, int32_t Cx_lo,
+                                    const float* amax_prev, float* amax_now, float* amax_next, int32_t B, int32_t H, int32_t W,
+                                    int32_t Cz, int32_t Cx, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(dz && wq_d && wscale_d && dx && amax_prev);
+  IM2IM_REQUIRE(B > 0 && H > 0 && W > 0);
+  IM2IM_REQUIRE(Cz > 0 && Cz % 64 == 0 && Cz <= 2048);
+  IM2IM_REQUIRE(Cx > 0 && Cx % 64 == 0);
+  if (dx_hi) IM2IM_REQUIRE(Cx_lo > 0 && Cx_lo % 64 == 0 && Cx_lo < Cx && (Cx - Cx_lo) % 64 == 0);
+  else Cx_lo = Cx;
+  Fp8ConvArgs a{(const bf16_t*)dz, nullptr, nullptr, nullptr, (const unsigned char*)wq_d, wscale_d, nullptr, nullptr, nullptr,
+                (bf16_t*)dx, nullptr, B, H, W, Cz, Cx, Cz, 0, 0, 0, (bf16_t*)dx_hi, Cx_lo, amax_prev, amax_now, amax_next};
+  return dispatch_fp8(a, stream);
 }

@@ -144,6 +144,62 @@ def pack_weight_fp8(w: torch.Tensor):
     return wq, wscale
 
 
+def pack_weight_fp8_dgrad(w: torch.Tensor):
+    """w [Co,Ci,3,3] fp32 -> (wq_d uint8 [Ci,9 reversed,Co] e4m3 bytes, wscale_d [Ci] fp32): operand of the fp8 data-gradient."""
+    co, ci = w.shape[0], w.shape[1]
+    taps = w.shape[2] * w.shape[3]
+    w = w.detach()
+    if w.dtype != F32 or not w.is_contiguous():
+        w = w.to(F32).contiguous()
+    wq = torch.empty((ci, taps, co), dtype=torch.uint8, device=w.device)
+    wscale = torch.empty((ci,), dtype=F32, device=w.device)
+    check(lib.im2im_pack_conv_weight_fp8_dgrad(dptr(w), co, ci, taps, dptr(wq), dptr(wscale), stream_ptr(w.device)),
+          "im2im_pack_conv_weight_fp8_dgrad")
+    return wq, wscale
+
+
+FP8_DGRAD = os.environ.get("IM2IM_FP8_DGRAD", "1") != "0"     # fp8 mode: data-gradients on the fp8 kernel too (e5m2 operand)
+
+
+class Fp8GradScale:
+    """delayed-scaling state of ONE gradient tensor (the dz a conv's data-gradient consumes): three device floats rotated
+    step by step -- max |dz| of the previous step (sets this step's scale), this step's accumulator, the next one's (zeroed
+    by this step's kernel).  Seeded from the tensor itself the first time."""
+    __slots__ = ("amax", "step")
+
+    def __init__(self):
+        self.amax, self.step = None, 0
+
+    def slots(self, dz):
+        if self.amax is None:
+            self.amax = torch.zeros(3, dtype=F32, device=dz.device)
+            self.amax[2] = dz.detach().abs().max().to(F32)           # plays "previous step" for step 0
+        s = self.step
+        self.step += 1
+        base, prev, now, nxt = self.amax.data_ptr(), (s + 2) % 3, s % 3, (s + 1) % 3
+        return base + 4 * prev, base + 4 * now, base + 4 * nxt
+
+
+def conv_dgrad_fp8(dz, wq_d, wscale_d, state: Fp8GradScale, split_out=0):
+    """dx (bf16) = data-gradient of a 3x3 pad-1 conv with e5m2 dz / e4m3 weights (csrc/conv_fp8.hip, GRAD form)."""
+    b, h, w_, cz = dz.shape
+    cx = wq_d.shape[0]
+    if split_out:
+        dx = torch.empty((b, h, w_, split_out), dtype=BF16, device=dz.device)
+        dx_hi = torch.empty((b, h, w_, cx - split_out), dtype=BF16, device=dz.device)
+    else:
+        dx, dx_hi = torch.empty((b, h, w_, cx), dtype=BF16, device=dz.device), None
+    prev, now, nxt = state.slots(dz)
+    small = h < 64 or w_ < 64
+    name = f"conv_fp8_kernel<{'2x8x8' if small else '1x16x16'},{128 if cx % 128 == 0 else 64},dgrad>"
+    ev = TIMER.wrap(name, 2.0 * b * h * w_ * cz * cx * 9, dz.device) if TIMER else None
+    check(lib.im2im_conv_dgrad_fp8(dptr(dz), dptr(wq_d), dptr(wscale_d), dptr(dx), dptr(dx_hi), int(split_out), prev, now, nxt,
+                                   b, h, w_, cz, cx, stream_ptr(dz.device)), "im2im_conv_dgrad_fp8")
+    if ev is not None:
+        ev.record(torch.cuda.current_stream(dz.device))
+    return (dx, dx_hi) if split_out else dx
+
+
 def fp8_eligible(ci, co, x_dtype, ci_lo=None) -> bool:
     return _fp8_forward and x_dtype == BF16 and ci % 64 == 0 and co % 64 == 0 and (ci_lo is None or ci_lo % 64 == 0)
 
@@ -576,6 +632,8 @@ class ConvStats(torch.autograd.Function):
         in_ss_hi = lazy_ss(x_hi) if x_hi is not None else None
         xin_hi = nhwc(x_hi.detach(), cdt) if x_hi is not None else None
         ctx.link = getattr(x, LINK_ATTR, None) if (x_hi is None and not small) else None
+        fp8_d = None
+        ctx.fp8_gs = None
         center = running_mean if (BF16_CENTERING and cdt == BF16 and running_mean is not None) else None
         if small:
             xin = x.detach().to(F32).contiguous()
@@ -585,11 +643,23 @@ class ConvStats(torch.autograd.Function):
                 wd = None                                  # the network input: no data-gradient needed
         else:
             xin = nhwc(x.detach(), cdt)
-            wf, wd = pack_weight(weight, cdt)
+            wd = None
             if center is None and fp8_eligible(ci, co, cdt, xin.shape[3] if xin_hi is not None else None):
-                wq, wscale = pack_weight_fp8(weight)           # forward on the block-scaled fp8 MFMA; backward stays bf16 (wd)
+                wq, wscale = pack_weight_fp8(weight)           # forward on the block-scaled fp8 MFMA
                 z, stats = conv_fwd_fp8(xin, wq, wscale, bias.detach(), want_stats=True, in_ss=in_ss, x_hi=xin_hi, in_ss_hi=in_ss_hi)
+                if FP8_DGRAD and (x.requires_grad or xin_hi is not None):
+                    # ... and the data-gradient too (e5m2 dz under delayed scaling); the weight gradient stays bf16
+                    fp8_d = pack_weight_fp8_dgrad(weight)
+                    gs = getattr(weight, "_im2im_fp8_gs", None)
+                    if gs is None:
+                        gs = Fp8GradScale()
+                        if isinstance(weight, torch.nn.Parameter):
+                            weight._im2im_fp8_gs = gs
+                    ctx.fp8_gs = gs
+                else:
+                    wd = pack_weight(weight, cdt)[1]
             else:
+                wf, wd = pack_weight(weight, cdt)
                 z, stats = conv_fwd(xin, wf, bias.detach(), want_stats=True, in_ss=in_ss, center=center, x_hi=xin_hi, in_ss_hi=in_ss_hi)
         mean_invstd, scale_shift = bn_finalize(stats, b * h * w_, gamma.detach(), beta.detach(), running_mean, running_var,
                                                momentum, eps, centered=center is not None)
@@ -599,14 +669,16 @@ class ConvStats(torch.autograd.Function):
         ctx.set_materialize_grads(False)              # no zero tensors for the two non-differentiable outputs
         none = torch.empty(0)
         ctx.save_for_backward(xin, wd if wd is not None else none, in_ss if in_ss is not None else none,
-                              xin_hi if xin_hi is not None else none, in_ss_hi if in_ss_hi is not None else none)
+                              xin_hi if xin_hi is not None else none, in_ss_hi if in_ss_hi is not None else none,
+                              fp8_d[0] if fp8_d is not None else none, fp8_d[1] if fp8_d is not None else none)
+        ctx.fp8_dgrad = fp8_d is not None
         zz = nchw(z)
         ctx.mark_non_differentiable(scale_shift, mean_invstd)
         return zz, scale_shift, mean_invstd
 
     @staticmethod
     def backward(ctx, dz, _g1, _g2):
-        xin, wd, in_ss, xin_hi, in_ss_hi = ctx.saved_tensors
+        xin, wd, in_ss, xin_hi, in_ss_hi, wq_d, wscale_d = ctx.saved_tensors
         in_ss = in_ss if ctx.has[0] else None
         xin_hi = xin_hi if ctx.has[1] else None
         in_ss_hi = in_ss_hi if ctx.has[2] else None
@@ -642,9 +714,10 @@ class ConvStats(torch.autograd.Function):
                     halves = dz_ready = None
                 dw = conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi).view(dz.shape[3], ci, 3, 3)
             link = ctx.link
-            fuse = (FUSE_BN_REDUCE and xin_hi is None and link is not None and link.consumers == 1 and link.z.dtype == dz.dtype)
+            fuse = (FUSE_BN_REDUCE and xin_hi is None and link is not None and link.consumers == 1 and link.z.dtype == dz.dtype
+                    and not ctx.fp8_dgrad)
             b_first = 0
-            if (xin_hi is not None or ctx.needs_input_grad[0]) and not fuse:
+            if (xin_hi is not None or ctx.needs_input_grad[0]) and not fuse and not ctx.fp8_dgrad:
                 b_first = halves.b_first if halves is not None else _pipeline_split(dz)
             if b_first:
                 # data-gradient in two halves of the batch: the first waits only for ITS half of dz, and the BatchNorm
@@ -670,7 +743,14 @@ class ConvStats(torch.autograd.Function):
             else:
                 if dz_ready is not None:
                     main.wait_event(dz_ready)
-                if xin_hi is not None:
+                if ctx.fp8_dgrad and (xin_hi is not None or ctx.needs_input_grad[0]):
+                    # fp8 mode: e5m2 dz x e4m3 weights on the block-scaled MFMA (conv_fp8.hip, GRAD form)
+                    if xin_hi is not None:
+                        dx, dx_hi = conv_dgrad_fp8(dz, wq_d, wscale_d, ctx.fp8_gs, split_out=xin.shape[3])
+                        dx, dx_hi = nchw(dx), nchw(dx_hi)
+                    else:
+                        dx = nchw(conv_dgrad_fp8(dz, wq_d, wscale_d, ctx.fp8_gs))
+                elif xin_hi is not None:
                     # the data-gradient lands directly in d(skip) and d(up): no concatenated gradient tensor
                     dx, dx_hi = conv_fwd(dz, wd, split_out=xin.shape[3])
                     dx, dx_hi = nchw(dx), nchw(dx_hi)

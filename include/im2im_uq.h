@@ -184,7 +184,7 @@ int im2im_conv_fwd_split(const void* x, const float* in_scale_shift, const void*
  *   x (bf16, optionally the producer's pre-BatchNorm z with lazy coefficients) is scaled by 2^4, clamped to +-448 and
  *     converted to e4m3 while it is staged into LDS (the 2^4 is undone by the instruction's block scale);
  *   Ci % 64 == 0 (Ci_lo % 64 == 0 when split), Co % 64 == 0; no split output, no `center`.
- * stats rows: im2im_conv_fp8_stats_rows(B, H, W).  The backward pass uses the bf16 kernels. */
+ * stats rows: im2im_conv_fp8_stats_rows(B, H, W). */
 int64_t im2im_conv_fp8_stats_rows(int32_t B, int32_t H, int32_t W);
 int im2im_pack_conv_weight_fp8(const float* w, int32_t Co, int32_t Ci, int32_t taps, void* wq, float* wscale,
                                im2im_stream_t stream);
@@ -192,6 +192,23 @@ int im2im_conv_fwd_fp8(const void* x, const float* in_scale_shift, const void* x
                        int32_t Ci_lo, const void* wq, const float* wscale, const float* bias, const float* scale,
                        const float* shift, void* y, float* stats, int32_t B, int32_t H, int32_t W, int32_t Ci,
                        int32_t Co, int32_t relu, im2im_stream_t stream);
+
+/* fp8 data-gradient of the same convolution (the autograd backward of unet_parts.py:16,19 with respect to its input):
+ * dx[b,h,w,cx] = sum_{tap,cz} dz[b,h+..,w+..,cz] * w[cz][cx][flipped tap], on the same kernel with the gradient operand in
+ * OCP e5m2 (range over precision) under a per-tensor power-of-two scale, weights e4m3 with one scale per cx.
+ *   wq_d / wscale_d from im2im_pack_conv_weight_fp8_dgrad(w [Co][Ci][taps] fp32): wq_d [Ci][taps reversed][Co], wscale_d [Ci];
+ *   dz [B][H][W][Cz] bf16 (Cz = the layer's Co), dx [B][H][W][Cx] bf16 (Cx = the layer's Ci), or split into
+ *     dx [..][Cx_lo] and dx_hi [..][Cx - Cx_lo] (both multiples of 64) like im2im_conv_fwd_split's y / y_hi;
+ *   delayed scaling: *amax_prev = max |dz| of this tensor at the previous step (the caller seeds it once); the kernel
+ *     scales dz so that amax_prev lands in [2^13, 2^14) of e5m2's 57344, accumulates this launch's max |dz| into
+ *     *amax_now (atomic max; must be 0 on entry) and zeroes *amax_next for the launch after -- a caller rotates three
+ *     floats.  amax_now / amax_next may be NULL (fixed scale from amax_prev).
+ * Cz % 64 == 0, Cx % 64 == 0.  The weight gradient stays bf16 (im2im_conv_wgrad). */
+int im2im_pack_conv_weight_fp8_dgrad(const float* w, int32_t Co, int32_t Ci, int32_t taps, void* wq_d, float* wscale_d,
+                                     im2im_stream_t stream);
+int im2im_conv_dgrad_fp8(const void* dz, const void* wq_d, const float* wscale_d, void* dx, void* dx_hi, int32_t Cx_lo,
+                         const float* amax_prev, float* amax_now, float* amax_next, int32_t B, int32_t H, int32_t W,
+                         int32_t Cz, int32_t Cx, im2im_stream_t stream);
 
 /* Data-gradient of a convolution whose input was a lazy BatchNorm+ReLU activation (unet_parts.py:16-21 chained): dx is
  * the gradient da of that activation, and the epilogue that writes it also reads the producer's pre-BN output bn_z

@@ -222,3 +222,119 @@ def test_fp8_mode_trains_and_calibrates():
         risk = float(eval_set_metrics(model, TensorDataset(x[:32], y[:32]), cfg)[0])
         assert 0 < float(model.lhat) <= 6.0 and risk <= 0.1 + 0.02
     assert abs(tails["fp8"] / tails["bf16"] - 1.0) < 0.15, tails
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# [r3] fp8 data-gradient: e5m2 dz under a per-tensor power-of-two scale (delayed: the previous step's amax), e4m3 weights
+# with one scale per input channel, on the same kernel (csrc/conv_fp8.hip GRAD form)
+def _grad_scale(amax):
+    import math
+    if not (amax > 0):
+        return 1.0
+    _, e = math.frexp(amax)
+    return 2.0 ** (14 - e)
+
+
+def _dgrad_emulation(dz_nchw, wt, amax):
+    """the kernel's arithmetic on the CPU: dz -> bf16 -> x scale -> clamp -> e5m2; weights / per-ci power of two -> e4m3;
+    fp32 transposed convolution; scales undone."""
+    xs = _grad_scale(amax)
+    dq = (dz_nchw.to(BF16).to(F32) * xs).clamp(-57344.0, 57344.0).to(torch.float8_e5m2).to(F32) / xs
+    co, ci = wt.shape[0], wt.shape[1]
+    amax_ci = wt.abs().amax(dim=(0, 2, 3))
+    scale = torch.where(amax_ci > 0, torch.exp2(torch.floor(torch.log2(amax_ci)) + 1 - 8), torch.ones_like(amax_ci))
+    wq = (wt / scale[None, :, None, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(F32) * scale[None, :, None, None]
+    return F.conv_transpose2d(dq, wq, padding=1), scale
+
+
+DGRAD_CASES = [
+    # B, H, W, Cz (the layer's Co), Cx (the layer's Ci), split result
+    (2, 20, 24, 64, 64, False),
+    (1, 40, 40, 128, 128, False),
+    (2, 70, 66, 64, 128, False),
+    (1, 64, 64, 192, 64, False),
+    (2, 36, 20, 64, 128, True),         # d(skip) 64 + d(up) 64
+    (1, 96, 80, 128, 256, True),
+    (5, 9, 7, 256, 256, False),
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES)
+def test_conv_dgrad_fp8_vs_cpu_on_identically_quantised_operands(case):
+    from im2im_uq_amd import nn_ops
+    b, h, w, cz, cx, split = case
+    dz = rnd(b, cz, h, w, seed=1, scale=3e-5)                   # gradient-sized values: far below e4m3 / e5m2 normals unscaled
+    dz[0, 0, 0, 0] = 2.5e-4                                     # the tensor's amax
+    wt = rnd(cz, cx, 3, 3, seed=2, scale=(cx * 9) ** -0.5)      # the layer's weight [Co = cz][Ci = cx]
+    wt[:, 5] *= 30.0                                            # one input channel with a very different weight scale
+    amax = float(dz.to(BF16).to(F32).abs().max())
+    ref, scale = _dgrad_emulation(dz, wt, amax)
+    wq_d, ws_d = nn_ops.pack_weight_fp8_dgrad(wt.to(DEV))
+    assert torch.equal(ws_d.cpu(), scale)
+    dz_d = dz.to(DEV).permute(0, 2, 3, 1).contiguous().to(BF16)
+    st = nn_ops.Fp8GradScale()
+    out = nn_ops.conv_dgrad_fp8(dz_d, wq_d, ws_d, st, split_out=cx // 2 if split else 0)
+    got = (torch.cat(out, dim=-1) if split else out).float().cpu().permute(0, 3, 1, 2)
+    assert rel_l2(got, ref) < 4e-3                              # bf16 rounding of the stored result
+    # the launch recorded this tensor's amax for the next step and zeroed the slot after it
+    torch.cuda.synchronize()
+    assert float(st.amax[2]) == amax and float(st.amax[0]) == amax and float(st.amax[1]) == 0.0
+    # against the bf16 data-gradient: what e5m2 (2 mantissa bits) x e4m3 costs on a K = 9*Cz contraction
+    _, wd = nn_ops.pack_weight(wt.to(DEV), BF16)
+    bf = nn_ops.conv_fwd(dz_d, wd).float().cpu().permute(0, 3, 1, 2)
+    assert rel_l2(got, bf) < 0.08, rel_l2(got, bf)
+
+
+def test_conv_dgrad_fp8_delayed_scale_follows_the_gradient_magnitude():
+    """three steps with gradients growing 2x per step, then a collapse by 1000x: every step is scaled by the PREVIOUS step's
+    amax; the 3.5x headroom absorbs the growth, and after the collapse one step runs with a too-small scale (values near
+    e5m2's subnormals, larger error) before the scale catches up."""
+    from im2im_uq_amd import nn_ops
+    b, h, w, c = 1, 32, 32, 64
+    wt = rnd(c, c, 3, 3, seed=2, scale=0.04)
+    wq_d, ws_d = nn_ops.pack_weight_fp8_dgrad(wt.to(DEV))
+    _, wd = nn_ops.pack_weight(wt.to(DEV), BF16)
+    st = nn_ops.Fp8GradScale()
+    errs = []
+    for k, mag in enumerate([1e-4, 2e-4, 4e-4, 4e-7, 4e-7]):
+        dz = (rnd(b, h, w, c, seed=10 + k) * mag).to(DEV).to(BF16)
+        got = nn_ops.conv_dgrad_fp8(dz, wq_d, ws_d, st).float()
+        ref = nn_ops.conv_fwd(dz, wd).float()
+        assert bool(torch.isfinite(got).all())
+        errs.append(rel_l2(got.cpu(), ref.cpu()))
+    assert max(errs[:3]) < 0.08 and errs[4] < 0.08, errs
+    assert errs[3] < 0.5, errs                                   # one step on a stale scale: degraded, not broken
+
+
+def test_fp8_mode_train_step_uses_the_fp8_data_gradient():
+    """in fp8 mode the eligible convolutions' data-gradients run on the fp8 kernel (IM2IM_FP8_DGRAD, default on): the step is
+    finite and its gradients stay within e5m2-sized distance of the bf16-backward step."""
+    from im2im_uq_amd import nn_ops
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from im2im_uq_amd.core.models.trunks.unet import UNet
+    nn_ops.set_compute_dtype("fp8")
+    torch.manual_seed(0)
+    model = add_uncertainty(UNet(1, 1), dict(PARAMS)).to(DEV).train()
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.randn(3, 1, 64, 64, generator=g).to(DEV), torch.rand(3, 1, 64, 64, generator=g).to(DEV)
+    grads = {}
+    was = nn_ops.FP8_DGRAD
+    try:
+        for flag in (False, True):
+            nn_ops.FP8_DGRAD = flag
+            nn_ops.TIMER = nn_ops.KernelTimer()
+            for p in model.parameters():
+                p.grad = None
+            loss = model.loss_fn(model(x), y)
+            loss.backward()
+            nn_ops.join_side_streams()
+            rows = nn_ops.TIMER.collect()
+            nn_ops.TIMER = None
+            assert any("dgrad" in k for k in rows) == flag        # the fp8 data-gradient kernel ran iff the switch is on
+            grads[flag] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+            assert all(bool(torch.isfinite(v).all()) for v in grads[flag].values())
+    finally:
+        nn_ops.FP8_DGRAD = was
+        nn_ops.TIMER = None
+    errs = sorted(rel_l2(grads[True][n].cpu(), grads[False][n].cpu()) for n in grads[True] if float(grads[False][n].abs().max()) > 0)
+    assert errs[len(errs) // 2] < 0.15 and errs[-1] < 0.6, (errs[len(errs) // 2], errs[-1])
