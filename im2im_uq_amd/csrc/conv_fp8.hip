@@ -357,7 +357,10 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
     if (a.amax_out) {                                  // max over the wave, one atomic per wave (positive floats order like their bits)
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) amax_seen = fmaxf(amax_seen, __shfl_xor(amax_seen, off, 64));
-      if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(a.amax_out), __float_as_uint(amax_seen));
+      // tens of thousands of waves hit ONE word: only those that would raise it pay for the atomic (a single address
+      // serialises at ~90 atomics/us -- unconditionally this was 2/3 of the kernel's time); a stale read only costs an atomic
+      if (lane == 0 && __float_as_uint(amax_seen) > __hip_atomic_load(reinterpret_cast<unsigned*>(a.amax_out), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(reinterpret_cast<unsigned*>(a.amax_out), __float_as_uint(amax_seen));
     }
   }
   const float inv_xs = GRAD ? 1.f / xs : 1.f;          // exact: xs is a power of two

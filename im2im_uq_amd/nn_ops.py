@@ -647,7 +647,8 @@ class ConvStats(torch.autograd.Function):
             if center is None and fp8_eligible(ci, co, cdt, xin.shape[3] if xin_hi is not None else None):
                 wq, wscale = pack_weight_fp8(weight)           # forward on the block-scaled fp8 MFMA
                 z, stats = conv_fwd_fp8(xin, wq, wscale, bias.detach(), want_stats=True, in_ss=in_ss, x_hi=xin_hi, in_ss_hi=in_ss_hi)
-                if FP8_DGRAD and (x.requires_grad or xin_hi is not None):
+                # (128-wide result tiles only: at 64 output channels the fp8 kernel is no faster than the bf16 one)
+                if FP8_DGRAD and ci % 128 == 0 and (x.requires_grad or xin_hi is not None):
                     # ... and the data-gradient too (e5m2 dz under delayed scaling); the weight gradient stays bf16
                     fp8_d = pack_weight_fp8_dgrad(weight)
                     gs = getattr(weight, "_im2im_fp8_gs", None)
