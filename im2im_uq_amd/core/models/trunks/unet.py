@@ -43,6 +43,11 @@ class UNet(nn.Module):
         self.out = OutConv(base, self.n_channels_middle)
 
     def forward(self, x):
+        return self.out(self.features(x))
+
+    def features(self, x):
+        """everything but the final 1x1 OutConv: the last Up block's activation (ModelWithUncertainty's eval-mode forward
+        feeds it to the fused OutConv + heads kernel)."""
         # lazy=True: between these blocks activations stay "pre-BatchNorm + (scale, shift)"; every consumer below is one
         # of this package's kernels and applies BatchNorm+ReLU on the fly (see DoubleConv.forward).
         # pool=True: a skip block also hands back MaxPool2d(2) of its output for the next Down block (pooled=True), so the
@@ -57,4 +62,4 @@ class UNet(nn.Module):
         h = getattr(self, f"down{depth}")(pooled, lazy=True, pooled=True)
         for k in range(1, depth + 1):                                  # up1(x5, x4) ... up4(., x1)  (:40-43)
             h = getattr(self, f"up{k}")(h, skips[depth - k], lazy=True)
-        return self.out(h)
+        return h

@@ -908,6 +908,50 @@ def conv_bn_relu_eval(x, weight, bias, gamma, beta, running_mean, running_var, e
     return nchw(conv_fwd(xin, packed, None, fold, relu=True, x_hi=xin_hi))
 
 
+_HEAD_ACT = {"relu": 0, "abs": 1}
+# opt-in: measured on MI355X (fastMRI calibration, 3,474 images, profiles/r03_ab_experiments.txt) the fused tail is bit-identical
+# but SLOWER end to end -- 6,510-6,520 vs 6,790-6,800 calib img/s: its 100 KB of LDS allow one workgroup per CU, so the staging,
+# the 1x1 MFMAs, the heads and the output copy of a tile run one after the other, where the two separate kernels each overlap
+# several workgroups per CU; the 1.2 GB of feature-map traffic it saves per 78 images is worth less than that
+FUSE_EVAL_TAIL = os.environ.get("IM2IM_FUSE_EVAL_TAIL", "0") == "1"
+_TAIL_CACHE = weakref.WeakKeyDictionary()      # OutConv's conv module -> (key, packed operands)
+
+
+def conv1x1_heads_eval(x, out_conv, head_convs, act=None):
+    """eval-mode tail in ONE kernel (csrc/smallconv.hip conv1x1_heads_kernel): heads3x3(OutConv1x1(x)) -> [B,K,C,H,W] fp32,
+    bit-identical to Conv1x1 followed by the heads kernel; the 32-channel feature map never reaches HBM.  x: the trunk's
+    64-channel activation, logical [B,64,H,W], channels-last bf16.  Returns None when the shape / dtype is not the fused
+    kernel's (the caller then runs the two modules)."""
+    w1, b1 = out_conv.weight, out_conv.bias
+    k, c_out = len(head_convs), head_convs[0].weight.shape[0]
+    if (not FUSE_EVAL_TAIL or not x.is_cuda or x.dtype != BF16 or w1.shape[0] != 32 or w1.shape[1] != 64 or k * c_out > 8
+            or not x.permute(0, 2, 3, 1).is_contiguous() or getattr(x, LAZY_ATTR, None) is not None):
+        return None
+    tensors = [w1, b1] + [t for cv in head_convs for t in (cv.weight, cv.bias)]
+    key = tuple(v for t in tensors for v in (t.data_ptr(), t._version))
+    hit = _TAIL_CACHE.get(out_conv)
+    if hit is not None and hit[0] == key:
+        wf1, b1f, wh, bh = hit[1]
+    else:
+        wf1 = pack_weight(w1, BF16, want_wd=False)[0]                                # [32][1][64] bf16
+        b1f = b1.detach().to(F32).contiguous()
+        wh = pack_weight(torch.cat([cv.weight.detach() for cv in head_convs], dim=0), F32, want_wd=False)[0]   # [K*C][9][32] fp32
+        bh = torch.cat([cv.bias.detach() for cv in head_convs], dim=0).to(F32).contiguous()
+        _TAIL_CACHE[out_conv] = (key, (wf1, b1f, wh, bh))
+    xin = nhwc(x.detach())
+    b, h, w_, _ = xin.shape
+    out = torch.empty((b, k * c_out, h, w_), dtype=F32, device=x.device)
+    check(lib.im2im_conv1x1_heads_fwd(dptr(xin), dptr(wf1), dptr(b1f), dptr(wh), dptr(bh), dptr(out), b, h, w_, 64, 32, k * c_out,
+                                      _DT[BF16], stream_ptr(x.device)), "im2im_conv1x1_heads_fwd")
+    out = out.view(b, k, c_out, h, w_)
+    if act is not None:
+        p = c_out * h * w_
+        pre = torch.empty((b, p), dtype=F32, device=out.device)
+        check(lib.im2im_head_activation_fwd(dptr(out), dptr(pre), b, p, k * p, p, _HEAD_ACT[act], stream_ptr(out.device)),
+              "im2im_head_activation_fwd")
+    return out
+
+
 # ----------------------------------------------------------------------------------------- GroupNorm (north-star extra)
 def conv_fwd_per_image(x, wf, bias, in_ss_img=None):
     """conv with one image per tile: y [B,H,W,Co] + per-tile statistics rows grouped by image -> (y, stats, rows_per_image).
@@ -1287,9 +1331,6 @@ class QuantileHeads(torch.autograd.Function):
         dw = dw.view(3, c, cmid, 3, 3)
         db = db.view(3, c)
         return dfeat, dw[0], db[0], dw[1], db[1], dw[2], db[2], None
-
-
-_HEAD_ACT = {"relu": 0, "abs": 1}
 
 
 class Heads(torch.autograd.Function):
