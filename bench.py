@@ -552,7 +552,7 @@ def main():
 
     dist_info = {"backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else None,
                  "world_size": world, "allreduce_bytes_per_step": wl.allreduce_bytes,
-                 "gpus_visible": torch.cuda.device_count(), "self_spawned": os.environ.get("TORCHELASTIC_RUN_ID") is not None}
+                 "gpus_visible": torch.cuda.device_count(), "under_torch_distributed_run": os.environ.get("TORCHELASTIC_RUN_ID") is not None}
 
     if "calib" not in legs:
         if rank == 0:

@@ -44,6 +44,7 @@ SIGNATURES = {
     "im2im_set_option": (_i32, [ctypes.c_char_p, _i32]),
     "im2im_rcps_scan": (_i32, [_ptr, _i64, _i32, _i64, _i64, _ptr, _f64, _f64, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "im2im_pack_conv_weight": (_i32, [_ptr, _i32, _i32, _i32, _i32, _ptr, _ptr, _ptr]),
+    "im2im_pack_conv_weights_multi": (_i32, [_i32, _ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr]),
     "im2im_conv_stats_rows": (_i64, [_i32, _i32, _i32, _i32]),
     "im2im_conv_fwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     # x, in_ss, x_hi, in_ss_hi, Ci_lo, wf, bias, center, scale, shift, y, y_hi, Co_lo, stats, B, H, W, Ci, Co, taps, relu, dtype, stream
@@ -66,7 +67,7 @@ SIGNATURES = {
                                       _i32, _ptr]),
     "im2im_conv_wgrad": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_reduce_workspace_bytes": (_i64, [_i64]),
-    "im2im_bn_finalize": (_i32, [_ptr, _i64, _i32, _i64, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _i32, _ptr, _ptr, _ptr, _ptr]),
+    "im2im_bn_finalize": (_i32, [_ptr, _i64, _i32, _i64, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _i32, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "im2im_bn_fold_eval": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _f32, _i32, _ptr, _ptr]),
     "im2im_bn_relu_apply": (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr]),
     "im2im_bn_bwd_workspace_bytes": (_i64, [_i64, _i32]),

@@ -71,8 +71,7 @@ class DoubleConv(nn.Module):
                 momentum = bn.momentum if bn.momentum is not None else 0.1
                 x = nn_ops.conv_bn_relu_train(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                                               bn.running_var, momentum, bn.eps, cdt, lazy_out=(lazy or ci == 0), x_hi=x_hi,
-                                              pool=(pool and ci == 3))
-                bn.num_batches_tracked += 1
+                                              pool=(pool and ci == 3), num_batches_tracked=bn.num_batches_tracked)
             else:
                 needs_graph = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad or bn.weight.requires_grad)
                 x = nn_ops.conv_bn_relu_eval(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,

@@ -71,11 +71,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
                                                            float momentum, float eps, int centered,
-                                                           float* __restrict__ mean_invstd, float* __restrict__ scale_shift) {
+                                                           float* __restrict__ mean_invstd, float* __restrict__ scale_shift,
+                                                           long long* __restrict__ num_batches_tracked) {
   // one wave per channel: lane i holds split-row i (S <= 64); the xor butterfly applies the (symmetric) merge, so every
   // lane ends with the same, order-fixed result
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
+  // BatchNorm2d's `num_batches_tracked += 1` (torch does it in the module's forward; 18 one-element add launches per step)
+  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
   if (c >= C) return;
   Moments m{0.0, 0.0, 0.0};
   if (lane < S) { const double* row = tmp + (size_t)lane * 3 * C; m = Moments{row[c], row[C + c], row[2 * C + c]}; }
@@ -1510,7 +1513,8 @@ extern "C" int64_t im2im_reduce_workspace_bytes(int64_t K) { return im2im::reduc
 
 extern "C" int im2im_bn_finalize(const float* partial, int64_t R, int32_t C, int64_t count, const float* gamma,
                                  const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                 int32_t centered, float* mean_invstd, float* scale_shift, void* ws, im2im_stream_t stream_) {
+                                 int32_t centered, float* mean_invstd, float* scale_shift, void* ws, int64_t* num_batches_tracked,
+                                 im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(partial && gamma && beta && mean_invstd && scale_shift && ws && R > 0 && C > 0 && count > 0);
   IM2IM_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
@@ -1520,7 +1524,8 @@ extern "C" int im2im_bn_finalize(const float* partial, int64_t R, int32_t C, int
                      cdiv(R, S), (double*)ws);
   if (int rc = check_launch("bn_stats_stage1_kernel")) return rc;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, stream, (const double*)ws, S, (int)C,
-                     (double)count, gamma, beta, running_mean, running_var, momentum, eps, (int)centered, mean_invstd, scale_shift);
+                     (double)count, gamma, beta, running_mean, running_var, momentum, eps, (int)centered, mean_invstd, scale_shift,
+                     (long long*)num_batches_tracked);
   return check_launch("bn_finalize_kernel");
 }
 

@@ -139,6 +139,13 @@ int im2im_set_option(const char* key, int32_t value);
 int im2im_pack_conv_weight(const float* w, int32_t Co, int32_t Ci, int32_t taps, int32_t dtype,
                            void* wf, void* wd, im2im_stream_t stream);
 
+/* The same packing for n tensors in one launch (a training step re-packs every conv weight after the optimizer changed
+ * them; 18 separate launches were 6 % of a small-batch step's launches).  w[i] [Co[i]][Ci[i]][taps[i]] fp32 ->
+ * wf[i] [Co][taps][Ci], wd[i] [Ci][taps reversed][Co] (wd[i] may be NULL), all in `dtype`.  Host arrays of n entries. */
+int im2im_pack_conv_weights_multi(int32_t n_tensors, const float* const* w, const int32_t* Co, const int32_t* Ci,
+                                  const int32_t* taps, int32_t dtype, void* const* wf, void* const* wd,
+                                  im2im_stream_t stream);
+
 /* y[b,h,w,co] = epi( sum_{tap,ci} x[b,h+kh-1,w+kw-1,ci] * wf[co][tap][ci] + bias[co] )
  *   x [B][H][W][Ci], y [B][H][W][Co] (dtype), Ci % 32 == 0, Co % 32 == 0, taps in {9,1}
  *   bias fp32 [Co] or NULL;  scale/shift fp32 [Co] or both NULL: v = v*scale + shift (folded eval-mode
@@ -246,7 +253,8 @@ int64_t im2im_reduce_workspace_bytes(int64_t K);
  * im2im_bn_finalize: per-tile partial moments from the conv epilogue (partial [R][3][C]: mean, M2, count) -> batch
  *   mean and biased variance (pairwise merge in fp64, never E[z^2]-E[z]^2); writes mean_invstd [2][C],
  *   scale_shift [2][C] (scale = gamma*invstd, shift = beta - mean*scale) and, if non-NULL, the running statistics
- *   (unbiased variance, as torch).  ws: im2im_reduce_workspace_bytes(3*C) bytes.
+ *   (unbiased variance, as torch).  ws: im2im_reduce_workspace_bytes(3*C) bytes.  num_batches_tracked (device int64
+ *   scalar or NULL) is incremented by one: nn.BatchNorm2d's bookkeeping in the same launch.
  * im2im_bn_fold_eval: eval-mode fold into the conv epilogue: scale = gamma/sqrt(rv+eps),
  *   shift = beta + (conv_bias - rm)*scale.
  * im2im_bn_relu_apply: a = max(z*scale + shift, 0).
@@ -256,7 +264,7 @@ int64_t im2im_reduce_workspace_bytes(int64_t K);
 int im2im_bn_finalize(const float* partial, int64_t R, int32_t C, int64_t count, const float* gamma,
                       const float* beta, float* running_mean, float* running_var, float momentum,
                       float eps, int32_t centered, float* mean_invstd, float* scale_shift, void* ws,
-                      im2im_stream_t stream);
+                      int64_t* num_batches_tracked, im2im_stream_t stream);
 int im2im_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, const float* conv_bias, float eps, int32_t C,
                        float* scale_shift, im2im_stream_t stream);
