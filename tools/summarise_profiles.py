@@ -11,7 +11,7 @@ def first(pattern):
     return hits[0] if hits else None
 
 
-for leg in ("train", "calib"):
+for leg in ("train", "calib", "train_isolated", "fp32", "temca1024", "bsbcm512"):
     src = first(os.path.join(go, f"{tag}_prof_{leg}", "**", "*kernel_stats.csv"))
     if src:
         shutil.copy(src, os.path.join(pr, f"{tag}_{leg}_kernel_stats.csv"))
