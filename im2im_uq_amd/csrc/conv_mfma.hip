@@ -30,6 +30,11 @@
 #endif
 #include <string>
 #include <type_traits>
+// measurement-only builds (tools/ab_build.sh, never the shipped library): bit 0 = no BatchNorm statistics in the epilogue,
+// bit 1 = the epilogue is one sum + one store per lane, bit 2 = no lazy BatchNorm+ReLU on the staged input
+#ifndef IM2IM_ABLATE
+#define IM2IM_ABLATE 0
+#endif
 
 namespace {
 
@@ -65,12 +70,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 || BN < 128) ? 2 : 1) void con
   constexpr int HROWB = HWD * ROWB + (sizeof(T) == 2 ? 96 : 0);
   constexpr int HIMGB = HH * HROWB;
   constexpr int A_BYTES = TB * HIMGB, B_BYTES = BN * ROWB;
+  constexpr int NBUF = 2;                           // weight buffers (one tap each, double-buffered)
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ldsA = smem;
-  char* ldsB = smem + A_BYTES;                      // two weight buffers
+  char* ldsB = smem + A_BYTES;                      // the weight buffers
   float* ldsS = reinterpret_cast<float*>(smem);     // stats scratch, re-uses A after the main loop
-  float* ldsSS = reinterpret_cast<float*>(smem + A_BYTES + 2 * B_BYTES);   // [2][Ci] input scale/shift (lazy BN+ReLU)
+  float* ldsSS = reinterpret_cast<float*>(smem + A_BYTES + NBUF * B_BYTES);   // [2][Ci] input scale/shift (lazy BN+ReLU)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 || BN < 128) ? 2 : 1) void con
   }
   auto swrite_A = [&](int chunk) {
     const bool lazy_in = (split_in && chunk * KC >= a.Ci_lo) ? lazy_hi : lazy_lo;
-    if (lazy_in) {
+    if (lazy_in && !(IM2IM_ABLATE & 4)) {
       // this thread's pieces all cover the same EPP channels of the chunk: chunk*KC + (tid % PPR)*EPP ...
       const int c0 = chunk * KC + (tid % PPR) * EPP;
       float sc[EPP], sh[EPP];
@@ -307,7 +313,20 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 || BN < 128) ? 2 : 1) void con
   const bool to_hi = a.y_hi != nullptr && ncol >= a.Co_lo;
   T* __restrict__ yg = reinterpret_cast<T*>(to_hi ? a.y_hi : a.y) + (to_hi ? ncol - a.Co_lo : ncol);
   const int ystride = a.y_hi == nullptr ? a.Co : (to_hi ? a.Co - a.Co_lo : a.Co_lo);
-  constexpr bool want_stats = (EPI == 1);
+  constexpr bool want_stats = (EPI == 1) && !(IM2IM_ABLATE & 1);
+#if IM2IM_ABLATE & 2
+  {
+    float t = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[mt][nt][r];
+    yg[(size_t)tile_id * 256 + tid] = from_float<T>(t);
+    return;
+  }
+#endif
   // EPI 3: the producer's z pieces this lane will need in the row-copy loop below are requested NOW, so their HBM
   // latency runs under the accumulator conversion and the LDS transpose instead of stalling each pass
   constexpr int PASSES = WROWS / ROWS_PER_PASS;
@@ -696,15 +715,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 // NEXT pixel tile into registers while the MFMAs of the current one run from LDS; the tile is then written to the
 // other LDS buffer and one barrier per tile separates the two.  (The single-buffered kernel above spends 63 % of
 // its wave cycles waiting on memory; SQ_WAIT_ANY, profiles/.)
-template <int TH, int TW>
+// COT = output channels per workgroup: 64 (a wave = 32 co x 32 ci x 3 taps, 48 accumulators) or 128 [r3] (a wave = 64 co x 32 ci x
+// 3 taps, 96 accumulators: every x fragment feeds two MFMAs, 1.7 transposing LDS reads per MFMA instead of 2.7, and an x tile is
+// fetched once per 128 output channels instead of once per 64).
+template <int TH, int TW, int COT>
 __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
   using T = bf16_t;
   constexpr int NT = 768;
   constexpr int HH = TH + 2, HWD = TW + 2, HPX = HH * HWD;
   constexpr int M = TH * TW;
-  constexpr int CT = 64, EPP = 8, PPR = 8, PB = 192;
-  constexpr int A_BYTES = M * PB, B_BYTES = HPX * PB, BUF_BYTES = A_BYTES + B_BYTES;
-  constexpr int A_ROUNDS = (M * PPR + NT - 1) / NT, B_ROUNDS = (HPX * PPR + NT - 1) / NT;
+  constexpr int CT = 64, EPP = 8, PPR = 8, PB = 192;   // x: 64 input channels per workgroup, 128 B of data + 64 B pad per pixel
+  constexpr int CJ = COT / 64;                         // 32-channel co sub-blocks per wave
+  constexpr int PA = COT * 2 + 64;                     // dz pixel pitch: 192 / 320 B (rows land on distinct 16-bank windows)
+  constexpr int PPRA = COT / 8;                        // 16-byte pieces per dz pixel
+  constexpr int A_BYTES = M * PA, B_BYTES = HPX * PB, BUF_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_ROUNDS = (M * PPRA + NT - 1) / NT, B_ROUNDS = (HPX * PPR + NT - 1) / NT;
   constexpr int KSTEPS = M / 16;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -726,16 +751,18 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
     cb = j % (int)gridDim.x;
   }
 #endif
-  const int co0 = (cb / ci_tiles) * CT, ci0 = (cb % ci_tiles) * CT;
+  const int co0 = (cb / ci_tiles) * COT, ci0 = (cb % ci_tiles) * CT;
   const WgradSrc<T> xs(a, ci0);
   const T* __restrict__ xg = xs.x;
   const T* __restrict__ dzg = reinterpret_cast<const T*>(a.dz);
 
-  f32x16 acc[3];
+  f32x16 acc[CJ][3];
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+  for (int j = 0; j < CJ; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
 
   const int q = lane & 15;
   const int tr_col_b = (((lane >> 4) & 1) * 16 + (q & 3) * 4) * 2;
@@ -744,16 +771,25 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
   // staging pieces of this thread (tile-independent parts)
   int a_px[A_ROUNDS], a_part[A_ROUNDS], b_px[B_ROUNDS], b_part[B_ROUNDS];
 #pragma unroll
-  for (int i = 0; i < A_ROUNDS; ++i) { const int p = i * NT + tid; a_px[i] = (p < M * PPR) ? p / PPR : -1; a_part[i] = p % PPR; }
+  for (int i = 0; i < A_ROUNDS; ++i) { const int p = i * NT + tid; a_px[i] = (p < M * PPRA) ? p / PPRA : -1; a_part[i] = p % PPRA; }
 #pragma unroll
   for (int i = 0; i < B_ROUNDS; ++i) { const int p = i * NT + tid; b_px[i] = (p < HPX * PPR) ? p / PPR : -1; b_part[i] = p % PPR; }
   uint4 ra[A_ROUNDS], rb[B_ROUNDS];
   unsigned b_valid = 0;                              // bit i: rb[i] holds real pixels (not zero padding)
-  float xsc[EPP], xsh[EPP];                          // this thread's pieces always cover channels ci0 + (tid % 8)*8 ...
+  // lazy BatchNorm coefficients of the 64 input channels: in registers (COT = 64) or, where the 96 accumulators leave no room
+  // for 16 more live values, in LDS behind the tile buffers and read back per tile (COT = 128)
+  constexpr bool SS_LDS = COT > 64;
+  float xsc[SS_LDS ? 1 : EPP], xsh[SS_LDS ? 1 : EPP];   // this thread's pieces always cover channels ci0 + (tid % 8)*8 ...
+  float* ldsSS = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);
   const bool lazy_x = xs.sc != nullptr;
   if (lazy_x) {
+    if constexpr (SS_LDS) {
+      if (tid < CT) { ldsSS[tid] = xs.sc[tid]; ldsSS[CT + tid] = xs.sh[tid]; }
+      __syncthreads();
+    } else {
 #pragma unroll
-    for (int k = 0; k < EPP; ++k) { xsc[k] = xs.sc[(tid % PPR) * EPP + k]; xsh[k] = xs.sh[(tid % PPR) * EPP + k]; }
+      for (int k = 0; k < EPP; ++k) { xsc[k] = xs.sc[(tid % PPR) * EPP + k]; xsh[k] = xs.sh[(tid % PPR) * EPP + k]; }
+    }
   }
 
   auto gload = [&](int t) {
@@ -792,7 +828,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
     char* la = smem + buf * BUF_BYTES;
     char* lb = la + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < A_ROUNDS; ++i) if (a_px[i] >= 0) *reinterpret_cast<uint4*>(la + a_px[i] * PB + a_part[i] * 16) = ra[i];
+    for (int i = 0; i < A_ROUNDS; ++i) if (a_px[i] >= 0) *reinterpret_cast<uint4*>(la + a_px[i] * PA + a_part[i] * 16) = ra[i];
 #pragma unroll
     for (int i = 0; i < B_ROUNDS; ++i) {
       if (b_px[i] >= 0) {
@@ -800,8 +836,14 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
         if (lazy_x && ((b_valid >> i) & 1)) {
           float f[EPP];
           Vec16<T>::load(reinterpret_cast<const T*>(&v), f);
+          if constexpr (SS_LDS) {
+            const int c0 = (tid % PPR) * EPP;
 #pragma unroll
-          for (int k = 0; k < EPP; ++k) f[k] = fmaxf(f[k] * xsc[k] + xsh[k], 0.f);
+            for (int k = 0; k < EPP; ++k) f[k] = fmaxf(f[k] * ldsSS[c0 + k] + ldsSS[CT + c0 + k], 0.f);
+          } else {
+#pragma unroll
+            for (int k = 0; k < EPP; ++k) f[k] = fmaxf(f[k] * xsc[k] + xsh[k], 0.f);
+          }
           Vec16<T>::store(reinterpret_cast<T*>(&v), f);
         }
         *reinterpret_cast<uint4*>(lb + b_px[i] * PB + b_part[i] * 16) = v;
@@ -814,15 +856,18 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
     // k-step ks covers tile row ks (TW == 16): every address below is lane base + compile-time constant, so the fully
     // unrolled loop has no address arithmetic (it was ~5 VALU per MFMA when only partially unrolled)
     static_assert(TW == 16, "k-step == one 16-pixel tile row");
-    const char* pa = la + (half * 8 + tr_row) * PB + wco * 64 + tr_col_b;
+    const char* pa = la + (half * 8 + tr_row) * PA + wco * (COT / 2) * 2 + tr_col_b;
     const char* pb = lb + (half * 8 + tr_row) * PB + wci * 64 + tr_col_b;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      const short8 fa = WFrag<bf16_t>::load(pa + ks * 16 * PB, pa + (ks * 16 + 4) * PB);
+      short8 fa[CJ];
+#pragma unroll
+      for (int j = 0; j < CJ; ++j) fa[j] = WFrag<bf16_t>::load(pa + j * 64 + ks * 16 * PA, pa + j * 64 + (ks * 16 + 4) * PA);
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const short8 fb = WFrag<bf16_t>::load(pb + (ks * HWD + kw) * PB, pb + (ks * HWD + kw + 4) * PB);
-        acc[kw] = WFrag<bf16_t>::mfma(fa, fb, acc[kw]);
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) acc[j][kw] = WFrag<bf16_t>::mfma(fa[j], fb, acc[j][kw]);
       }
     }
   };
@@ -845,13 +890,15 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
   }
   float* out = a.partial + (size_t)split * a.Co * 9 * a.Ci;
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw)
+  for (int j = 0; j < CJ; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int ci = ci0 + wci * 32 + l31;
-      if (co < a.Co) out[((size_t)co * 9 + tg * 3 + kw) * a.Ci + ci] = acc[kw][r];
-    }
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wco * (COT / 2) + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int ci = ci0 + wci * 32 + l31;
+        if (co < a.Co) out[((size_t)co * 9 + tg * 3 + kw) * a.Ci + ci] = acc[j][kw][r];
+      }
 }
 
 // sum partial[nsplit][Co][TAPS][Ci] over splits and write torch layout dw[Co][Ci][TAPS].  Block = 64 outputs x 4 split
@@ -1097,6 +1144,7 @@ extern "C" int im2im_conv_dgrad_bn(const void* dz, const void* wd, void* dx, con
 }
 
 namespace {
+int g_wgrad_co128 = 1;      // A/B switch (im2im_set_option "wgrad_co128")
 template <typename T, int TAPS>
 int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float* x_ss_hi, int Ci_lo, const void* dz, float* partial,
                  int64_t partial_bytes, float* dw, int B, int H, int W, int Ci, int Co, hipStream_t stream) {
@@ -1120,8 +1168,27 @@ int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float
   const bool pipe = IS_BF16 && TAPS == 9 && Ci % 64 == 0;   // the pipelined kernel has no channel masking
   if (pipe) {
    if constexpr (IS_BF16 && TAPS == 9) {
+    const bool wide = g_wgrad_co128 && Co % 128 == 0;         // 128 output channels per workgroup (see the kernel)
+    if (wide) {
+      const int cb128 = (Co / 128) * (Ci / 64);
+      nsplit = cdiv(256, cb128);
+      if (nsplit > a.ntiles) nsplit = a.ntiles;
+      if (nsplit > max_split) nsplit = max_split;
+      if (nsplit < 1) nsplit = 1;
+      a.tiles_per_split = (int)cdiv(a.ntiles, nsplit);
+      nsplit = cdiv(a.ntiles, a.tiles_per_split);
+      constexpr size_t smem128 = 2 * ((size_t)TH * TW * (128 * 2 + 64) + (size_t)(TH + 2) * (TW + 2) * 192) + 512;
+      auto kern = conv_wgrad_pipe_kernel<TH, TW, 128>;
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem128);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)cb128, (unsigned)nsplit), dim3(768), smem128, stream, a);
+      if (int rc = check_launch("conv_wgrad_pipe_kernel<128>")) return rc;
+    } else {
     constexpr size_t smem2 = 2 * smem;                        // double-buffered tiles, one 12-wave workgroup per CU
-    auto kern = conv_wgrad_pipe_kernel<TH, TW>;
+    auto kern = conv_wgrad_pipe_kernel<TH, TW, 64>;
     static bool attr_set = false;
     if (!attr_set) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
@@ -1129,6 +1196,7 @@ int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)cblocks, (unsigned)nsplit), dim3(768), smem2, stream, a);
     if (int rc = check_launch("conv_wgrad_pipe_kernel")) return rc;
+    }
    }
   } else {
     auto kern = conv_wgrad_kernel<T, TH, TW, TAPS>;
@@ -1209,6 +1277,7 @@ extern "C" int im2im_pack_conv_weight(const float* w, int32_t Co, int32_t Ci, in
 extern "C" int im2im_set_option(const char* key, int32_t value) {
   IM2IM_REQUIRE(key != nullptr);
   if (std::string(key) == "conv_pp") { im2im::set_conv_pp_mode(value); return IM2IM_OK; }
+  if (std::string(key) == "wgrad_co128") { g_wgrad_co128 = value; return IM2IM_OK; }
   return im2im::fail_invalid("unknown option");
 }
 
