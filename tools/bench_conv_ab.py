@@ -1,6 +1,6 @@
 """within-process A/B of conv kernel variants on the BASELINE layer shapes (batch 78, bf16): the 4-wave kernel
 (conv_pp = 0) against the 8-wave ping-pong kernel (conv_pp = 3), interleaved rounds, median of the per-round times.
-    python tools/bench_conv_ab.py [batch] [rounds] [modes, e.g. 0,3]"""
+    python tools/bench_conv_ab.py [batch] [rounds] [modes, e.g. 0,3] [option key, default conv_pp; e.g. conv_persistent]"""
 import os
 import statistics
 import sys
@@ -14,6 +14,7 @@ dev = "cuda:0"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 78
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 modes = [int(m) for m in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 3]
+KEY = sys.argv[4] if len(sys.argv) > 4 else "conv_pp"
 # (h, ci, co, split_in, kind)  kind: fwd = forward + statistics + lazy input; dgrad = plain store
 LAYERS = [(320, 64, 64, False, "fwd"), (320, 128, 64, True, "fwd"), (320, 64, 64, False, "dgrad"), (320, 64, 128, False, "dgrad_split"),
           (160, 64, 128, False, "fwd"), (160, 128, 128, False, "fwd"), (160, 256, 128, True, "fwd"), (160, 128, 128, False, "dgrad"),
@@ -38,12 +39,12 @@ for (h, ci, co, split, kind) in LAYERS:
         fn = lambda: nn_ops.conv_fwd(x, wf)
     times = {m: [] for m in modes}
     for m in modes:
-        hip_ops.set_option("conv_pp", m)
+        hip_ops.set_option(KEY, m)
         for _ in range(2):
             fn()
     for r in range(rounds):
         for m in modes:
-            hip_ops.set_option("conv_pp", m)
+            hip_ops.set_option(KEY, m)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
