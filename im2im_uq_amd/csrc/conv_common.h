@@ -38,6 +38,16 @@ struct ConvArgs {
   int pp_group_bytes, pp_ntiles, pp_flags;
 };
 
+// Packed bf16 3x3 weights are FRAGMENT-MAJOR: the 32 rows x 16 reduction channels one lane-set of v_mfma_f32_32x32x16_bf16
+// consumes form one contiguous 1 KiB block, lane (half*32 + row%32) owning 16 bytes, so a wave fetches a whole operand
+// fragment from L2 with a single fully coalesced global_load_dwordx4 (conv_mfma.hip reads them straight into registers).
+// Blocks are ordered [row block of 32][tap][32-channel chunk][k-step].  N x 9 x K logical tensor, K % 32 == 0, N % 32 == 0.
+__host__ __device__ inline size_t wfrag_index(int n, int tap, int k, int K) {
+  const int nch = K >> 5;
+  return ((((size_t)(n >> 5) * 9 + tap) * nch + (k >> 5)) * 2 + ((k >> 4) & 1)) * 512 + ((((k >> 3) & 1) * 32 + (n & 31)) * 8) + (k & 7);
+}
+inline bool wfrag_layout(int elem_bytes, int taps, int Co, int Ci) { return elem_bytes == 2 && taps == 9 && Co % 32 == 0 && Ci % 32 == 0; }
+
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> {
   using AB = short8;

@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
     const int m = wm * WROWS + row;
     const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
     if (bb < a.B && yy < a.H && xx < a.W)
-      *reinterpret_cast<uint4*>(yg + (((size_t)bb * a.H + yy) * a.W + xx) * ystride + piece * EPP) = v;
+      __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(yg + (((size_t)bb * a.H + yy) * a.W + xx) * ystride + piece * EPP));
   }
   if (want_stats) {
     __syncthreads();

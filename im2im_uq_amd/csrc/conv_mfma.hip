@@ -46,11 +46,11 @@ using namespace im2im;
 //      addresses and accumulate sum(g) and sum(g*xhat), g = da*[z*scale+shift > 0] -- bn_relu_bwd_reduce without its
 //      own pass over da and z.  Compile-time so the 128 values per lane pay only for what
 //      the launch needs (the generic epilogue was ~10 VALU per value; the data-gradient needs ~1).
-// bf16: two workgroups per CU (256 registers per lane each).  fp32: the operand buffers are twice as large (84-94 KB for
+// bf16: two workgroups per CU (256 registers per lane each), three for the 64- and 32-channel-wide tiles (168 registers).  fp32: the operand buffers are twice as large (84-94 KB for
 // the 128-wide tiles), so only one workgroup fits a CU anyway -- it may then use the whole 512-entry register file
 // instead of spilling 150-540 registers to scratch as it did under the two-workgroup bound.
 template <typename T, int TB, int TH, int TW, int BN, int WM, int WN, int TAPS, int EPI>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 || BN < 128) ? 2 : 1) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (BN < 128 ? 3 : 2) : (BN < 128 ? 2 : 1))) void conv_igemm_kernel(ConvArgs a) {
   constexpr int PAD = (TAPS == 9) ? 1 : 0;
   constexpr int HH = TH + 2 * PAD, HWD = TW + 2 * PAD, HPI = HH * HWD, HPX = TB * HPI;   // halo pixels per image / per tile
   constexpr int MI = TH * TW;                         // output pixels per image in the tile
@@ -70,6 +70,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 || BN < 128) ? 2 : 1) void con
   constexpr int HROWB = HWD * ROWB + (sizeof(T) == 2 ? 96 : 0);
   constexpr int HIMGB = HH * HROWB;
   constexpr int A_BYTES = TB * HIMGB, B_BYTES = BN * ROWB;
+  constexpr bool FRAGW = sizeof(T) == 2 && TAPS == 9;   // packed weights are fragment-major (conv_common.h wfrag_index)
+  // ... and read straight from L2 into registers where a fragment feeds MT = 4 MFMAs.  With MT = 2 (4 x 1 waves on a 64-wide
+  // tile, three workgroups per CU) the same loads saturate the CU's load path (16 KiB per workgroup and tap): 750 vs 847 TF on
+  // the 320x320 64->64 data-gradient; such tiles stage the weights through LDS once per workgroup.  (A 2 x 2 wave split of the
+  // 64-wide tile, MT = 4 / NT = 1 with direct weights, measured 6-14 % slower than that on the three 64-output-channel layers.)
+  constexpr bool DIRECTW = FRAGW && MT >= 4;
   constexpr int NBUF = 2;                           // weight buffers (one tap each, double-buffered)
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -168,7 +174,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 || BN < 128) ? 2 : 1) void con
   for (int i = 0; i < B_ROUNDS; ++i) {
     const int p = i * 256 + tid;
     const int n = p / PPR, part = p % PPR;
-    b_goff[i] = (n < BN) ? (n * TAPS * a.Ci + part * EPP) : -1;
+    if constexpr (FRAGW) b_goff[i] = (n < BN) ? (int)(wfrag_index(n0 + n, 0, part * EPP, a.Ci) - (size_t)n0 * TAPS * a.Ci) : -1;   // fragment-major pack
+    else b_goff[i] = (n < BN) ? (n * TAPS * a.Ci + part * EPP) : -1;
     b_loff[i] = (n < BN) ? n * ROWB + part * 16 : -1;
   }
 
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 || BN < 128) ? 2 : 1) void con
       if ((HPX * PPR) % 256 == 0 || a_loff[i] >= 0) *reinterpret_cast<uint4*>(ldsA + a_loff[i]) = ra[i];
   };
   auto gload_B = [&](uint4 (&r)[B_ROUNDS], int chunk, int tap) {
-    const T* src = wg_tile + (tap * a.Ci + chunk * KC);
+    const T* src = wg_tile + (FRAGW ? ((tap * (a.Ci >> 5) + chunk) << 10) : (tap * a.Ci + chunk * KC));
 #pragma unroll
     for (int i = 0; i < B_ROUNDS; ++i) {
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -252,7 +259,58 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 || BN < 128) ? 2 : 1) void con
   };
 
   const int nchunks = a.Ci / KC;
-  if constexpr (TAPS == 9) {
+  if constexpr (DIRECTW) {
+    // bf16 3x3, 128-channel-wide tiles: the weight operand never touches LDS.  The packed weights are fragment-major (conv_common.h): a wave reads
+    // each 32 x 16 operand fragment of its NT channel blocks straight from L2 into registers with one coalesced 1 KiB load, one
+    // tap ahead of its use.  Only the halo goes through LDS, so a chunk's nine taps (18 k-steps) run between two barriers
+    // instead of ten, with no weight ds_write / ds_read at all (tools/hwprobe/directb_probe.hip measured the loop shape).
+    using AB = typename Frag<T>::AB;
+    AB fw[2][2][NT];                                   // [register set][k-step][channel block]
+    const size_t cob_stride = (size_t)9 * nchunks * 1024;                 // elements per 32-row block
+    const T* __restrict__ wfr = wg + (size_t)(n0 / 32 + wn * NT) * cob_stride + lane * 8;
+    auto gload_F = [&](AB (&f)[2][NT], int chunk, int tap) __attribute__((always_inline)) {
+      const T* p = wfr + ((size_t)(tap * nchunks + chunk) << 10);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) f[ks][nt] = *reinterpret_cast<const AB*>(p + nt * cob_stride + ks * 512);
+    };
+    auto compute_F = [&](int toff, const AB (&f)[2][NT]) __attribute__((always_inline)) {
+      const char* pa = ldsA + toff;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        AB fa[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) fa[mt] = Frag<T>::load(pa + aoff[mt], ks, half);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Frag<T>::mfma(fa[mt], f[ks][nt], acc[mt][nt]);
+      }
+    };
+    gload_A(0);
+    gload_F(fw[0], 0, 0);
+    auto chunk_body = [&](auto parity, int chunk) __attribute__((always_inline)) {
+      constexpr int P0 = decltype(parity)::value;        // 9 taps per chunk: the register-set parity of a chunk's first tap alternates
+      const bool more = chunk + 1 < nchunks;
+      if (chunk) __syncthreads();                      // everyone done reading the previous halo
+      swrite_A(chunk);
+      __syncthreads();
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        constexpr int dummy = 0; (void)dummy;
+        const int set = (P0 + tap) & 1;                  // compile-time after unrolling
+        if (tap + 1 < 9) { if (set) gload_F(fw[0], chunk, tap + 1); else gload_F(fw[1], chunk, tap + 1); }
+        else if (more) { if (set) gload_F(fw[0], chunk + 1, 0); else gload_F(fw[1], chunk + 1, 0); }
+        if (tap == 6 && more) gload_A(chunk + 1);        // the next chunk's halo, three taps early
+        if (set) compute_F((tap / 3) * HROWB + (tap % 3) * ROWB, fw[1]); else compute_F((tap / 3) * HROWB + (tap % 3) * ROWB, fw[0]);
+      }
+    };
+    for (int chunk = 0; chunk < nchunks; chunk += 2) {
+      chunk_body(std::integral_constant<int, 0>{}, chunk);
+      if (chunk + 1 < nchunks) chunk_body(std::integral_constant<int, 1>{}, chunk + 1);
+    }
+  } else if constexpr (TAPS == 9) {
     // 9 taps fully unrolled (every register-set / LDS-buffer index and tap offset is a compile-time constant).
     // Weight tiles are prefetched TWO iterations ahead: iteration `it` writes register set it&1 (loaded at it-2)
     // to LDS buffer it&1 and immediately re-issues that set for it+2.  9 is odd, so the parity of a chunk's first
@@ -427,7 +485,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 || BN < 128) ? 2 : 1) void con
     const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
     if (bb < a.B && yy < a.H && xx < a.W) {
       const size_t off = (((size_t)bb * a.H + yy) * a.W + xx) * ystride + piece * EPP;
-      *reinterpret_cast<uint4*>(yg + off) = v;
+      // streamed: the tile is not read again by this kernel and is far larger than L2 (+2 % over the 13 BASELINE layers)
+      __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(yg + off));
       if constexpr (EPI == 3) {
         float g[EPP], zz[EPP];
         Vec16<T>::load(reinterpret_cast<const T*>(&v), g);
@@ -953,15 +1012,21 @@ template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, int Co, int Ci, int taps,
                                                            T* __restrict__ wf, T* __restrict__ wd) {
   const size_t total = (size_t)Co * Ci * taps;
+  const bool frag = sizeof(T) == 2 && taps == 9 && Co % 32 == 0 && Ci % 32 == 0;      // wfrag_layout (conv_common.h)
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    // i indexes wf: (co, tp, ci)
+    // i indexes the logical wf: (co, tp, ci)
     const int ci = (int)(i % Ci);
     const size_t r = i / Ci;
     const int tp = (int)(r % taps);
     const size_t co = r / taps;
     const T v = from_float<T>(w[(co * Ci + ci) * taps + tp]);
-    wf[i] = v;
-    if (wd) wd[((size_t)ci * taps + (taps - 1 - tp)) * Co + co] = v;
+    if (frag) {
+      wf[wfrag_index((int)co, tp, ci, Ci)] = v;
+      if (wd) wd[wfrag_index(ci, taps - 1 - tp, (int)co, Co)] = v;
+    } else {
+      wf[i] = v;
+      if (wd) wd[((size_t)ci * taps + (taps - 1 - tp)) * Co + co] = v;
+    }
   }
 }
 
@@ -980,6 +1045,7 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(PackMultiArgs a)
   int t = 0;
   while (t + 1 < a.n && chunk >= a.start[t + 1]) ++t;
   const int Co = a.Co[t], Ci = a.Ci[t], taps = a.taps[t];
+  const bool frag = sizeof(T) == 2 && taps == 9 && Co % 32 == 0 && Ci % 32 == 0;
   const size_t total = (size_t)Co * Ci * taps;
   const float* __restrict__ w = a.w[t];
   T* __restrict__ wf = reinterpret_cast<T*>(a.wf[t]);
@@ -993,8 +1059,13 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(PackMultiArgs a)
       const int tp = (int)(r % taps);
       const size_t co = r / taps;
       const T v = from_float<T>(w[(co * Ci + ci) * taps + tp]);
-      wf[i] = v;
-      if (wd) wd[((size_t)ci * taps + (taps - 1 - tp)) * Co + co] = v;
+      if (frag) {
+        wf[wfrag_index((int)co, tp, ci, Ci)] = v;
+        if (wd) wd[wfrag_index(ci, taps - 1 - tp, (int)co, Co)] = v;
+      } else {
+        wf[i] = v;
+        if (wd) wd[((size_t)ci * taps + (taps - 1 - tp)) * Co + co] = v;
+      }
     }
   }
 }

@@ -205,9 +205,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
     return *reinterpret_cast<const int2*>(smem + oOFF + (i * 256 + t) * 8);
   };
   // weight piece i of this thread: row n = i*64 + t/4, 16-byte part t%4 -> global offset b_goff0 + i*64*9*Ci, LDS b_loff0 + i*64*ROWB
-  const int b_goff0 = (t / PPR) * TAPS * aCi + (t % PPR) * EPP;
+  // (fragment-major packed weights, conv_common.h wfrag_index: row n0 + i*64 + t/4, channels (t%4)*8.. of the chunk)
+  const int b_goff0 = (int)wfrag_index(n0 + t / PPR, 0, (t % PPR) * EPP, aCi);
   const int b_loff0 = (t / PPR) * ROWB + (t % PPR) * 16;
-  const int b_gstep = 64 * TAPS * aCi;
+  const int b_gstep = 64 * TAPS * aCi;                 // 64 rows = two row blocks of 9 * (Ci/32) * 1024 elements
 
   if (LAZY) {
     const int clo = split_in ? aCi_lo : aCi, chi = aCi - clo;
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
   };
   auto gload_B = [&](int gt) __attribute__((always_inline)) {                       // gt = global tap index = chunk*9 + tap
     const int chunk = gt / 9, tap = gt - chunk * 9;
-    const T* src = wg_tile + (tap * aCi + chunk * KC) + b_goff0;
+    const T* src = wg + ((tap * (aCi >> 5) + chunk) << 10) + b_goff0;
     rb0 = *reinterpret_cast<const uint4*>(src);
     if constexpr (B_ROUNDS > 1) rb1 = *reinterpret_cast<const uint4*>(src + b_gstep);
   };
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
     const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
     if (!ghost && bb < aB && yy < aH && xx < aW) {
       const size_t off = (((size_t)bb * aH + yy) * aW + xx) * ystride + pc * EPP;
-      *reinterpret_cast<uint4*>(yg + off) = v;
+      __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(yg + off));
     }
   }
   if (want_stats) {

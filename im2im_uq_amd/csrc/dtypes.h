@@ -11,6 +11,7 @@ typedef short short4v __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(3))) short4v lds_short4;
 
@@ -33,6 +34,11 @@ template <> struct Vec16<float> {
   static __device__ __forceinline__ void store(float* p, const float* in) {
     *reinterpret_cast<float4*>(p) = make_float4(in[0], in[1], in[2], in[3]);
   }
+  // streamed (non-temporal) form for tensors far larger than L2 that this kernel does not read again
+  static __device__ __forceinline__ void store_nt(float* p, const float* in) {
+    f32x4 v = {in[0], in[1], in[2], in[3]};
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+  }
 };
 template <> struct Vec16<bf16_t> {
   static constexpr int N = 8;
@@ -53,6 +59,15 @@ template <> struct Vec16<bf16_t> {
       w[i] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
     }
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  static __device__ __forceinline__ void store_nt(bf16_t* p, const float* in) {
+    u32x4 w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16_t lo = (bf16_t)in[2 * i], hi = (bf16_t)in[2 * i + 1];
+      w[i] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+    }
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(p));
   }
 };
 

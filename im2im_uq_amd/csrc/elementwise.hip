@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restr
       const float xhat = (zz[k] - mu[k]) * is[k];
       o[k] = sc[k] * (gg - k1[k] - xhat * k2[k]);
     }
-    Vec16<T>::store(dz + i * N, o);
+    Vec16<T>::store_nt(dz + i * N, o);
   };
   const int64_t stride = (int64_t)gridDim.x * 256;
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
       lz.apply(v00); lz.apply(v01); lz.apply(v10); lz.apply(v11);
 #pragma unroll
       for (int k = 0; k < N; ++k) o[k] = fmaxf(fmaxf(v00[k], v01[k]), fmaxf(v10[k], v11[k]));
-      Vec16<T>::store(y + (((int64_t)row * Wo + xo) * C) + cv * N, o);
+      Vec16<T>::store_nt(y + (((int64_t)row * Wo + xo) * C) + cv * N, o);
     }
   }
 }
@@ -702,16 +702,16 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
 #pragma unroll
           for (int q = 0; q < 4; ++q) o[q][k] = (am == q) ? g[k] : 0.f;
         }
-        Vec16<T>::store(dx + base, o[0]);
-        Vec16<T>::store(dx + base + C, o[1]);
-        Vec16<T>::store(dx + base + (int64_t)W * C, o[2]);
-        Vec16<T>::store(dx + base + (int64_t)W * C + C, o[3]);
+        Vec16<T>::store_nt(dx + base, o[0]);
+        Vec16<T>::store_nt(dx + base + C, o[1]);
+        Vec16<T>::store_nt(dx + base + (int64_t)W * C, o[2]);
+        Vec16<T>::store_nt(dx + base + (int64_t)W * C + C, o[3]);
       } else {
         // odd tail: positions not covered by any window
         for (int dyy = 0; dyy < 2; ++dyy)
           for (int dxx = 0; dxx < 2; ++dxx) {
             const int yy = 2 * yo + dyy, xx = 2 * xo + dxx;
-            if (yy < H && xx < W) Vec16<T>::store(dx + ((((int64_t)b * H + yy) * W + xx) * (int64_t)C) + cv * N, z);
+            if (yy < H && xx < W) Vec16<T>::store_nt(dx + ((((int64_t)b * H + yy) * W + xx) * (int64_t)C) + cv * N, z);
           }
       }
     }
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const T* __restri
           if constexpr (APPLY) o[k] = sc[k] * (gg - k1[k] - xhat * k2[k]);
           else { s1[k] += gg; s2[k] += gg * xhat; }
         }
-        if constexpr (APPLY) Vec16<T>::store(dz + off[q], o);
+        if constexpr (APPLY) Vec16<T>::store_nt(dz + off[q], o);
       }
     }
   }
@@ -860,7 +860,7 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ de
           Vec16<T>::load(sp, v);
           const LazySS<N> lz(skip_ss, Cs, cv * N);
           lz.apply(v);
-          Vec16<T>::store(op, v);
+          Vec16<T>::store_nt(op, v);
         } else {
           *reinterpret_cast<uint4*>(op) = *reinterpret_cast<const uint4*>(sp);
         }
@@ -901,7 +901,7 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ de
 #pragma unroll
         for (int k = 0; k < N; ++k) o[k] = ly0 * (lx0 * v00[k] + lx1 * v01[k]) + ly1 * (lx0 * v10[k] + lx1 * v11[k]);
       }
-      Vec16<T>::store(op, o);
+      Vec16<T>::store_nt(op, o);
     }
   }
 }
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(256) void upcat_bwd_kernel(const T* __restrict__ do
           for (int k = 0; k < N; ++k) acc[k] += ww * g[k];
         }
       }
-      Vec16<T>::store(ddeep + (((int64_t)r * w + xi) * (int64_t)Cd) + cv * N, acc);
+      Vec16<T>::store_nt(ddeep + (((int64_t)r * w + xi) * (int64_t)Cd) + cv * N, acc);
     }
   }
 }
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(256) void up2x_fwd_tiled_kernel(const T* __restrict
         o[k + 3] = ly0 * (lx0 * a.w + lx1 * bq.w) + ly1 * (lx0 * cq.w + lx1 * dq.w);
       }
     }
-    Vec16<T>::store(out + ((((int64_t)b * H + y) * W + x) * (int64_t)Ct) + c_off + c_base + cv * N, o);
+    Vec16<T>::store_nt(out + ((((int64_t)b * H + y) * W + x) * (int64_t)Ct) + c_off + c_base + cv * N, o);
   }
 }
 
@@ -1203,7 +1203,7 @@ __global__ __launch_bounds__(256) void up2x_bwd_tiled_kernel(const T* __restrict
         acc[k] += wv * a.x; acc[k + 1] += wv * a.y; acc[k + 2] += wv * a.z; acc[k + 3] += wv * a.w;
       }
     }
-    Vec16<T>::store(ddeep + ((((int64_t)b * h + yi) * w + xi) * (int64_t)Cd) + c_base + cv * N, acc);
+    Vec16<T>::store_nt(ddeep + ((((int64_t)b * h + yi) * w + xi) * (int64_t)Cd) + c_base + cv * N, acc);
   }
 }
 

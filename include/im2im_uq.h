@@ -135,6 +135,10 @@ int im2im_set_option(const char* key, int32_t value);
  * im2im_pack_conv_weight: w [Co][Ci][taps] fp32 (torch parameter layout, taps = kh*3+kw) ->
  *   wf [Co][taps][Ci]            operand of the forward conv
  *   wd [Ci][taps reversed][Co]   operand of dgrad (= forward conv of dz with flipped taps); may be NULL
+ * The packed buffers are opaque operands of the conv entry points (same element counts as above).  For bf16 3x3 weights
+ * with Co % 32 == 0 and Ci % 32 == 0 the storage order is fragment-major -- [row block of 32][tap][32-channel chunk]
+ * [16-channel k-step][lane 64][8] -- so that a wave reads one MFMA operand fragment with a single coalesced 1 KiB load
+ * (csrc/conv_common.h wfrag_index); everything else is stored in the logical order.
  */
 int im2im_pack_conv_weight(const float* w, int32_t Co, int32_t Ci, int32_t taps, int32_t dtype,
                            void* wf, void* wd, im2im_stream_t stream);
