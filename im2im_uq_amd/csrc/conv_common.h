@@ -88,6 +88,9 @@ struct TileChoice { int tb, th, tw, bn; };
 inline TileChoice pick_tile(int H, int W, int Co, bool per_image = false) {
   const bool small = (H < 64 || W < 64) && !per_image;       // per_image: every tile (and its statistics row) lies in ONE image
   const int bn = (Co % 128 == 0) ? 128 : (Co % 64 == 0) ? 64 : 32;
+  // 64 output channels (the full-resolution layers): 32 x 16 pixels, so that a wave owns 128 pixels x 64 channels and a weight
+  // fragment read from L2 feeds four MFMAs as in the 128-wide tiles (conv_mfma.hip DIRECTW)
+  if (!small && bn == 64 && !per_image && H % 32 == 0) return {1, 32, 16, bn};
   if (!small) return {1, 16, 16, bn};
   return TileChoice{4, 8, 8, bn};
 }

@@ -40,6 +40,10 @@ namespace {
 
 using namespace im2im;
 
+// workgroups per CU a variant is compiled for, by its accumulator registers per lane: bf16 128 -> 2 (256 registers each),
+// 64 or fewer -> 3 (168); fp32 (operand buffers twice as large) 128 -> 1 (the whole 512-entry file), fewer -> 2
+template <typename T, int ACC> constexpr int igemm_wgs_per_cu() { return sizeof(T) == 2 ? (ACC >= 128 ? 2 : 3) : (ACC >= 128 ? 1 : 2); }
+
 // EPI: 0 = (+bias) store only [data-gradient, 1x1 conv]; 1 = +bias, store, BatchNorm partial statistics [train forward];
 //      2 = folded BatchNorm affine + ReLU [eval forward];  3 = data-gradient that also starts the BatchNorm+ReLU backward
 //      of the layer it differentiates into: while the rows go out, the same lanes read the producer's z at the same
@@ -50,7 +54,7 @@ using namespace im2im;
 // the 128-wide tiles), so only one workgroup fits a CU anyway -- it may then use the whole 512-entry register file
 // instead of spilling 150-540 registers to scratch as it did under the two-workgroup bound.
 template <typename T, int TB, int TH, int TW, int BN, int WM, int WN, int TAPS, int EPI>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (BN < 128 ? 3 : 2) : (BN < 128 ? 2 : 1))) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (igemm_wgs_per_cu<T, TB * TH * TW / (32 * WM) * (BN / (32 * WN)) * 16>())) void conv_igemm_kernel(ConvArgs a) {
   constexpr int PAD = (TAPS == 9) ? 1 : 0;
   constexpr int HH = TH + 2 * PAD, HWD = TW + 2 * PAD, HPI = HH * HWD, HPX = TB * HPI;   // halo pixels per image / per tile
   constexpr int MI = TH * TW;                         // output pixels per image in the tile
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (BN < 128 ? 3 : 2) : (BN < 1
     b_loff[i] = (n < BN) ? n * ROWB + part * 16 : -1;
   }
 
-  auto gload_A = [&](int chunk) {
+  auto gload_A = [&](int chunk) __attribute__((always_inline)) {
     const int c = chunk * KC;
     const T* src = (split_in && c >= a.Ci_lo) ? xh_tile + (c - a.Ci_lo) : xg_tile + c;
 #pragma unroll
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (BN < 128 ? 3 : 2) : (BN < 1
     if (lazy_hi) for (int i = tid; i < chi; i += 256) { ldsSS[clo + i] = a.in_ss_hi[i]; ldsSS[a.Ci + clo + i] = a.in_ss_hi[chi + i]; }
     __syncthreads();
   }
-  auto swrite_A = [&](int chunk) {
+  auto swrite_A = [&](int chunk) __attribute__((always_inline)) {
     const bool lazy_in = (split_in && chunk * KC >= a.Ci_lo) ? lazy_hi : lazy_lo;
     if (lazy_in && !(IM2IM_ABLATE & 4)) {
       // this thread's pieces all cover the same EPP channels of the chunk: chunk*KC + (tid % PPR)*EPP ...
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (BN < 128 ? 3 : 2) : (BN < 1
     for (int i = 0; i < B_ROUNDS; ++i)
       if ((BN * PPR) % 256 == 0 || b_loff[i] >= 0) *reinterpret_cast<uint4*>(ldsB + buf * B_BYTES + b_loff[i]) = r[i];
   };
-  auto compute = [&](int toff, int buf) {
+  auto compute = [&](int toff, int buf) __attribute__((always_inline)) {
     const char* pa = ldsA + toff;
     const char* pb = ldsB + buf * B_BYTES;
 #pragma unroll
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (BN < 128 ? 3 : 2) : (BN < 1
       cnt = (float)__popcll(okmask);
     }
   }
-  auto convert_tile = [&](auto full_tag) {
+  auto convert_tile = [&](auto full_tag) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -1116,6 +1120,7 @@ int dispatch_conv(const ConvArgs& a, hipStream_t stream, bool per_image = false)
   const TileChoice t = pick_tile(a.H, a.W, a.Co, per_image);
   if (t.tb == 1) {
     if (t.bn == 128) return launch_conv<T, 1, 16, 16, 128, 2, 2, TAPS>(a, stream);
+    if (t.bn == 64 && t.th == 32) return launch_conv<T, 1, 32, 16, 64, 4, 1, TAPS>(a, stream);
     if (t.bn == 64) return launch_conv<T, 1, 16, 16, 64, 4, 1, TAPS>(a, stream);
     return launch_conv<T, 1, 16, 16, 32, 4, 1, TAPS>(a, stream);
   }

@@ -12,7 +12,7 @@ within absolute bounds.  Measured on MI355X over 3 perturbation seeds (fp32' vs 
   tail-200 train loss 0.3-2.4 % | 2.0-6.3 %;  lambda-hat 1-3 | 1-4 grid steps of 100;  prediction images (rel. L2)
   6.7-6.8 % | 6.0-8.0 %;  calibrated lower edge 7.2-9.1 % | 6.2-12.5 %;  upper edge 5.5-8.2 % | 4.8-9.1 %;  mean
   calibrated interval size 0.142-0.147 | 0.138-0.162 (fp32: 0.138);  validation risk 0.050-0.052 for all (alpha = 0.1).
-Bounds asserted: loss 10 %, lambda-hat 6 steps, prediction 12 %, lower 20 %, upper 15 %, size ratio in [0.75, 1.35], risk
+Bounds asserted: loss 10 %, lambda-hat 2x the fp32-vs-fp32' distance + 3 steps, prediction 12 %, lower 20 %, upper 15 %, size ratio in [0.75, 1.35], risk
 <= alpha -- a wrong rounding point or a lost gradient term costs tens of percent and a broken calibration moves the risk.
 """
 import numpy as np
@@ -105,7 +105,11 @@ def test_bf16_training_tracks_fp32_training_then_calibrates_alike():
         assert r["risk"] <= PARAMS["alpha"]                                           # the calibrated sets hold the risk
     assert r16["losses"][0] == pytest.approx(r32["losses"][0], rel=1e-2)              # same start
     # absolute bounds (measured spreads in the module docstring)
-    assert d16["loss"] < 0.10 and d16["lhat"] <= 6.0 + 1e-6
+    # (lambda-hat itself is NOT bounded absolutely: it is the ratio of two chaotic quantities -- the raw head widths of two fp32
+    # runs differed by 1.5x after a kernel's summation order changed [round 3: 17 grid steps between fp32 and fp32', 11
+    # between bf16 and fp32] while lambda-hat x width, the calibrated size below, agreed to 15-20 %; it is held relative to
+    # the fp32-vs-fp32' distance further down)
+    assert d16["loss"] < 0.10
     assert d16["mid"] < 0.12 and d16["lo"] < 0.20 and d16["hi"] < 0.15
     assert 0.75 < size["bf16"] / size["fp32"] < 1.35
     # and no further from fp32 than fp32 is from itself (2x + margin)
