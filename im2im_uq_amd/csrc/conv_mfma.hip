@@ -35,6 +35,9 @@
 #ifndef IM2IM_ABLATE
 #define IM2IM_ABLATE 0
 #endif
+#ifndef IM2IM_WGRAD_ABL      // measurement-only: bit 0 = no global loads after the first tile, bit 1 = no LDS writes, bit 2 = no MFMA phase
+#define IM2IM_WGRAD_ABL 0
+#endif
 
 namespace {
 
@@ -837,8 +840,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
   for (int i = 0; i < A_ROUNDS; ++i) { const int p = i * NT + tid; a_px[i] = (p < M * PPRA) ? p / PPRA : -1; a_part[i] = p % PPRA; }
 #pragma unroll
   for (int i = 0; i < B_ROUNDS; ++i) { const int p = i * NT + tid; b_px[i] = (p < HPX * PPR) ? p / PPR : -1; b_part[i] = p % PPR; }
-  uint4 ra[A_ROUNDS], rb[B_ROUNDS];
-  unsigned b_valid = 0;                              // bit i: rb[i] holds real pixels (not zero padding)
+  struct Stage { uint4 a[A_ROUNDS], b[B_ROUNDS]; unsigned valid; };   // one tile in flight; valid bit i: b[i] holds real pixels (not zero padding)
   // lazy BatchNorm coefficients of the 64 input channels: in registers (COT = 64) or, where the 96 accumulators leave no room
   // for 16 more live values, in LDS behind the tile buffers and read back per tile (COT = 128)
   constexpr bool SS_LDS = COT > 64;
@@ -855,7 +857,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
     }
   }
 
-  auto gload = [&](int t) {
+  auto gload = [&](int t, Stage& R) __attribute__((always_inline)) {
     int tt = t;
     const int tx_id = tt % a.tilesX; tt /= a.tilesX;
     const int ty_id = tt % a.tilesY;
@@ -871,9 +873,9 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
         if (yy < a.H && xx < a.W && co0 + a_part[i] * EPP < a.Co)
           v = *reinterpret_cast<const uint4*>(dzb + ((size_t)yy * a.W + xx) * a.Co + a_part[i] * EPP);
       }
-      ra[i] = v;
+      R.a[i] = v;
     }
-    b_valid = 0;
+    R.valid = 0;
 #pragma unroll
     for (int i = 0; i < B_ROUNDS; ++i) {
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -881,22 +883,22 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
         const int yy = y0 + b_px[i] / HWD - 1, xx = x0 + b_px[i] % HWD - 1;
         if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
           v = *reinterpret_cast<const uint4*>(xb + ((size_t)yy * a.W + xx) * xs.stride + b_part[i] * EPP);
-          b_valid |= 1u << i;
+          R.valid |= 1u << i;
         }
       }
-      rb[i] = v;
+      R.b[i] = v;
     }
   };
-  auto swrite = [&](int buf) {
+  auto swrite = [&](int buf, const Stage& R) __attribute__((always_inline)) {
     char* la = smem + buf * BUF_BYTES;
     char* lb = la + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < A_ROUNDS; ++i) if (a_px[i] >= 0) *reinterpret_cast<uint4*>(la + a_px[i] * PA + a_part[i] * 16) = ra[i];
+    for (int i = 0; i < A_ROUNDS; ++i) if (a_px[i] >= 0) *reinterpret_cast<uint4*>(la + a_px[i] * PA + a_part[i] * 16) = R.a[i];
 #pragma unroll
     for (int i = 0; i < B_ROUNDS; ++i) {
       if (b_px[i] >= 0) {
-        uint4 v = rb[i];
-        if (lazy_x && ((b_valid >> i) & 1)) {
+        uint4 v = R.b[i];
+        if (lazy_x && ((R.valid >> i) & 1)) {
           float f[EPP];
           Vec16<T>::load(reinterpret_cast<const T*>(&v), f);
           if constexpr (SS_LDS) {
@@ -913,7 +915,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
       }
     }
   };
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf) __attribute__((always_inline)) {
     const char* la = smem + buf * BUF_BYTES;
     const char* lb = la + A_BYTES + tg * HWD * PB;           // this wave's kernel row
     // k-step ks covers tile row ks (TW == 16): every address below is lane base + compile-time constant, so the fully
@@ -938,15 +940,24 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
   const int t_begin = split * a.tiles_per_split;
   const int t_end = min(t_begin + a.tiles_per_split, a.ntiles);
   if (t_begin < t_end) {
-    gload(t_begin);
-    swrite(0);
+    Stage R;
+    gload(t_begin, R);
+    swrite(0, R);
     __syncthreads();
     int cur = 0;
     for (int t = t_begin; t < t_end; ++t) {
       const bool more = t + 1 < t_end;
-      if (more) gload(t + 1);                          // in flight during the MFMAs below
+#if IM2IM_WGRAD_ABL & 8
+      if (more) gload(t_begin, R);                     // same instruction stream, data always cache-hot
+#elif !(IM2IM_WGRAD_ABL & 1)
+      if (more) gload(t + 1, R);                       // in flight during the MFMAs below
+#endif
+#if !(IM2IM_WGRAD_ABL & 4)
       compute(cur);
-      if (more) swrite(cur ^ 1);
+#endif
+#if !(IM2IM_WGRAD_ABL & 2)
+      if (more) swrite(cur ^ 1, R);
+#endif
       __syncthreads();
       cur ^= 1;
     }

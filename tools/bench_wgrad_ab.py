@@ -12,7 +12,8 @@ from im2im_uq_amd import hip_ops, nn_ops
 dev = "cuda:0"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 78
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 7
-LAYERS = [(160, 64, 128, False), (160, 128, 128, False), (160, 256, 128, True), (80, 128, 256, False), (80, 256, 256, False),
+MODES = tuple(int(m) for m in sys.argv[3].split(",")) if len(sys.argv) > 3 else (0, 1)
+LAYERS = [(320, 64, 64, False), (320, 128, 64, True), (160, 128, 64, False), (160, 64, 128, False), (160, 128, 128, False), (160, 256, 128, True), (80, 128, 256, False), (80, 256, 256, False),
           (80, 512, 256, True), (40, 256, 512, False), (40, 512, 512, False), (40, 1024, 512, True), (20, 512, 512, False)]
 tot = {0: 0.0, 1: 0.0}
 fl_tot = 0.0
@@ -25,15 +26,15 @@ for (h, ci, co, split) in LAYERS:
     ss = torch.stack([torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev)]).contiguous()
     fl = 2.0 * B * h * h * ci * co * 9
     fn = lambda: nn_ops.conv_wgrad(x, dz, 9, x_ss=ss, x_hi=xh)
-    times = {0: [], 1: []}
+    times = {m: [] for m in MODES}
     outs = {}
-    for m in (0, 1):
+    for m in MODES:
         hip_ops.set_option("wgrad_co128", m)
         for _ in range(2):
             outs[m] = fn()
-    rel = float((outs[1] - outs[0]).norm() / outs[0].norm())
+    rel = float((outs[MODES[-1]] - outs[MODES[0]]).norm() / outs[MODES[0]].norm())
     for r in range(rounds):
-        for m in (0, 1):
+        for m in MODES:
             hip_ops.set_option("wgrad_co128", m)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -42,11 +43,11 @@ for (h, ci, co, split) in LAYERS:
             e1.record()
             torch.cuda.synchronize()
             times[m].append(e0.elapsed_time(e1) / 3)
-    med = {m: statistics.median(times[m]) for m in (0, 1)}
-    for m in (0, 1):
+    med = {m: statistics.median(times[m]) for m in MODES}
+    for m in MODES:
         tot[m] += med[m]
     fl_tot += fl
-    print(f"wgrad {h:3d}x{h:<3d} {ci:4d}->{co:<3d} co64: {med[0]:.3f} ms {fl / med[0] / 1e9:6.0f} TF   co128: {med[1]:.3f} ms {fl / med[1] / 1e9:6.0f} TF"
-          f"   x{med[0] / med[1]:.3f}   |dw128 - dw64| / |dw64| = {rel:.2e}", flush=True)
+    print(f"wgrad {h:3d}x{h:<3d} {ci:4d}->{co:<3d} " + "   ".join(f"mode{m}: {med[m]:.3f} ms {fl / med[m] / 1e9:6.0f} TF" for m in MODES)
+          + f"   x{med[MODES[0]] / med[MODES[-1]]:.3f}   rel diff {rel:.2e}", flush=True)
 hip_ops.set_option("wgrad_co128", 1)
-print(f"total: co64 {tot[0]:.2f} ms {fl_tot / tot[0] / 1e9:6.0f} TF   co128 {tot[1]:.2f} ms {fl_tot / tot[1] / 1e9:6.0f} TF")
+print("total: " + "   ".join(f"mode{m}: {tot[m]:.2f} ms {fl_tot / tot[m] / 1e9:6.0f} TF" for m in MODES))
