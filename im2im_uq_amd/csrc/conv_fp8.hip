@@ -99,6 +99,14 @@ __device__ __forceinline__ float grad_scale(float amax) {
   return ldexpf(1.f, 14 - e);
 }
 
+// Packed fp8 weights are fragment-major like the bf16 ones (conv_common.h wfrag_index): the 32 rows x 64 reduction channels one
+// v_mfma_scale_f32_32x32x64_f8f6f4 consumes are one contiguous 2 KiB block = two 1 KiB parts; part p holds bytes 16p..16p+15 of
+// every lane's 32 (lane = (k / 32 % 2) * 32 + row % 32), so a wave fetches a fragment with two fully coalesced 16-byte loads.
+// Blocks are ordered [row block of 32][tap][64-channel chunk].  N x 9 x K logical tensor, N % 32 == 0, K % 64 == 0.
+__host__ __device__ inline size_t wfrag8_index(int n, int tap, int k, int K) {
+  return ((((size_t)(n >> 5) * 9 + tap) * (K >> 6) + (k >> 6)) * 2 + ((k >> 4) & 1)) * 1024 + ((((k >> 5) & 1) * 32 + (n & 31)) * 16) + (k & 15);
+}
+
 // EPI: 0 = (+bias) store; 1 = +bias, store, BatchNorm partial statistics; 2 = folded BatchNorm affine (+ReLU)
 // GRAD: data-gradient form (e5m2 operand under a run-time scale, amax bookkeeping, optional split result)
 template <int TB, int TH, int TW, int BN, int WM, int WN, int EPI, bool GRAD>
@@ -118,12 +126,16 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
   constexpr int HIMGB = HH * HROWB;
   constexpr int A_BYTES = TB * HIMGB, B_BYTES = BN * ROWB;
   static_assert(A_ROUNDS <= 18, "two rounds per tap at most");
+  // weight fragments straight from L2 into registers where a fragment feeds MT = 4 MFMAs (as conv_igemm_kernel's DIRECTW): no
+  // weight tile in LDS, one barrier per chunk instead of one per tap
+  constexpr bool DIRECTW = MT >= 4;
+  constexpr int B_TOTAL = DIRECTW ? 0 : 2 * B_BYTES;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ldsA = smem;                                  // two halo buffers
   char* ldsB = smem + 2 * A_BYTES;                    // two weight buffers
   float* ldsS = reinterpret_cast<float*>(smem);       // stats scratch (after the main loop)
-  float* ldsSS = reinterpret_cast<float*>(smem + 2 * A_BYTES + 2 * B_BYTES);   // [2][Ci] lazy coefficients
+  float* ldsSS = reinterpret_cast<float*>(smem + 2 * A_BYTES + B_TOTAL);       // [2][Ci] lazy coefficients
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -234,16 +246,14 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
     *reinterpret_cast<uint2*>(dst + loff) = q;
   };
 
-  const unsigned char* __restrict__ wg_tile = a.w + (size_t)n0 * 9 * a.Ci;
   uint4 rb[2][B_ROUNDS];
   auto gload_B = [&](uint4 (&r)[B_ROUNDS], int chunk, int tap) {
-    const unsigned char* src = wg_tile + (size_t)tap * a.Ci + chunk * KC;
 #pragma unroll
     for (int i = 0; i < B_ROUNDS; ++i) {
       const int p = i * 256 + tid;
       const int n = p >> 2, pt = p & 3;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if ((BN * 4) % 256 == 0 || n < BN) v = *reinterpret_cast<const uint4*>(src + (size_t)n * 9 * a.Ci + pt * 16);
+      if ((BN * 4) % 256 == 0 || n < BN) v = *reinterpret_cast<const uint4*>(a.w + wfrag8_index(n0 + n, tap, chunk * KC + pt * 16, a.Ci));
       r[i] = v;
     }
   };
@@ -253,6 +263,33 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
       const int p = i * 256 + tid;
       const int n = p >> 2, pt = p & 3;
       if ((BN * 4) % 256 == 0 || n < BN) *reinterpret_cast<uint4*>(ldsB + buf * B_BYTES + n * ROWB + pt * 16) = r[i];
+    }
+  };
+  auto mfma_tap = [&](int toff, int abuf, const i32x8 (&fb)[NT]) __attribute__((always_inline)) {
+    const char* pa = ldsA + abuf * A_BYTES + toff;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const uint4 lo = *reinterpret_cast<const uint4*>(pa + aoff[mt]);
+      const uint4 hi = *reinterpret_cast<const uint4*>(pa + aoff[mt] + 16);
+      const i32x8 fa = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        if constexpr (GRAD)      // A = e5m2 (format 1), neutral block scales: the run-time tensor scale is undone in the epilogue
+          acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb[nt], acc[mt][nt], 1, 0, 0, 127, 0, 127);
+        else
+          acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb[nt], acc[mt][nt], 0, 0, 0, XSCALE_E8M0, 0, 127);
+    }
+  };
+  // DIRECTW: this wave's NT weight fragments of one (tap, chunk), from the fragment-major pack
+  const size_t cob_stride8 = (size_t)9 * (a.Ci >> 6) * 2048;
+  const unsigned char* __restrict__ wfr = a.w + (size_t)(n0 / 32 + wn * NT) * cob_stride8 + lane * 16;
+  auto gload_F = [&](i32x8 (&f)[NT], int chunk, int tap) __attribute__((always_inline)) {
+    const unsigned char* p = wfr + ((size_t)(tap * (a.Ci >> 6) + chunk) << 11);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const uint4 lo = *reinterpret_cast<const uint4*>(p + nt * cob_stride8);
+      const uint4 hi = *reinterpret_cast<const uint4*>(p + nt * cob_stride8 + 1024);
+      f[nt] = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
     }
   };
   auto compute = [&](int toff, int bbuf, int abuf) {
@@ -296,8 +333,9 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < A_ROUNDS; ++i) convert_write(raw[i], real[i], loffs[i], ldsA, 0);
   }
-  gload_B(rb[0], 0, 0);
-  gload_B(rb[1], 0, 1);
+  i32x8 fw[2][NT];                                   // DIRECTW: this tap's / the next tap's weight fragments
+  if constexpr (DIRECTW) gload_F(fw[0], 0, 0);
+  else { gload_B(rb[0], 0, 0); gload_B(rb[1], 0, 1); }
   auto chunk_body = [&](auto parity, int chunk) {
     constexpr int P0 = decltype(parity)::value;
     const bool more = chunk + 1 < nchunks;
@@ -305,13 +343,19 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
     char* nextA = ldsA + (abuf ^ 1) * A_BYTES;
     int tid_o = tid;
     asm volatile("" : "+v"(tid_o));
+    if constexpr (DIRECTW) __syncthreads();            // the halo written during the previous chunk (or the prologue) is visible, its predecessor free
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int set = (P0 + tap) & 1;
+      if constexpr (DIRECTW) {
+        if (tap + 1 < 9) { if (set) gload_F(fw[0], chunk, tap + 1); else gload_F(fw[1], chunk, tap + 1); }
+        else if (more) { if (set) gload_F(fw[0], chunk + 1, 0); else gload_F(fw[1], chunk + 1, 0); }
+      } else {
       if (set) swrite_B(rb[1], 1); else swrite_B(rb[0], 0);
       __syncthreads();                                 // weight tile `set` (and, at tap 0, the halo written during the previous chunk) visible
       if (tap + 2 < 9) { if (set) gload_B(rb[1], chunk, tap + 2); else gload_B(rb[0], chunk, tap + 2); }
       else if (more) { if (set) gload_B(rb[1], chunk + 1, tap + 2 - 9); else gload_B(rb[0], chunk + 1, tap + 2 - 9); }
+      }
       // trickle the next chunk's halo: rounds {tap, tap + 9} are loaded before this tap's MFMAs and written after them
       uint4 raw0 = make_uint4(0, 0, 0, 0), raw1 = make_uint4(0, 0, 0, 0);
       int loff0 = -1, loff1 = -1;
@@ -328,7 +372,8 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
           if (real1) raw1 = *reinterpret_cast<const uint4*>(s1);
         }
       }
-      compute((tap / 3) * HROWB + (tap % 3) * ROWB, set, abuf);
+      if constexpr (DIRECTW) { if (set) mfma_tap((tap / 3) * HROWB + (tap % 3) * ROWB, abuf, fw[1]); else mfma_tap((tap / 3) * HROWB + (tap % 3) * ROWB, abuf, fw[0]); }
+      else compute((tap / 3) * HROWB + (tap % 3) * ROWB, set, abuf);
       if (more) {
         if (tap < A_ROUNDS) convert_write(raw0, real0, loff0, nextA, chunk + 1);
         if (tap + 9 < A_ROUNDS) convert_write(raw1, real1, loff1, nextA, chunk + 1);
@@ -482,7 +527,8 @@ __global__ __launch_bounds__(256) void pack_weight_fp8_kernel(const float* __res
     const int ci = i / taps, tp = i % taps;                  // source index (ci, tap)
     const float v = fminf(fmaxf(wc[i] * inv, -FP8_MAX), FP8_MAX);
     const int q = __builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false);
-    wq[((size_t)co * taps + tp) * Ci + ci] = (unsigned char)(q & 0xff);
+    if (taps == 9 && Ci % 64 == 0 && gridDim.x % 32 == 0) wq[wfrag8_index(co, tp, ci, Ci)] = (unsigned char)(q & 0xff);   // fragment-major
+    else wq[((size_t)co * taps + tp) * Ci + ci] = (unsigned char)(q & 0xff);
   }
 }
 
@@ -511,7 +557,8 @@ __global__ __launch_bounds__(256) void pack_weight_fp8_dgrad_kernel(const float*
     const int tp = i / Co, co = i % Co;                     // destination order (tap, co): coalesced bytes
     const float v = fminf(fmaxf(w[((size_t)co * Ci + ci) * taps + tp] * inv, -FP8_MAX), FP8_MAX);
     const int q = __builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false);
-    wq[((size_t)ci * taps + (taps - 1 - tp)) * Co + co] = (unsigned char)(q & 0xff);
+    if (taps == 9 && Co % 64 == 0 && Ci % 32 == 0) wq[wfrag8_index(ci, taps - 1 - tp, co, Co)] = (unsigned char)(q & 0xff);
+    else wq[((size_t)ci * taps + (taps - 1 - tp)) * Co + co] = (unsigned char)(q & 0xff);
   }
 }
 
@@ -521,7 +568,8 @@ int launch_fp8(const Fp8ConvArgs& a_in, hipStream_t stream) {
   a.tilesY = (int)cdiv(a.H, TH);
   a.tilesX = (int)cdiv(a.W, TW);
   constexpr int ROWB = 80;
-  constexpr size_t smem_main = (size_t)2 * TB * (TH + 2) * ((TW + 2) * ROWB + 96) + (size_t)2 * BN * ROWB;
+  constexpr bool DIRECTW = TB * TH * TW / (32 * WM) >= 4;                       // as in the kernel: no weight tile in LDS
+  constexpr size_t smem_main = (size_t)2 * TB * (TH + 2) * ((TW + 2) * ROWB + 96) + (DIRECTW ? 0 : (size_t)2 * BN * ROWB);
   constexpr size_t smem_epi = (size_t)4 * (TB * TH * TW / WM) * ((BN / WN) * 2 + 16);
   const size_t smem_in = smem_main + ((a.in_ss || a.in_ss_hi) ? (size_t)2 * a.Ci * sizeof(float) : 0);
   const size_t smem = smem_in > smem_epi ? smem_in : smem_epi;

@@ -179,7 +179,8 @@ def packed_pair(weight: torch.Tensor, dtype):
 
 
 def pack_weight_fp8(w: torch.Tensor):
-    """w [Co,Ci,3,3] fp32 -> (wq uint8 [Co,9,Ci] e4m3 bytes, wscale [Co] fp32 power-of-two scales)."""
+    """w [Co,Ci,3,3] fp32 -> (wq uint8 [Co,9,Ci] e4m3 bytes -- an opaque operand, logical order via fp8_pack_logical --,
+    wscale [Co] fp32 power-of-two scales)."""
     co, ci = w.shape[0], w.shape[1]
     taps = w.shape[2] * w.shape[3]
     w = w.detach()
@@ -190,6 +191,17 @@ def pack_weight_fp8(w: torch.Tensor):
     check(lib.im2im_pack_conv_weight_fp8(dptr(w), co, ci, taps, dptr(wq), dptr(wscale), stream_ptr(w.device)),
           "im2im_pack_conv_weight_fp8")
     return wq, wscale
+
+
+def fp8_pack_logical(wq: torch.Tensor) -> torch.Tensor:
+    """the packed fp8 weight bytes in logical order [N, 9, K].  The packed buffer is an opaque operand: for N % 32 == 0 and
+    K % 64 == 0 its storage order is fragment-major (csrc/conv_fp8.hip wfrag8_index: [row block of 32][tap][64-channel chunk]
+    [16-byte part][lane = (k / 32 % 2) * 32 + row % 32][16]); this undoes it (tests, tools)."""
+    n, taps, k = wq.shape
+    if taps != 9 or n % 32 or k % 64:
+        return wq
+    f = wq.reshape(n // 32, 9, k // 64, 2, 2, 32, 16)          # [row block][tap][chunk][part][k half][row in block][byte]
+    return f.permute(0, 5, 1, 2, 4, 3, 6).reshape(n, 9, k)     # -> [row block, row][tap][chunk, half, part, byte]
 
 
 def pack_weight_fp8_dgrad(w: torch.Tensor):

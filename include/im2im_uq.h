@@ -191,7 +191,8 @@ int im2im_conv_fwd_split(const void* x, const float* in_scale_shift, const void*
  * v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64, ~2x the bf16 MFMA rate), fp32 accumulate, bf16 in/out.  Same contract as
  * im2im_conv_fwd_split with dtype IM2IM_BF16 and taps = 9 (the nn.Conv2d forward of unet_parts.py:16,19), except:
  *   wq / wscale come from im2im_pack_conv_weight_fp8: wq [Co][9][Ci] e4m3 bytes = w / wscale[co], wscale[co] the power
- *     of two that maps the channel's max |w| into (128, 256];
+ *     of two that maps the channel's max |w| into (128, 256]; an opaque operand -- for Co % 32 == 0 and Ci % 64 == 0 the
+ *     storage order is fragment-major (csrc/conv_fp8.hip wfrag8_index), read straight from L2 into registers by the kernel;
  *   x (bf16, optionally the producer's pre-BatchNorm z with lazy coefficients) is scaled by 2^4, clamped to +-448 and
  *     converted to e4m3 while it is staged into LDS (the 2^4 is undone by the instruction's block scale);
  *   Ci % 64 == 0 (Ci_lo % 64 == 0 when split), Co % 64 == 0; no split output, no `center`.

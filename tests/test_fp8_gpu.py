@@ -65,7 +65,7 @@ def test_conv_fwd_fp8_vs_cpu_on_identically_quantised_operands(case):
     x_d = x.to(DEV).permute(0, 2, 3, 1).contiguous().to(BF16)
     wq, wscale = nn_ops.pack_weight_fp8(wt.to(DEV))
     # packed weights are exactly the emulation's
-    deq = (wq.view(torch.float8_e4m3fn).to(F32) * wscale[:, None, None]).cpu().view(co, 3, 3, ci).permute(0, 3, 1, 2)
+    deq = (nn_ops.fp8_pack_logical(wq).contiguous().view(torch.float8_e4m3fn).to(F32) * wscale[:, None, None]).cpu().view(co, 3, 3, ci).permute(0, 3, 1, 2)
     assert torch.equal(deq, om.fp8_weight(wt))
     if split:
         lo, hi = x_d[..., : ci // 2].contiguous(), x_d[..., ci // 2:].contiguous()
