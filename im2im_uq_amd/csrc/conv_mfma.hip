@@ -35,7 +35,7 @@
 #ifndef IM2IM_ABLATE
 #define IM2IM_ABLATE 0
 #endif
-#ifndef IM2IM_WGRAD_ABL      // measurement-only: bit 0 = no global loads after the first tile, bit 1 = no LDS writes, bit 2 = no MFMA phase
+#ifndef IM2IM_WGRAD_ABL      // measurement-only: bit 0 = no global loads after the first tile, bit 1 = no LDS writes, bit 2 = no MFMA phase, bit 3 = loads of the same (cache-hot) tile, bit 4 = the dz half of the staging only for the first tile
 #define IM2IM_WGRAD_ABL 0
 #endif
 
@@ -857,6 +857,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
     }
   }
 
+  bool abl_first = true; (void)abl_first;
   auto gload = [&](int t, Stage& R) __attribute__((always_inline)) {
     int tt = t;
     const int tx_id = tt % a.tilesX; tt /= a.tilesX;
@@ -865,6 +866,9 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
     const int y0 = ty_id * TH, x0 = tx_id * TW;
     const T* xb = xg + (size_t)b * a.H * a.W * xs.stride;
     const T* dzb = dzg + (size_t)b * a.H * a.W * a.Co + co0;
+#if IM2IM_WGRAD_ABL & 16
+    if (abl_first)
+#endif
 #pragma unroll
     for (int i = 0; i < A_ROUNDS; ++i) {
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -892,8 +896,14 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
   auto swrite = [&](int buf, const Stage& R) __attribute__((always_inline)) {
     char* la = smem + buf * BUF_BYTES;
     char* lb = la + A_BYTES;
+#if IM2IM_WGRAD_ABL & 16
+    if (abl_first)
+#endif
 #pragma unroll
     for (int i = 0; i < A_ROUNDS; ++i) if (a_px[i] >= 0) *reinterpret_cast<uint4*>(la + a_px[i] * PA + a_part[i] * 16) = R.a[i];
+#if IM2IM_WGRAD_ABL & 16
+    abl_first = false;
+#endif
 #pragma unroll
     for (int i = 0; i < B_ROUNDS; ++i) {
       if (b_px[i] >= 0) {
