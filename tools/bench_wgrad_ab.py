@@ -13,9 +13,10 @@ dev = "cuda:0"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 78
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 MODES = tuple(int(m) for m in sys.argv[3].split(",")) if len(sys.argv) > 3 else (0, 1)
+KEY = sys.argv[4] if len(sys.argv) > 4 else "wgrad_co128"
 LAYERS = [(320, 64, 64, False), (320, 128, 64, True), (160, 128, 64, False), (160, 64, 128, False), (160, 128, 128, False), (160, 256, 128, True), (80, 128, 256, False), (80, 256, 256, False),
           (80, 512, 256, True), (40, 256, 512, False), (40, 512, 512, False), (40, 1024, 512, True), (20, 512, 512, False)]
-tot = {0: 0.0, 1: 0.0}
+tot = {m: 0.0 for m in MODES}
 fl_tot = 0.0
 for (h, ci, co, split) in LAYERS:
     g = torch.Generator(device=dev).manual_seed(1)
@@ -29,13 +30,13 @@ for (h, ci, co, split) in LAYERS:
     times = {m: [] for m in MODES}
     outs = {}
     for m in MODES:
-        hip_ops.set_option("wgrad_co128", m)
+        hip_ops.set_option(KEY, m)
         for _ in range(2):
             outs[m] = fn()
     rel = float((outs[MODES[-1]] - outs[MODES[0]]).norm() / outs[MODES[0]].norm())
     for r in range(rounds):
         for m in MODES:
-            hip_ops.set_option("wgrad_co128", m)
+            hip_ops.set_option(KEY, m)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
@@ -49,5 +50,5 @@ for (h, ci, co, split) in LAYERS:
     fl_tot += fl
     print(f"wgrad {h:3d}x{h:<3d} {ci:4d}->{co:<3d} " + "   ".join(f"mode{m}: {med[m]:.3f} ms {fl / med[m] / 1e9:6.0f} TF" for m in MODES)
           + f"   x{med[MODES[0]] / med[MODES[-1]]:.3f}   rel diff {rel:.2e}", flush=True)
-hip_ops.set_option("wgrad_co128", 1)
+hip_ops.set_option(KEY, MODES[-1])
 print("total: " + "   ".join(f"mode{m}: {tot[m]:.2f} ms {fl_tot / tot[m] / 1e9:6.0f} TF" for m in MODES))
