@@ -42,6 +42,51 @@ PEAK_BF16_TFLOPS = 2500.0          # dense MFMA peak, MI355X_MICROARCH.md
 PEAK_FP32_TFLOPS = 157.3           # v_mfma_f32_32x32x2_f32 = the fp32 vector rate
 PEAK_FP8_TFLOPS = 5000.0           # dense MX-scaled fp8 MFMA peak (K = 64 / 128 forms), MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+LIVE_TRAFFIC = {}                  # kernel -> {"traffic_bytes_per_launch", "launches_profiled"}: PMC passes made by THIS run (live_pmc_traffic)
+
+
+def live_pmc_traffic(timeout=180):
+    """HBM bytes per launch of the two dominant kernels from hardware counters, measured by this run: short re-runs of the train /
+    calib leg of this same script under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` (separate
+    passes, nothing else enabled, as MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled for gfx950 as its HBM section says).  Any
+    failure (no rocprofv3, a timeout) leaves the entry out and the caller falls back to the committed profiles/pmc_traffic.json."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return {}
+    env = dict(os.environ, TMPDIR="/tmp", IM2IM_WGRAD_STREAM="0")
+    common = ["--no-cpu-baseline", "--no-fp32", "--no-extras", "--no-roofline", "--steps", "2", "--warmup", "1"]
+    legs = {"conv_igemm_kernel": ["--legs", "train"] + common, "rcps_hist_kernel": ["--legs", "calib"] + common}
+    out = {}
+    for kern, bargs in legs.items():
+        vals = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="im2im_pmc_", dir="/tmp")
+            try:
+                subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                                sys.executable, os.path.abspath(__file__)] + bargs, env=env, cwd="/tmp", stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+                files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+                with open(files[0]) as f:
+                    v = [float(r["Counter_Value"]) for r in csv.DictReader(f) if kern in r["Kernel_Name"] and r["Counter_Name"] == counter]
+                if v:
+                    vals[counter] = (sum(v) / len(v), len(v))
+            except Exception:  # noqa: BLE001
+                pass
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+        if len(vals) == 2:
+            out[kern] = {"traffic_bytes_per_launch": (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0,
+                         "launches_profiled": vals["FETCH_SIZE"][1]}
+    return out
+
+
+LIVE_SOURCE = ("measured in this run: rocprofv3 --pmc FETCH_SIZE --kernel-trace and --pmc WRITE_SIZE --kernel-trace passes (separate) over "
+               "`bench.py --legs {leg} --steps 2`, 2 x FETCH_SIZE + WRITE_SIZE averaged over {n} launches")
 MEASURED_BF16_RANDOM_TFLOPS = 1981.0   # register-only v_mfma_f32_32x32x16_bf16 loop on random operands, this part, profiles/r01_hwprobe.txt
 
 PARAMS = dict(uncertainty_type="quantiles", q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1,
@@ -292,6 +337,9 @@ def roofline_leg(wl, config_name, full=True):
             roof["traffic_source"] = "profiles/pmc_traffic.json (replayed: PMC passes of the same command, not measured in this run)"
     except Exception:  # noqa: BLE001
         pass
+    if "conv_igemm_kernel" in LIVE_TRAFFIC:
+        roof["traffic"] = LIVE_TRAFFIC["conv_igemm_kernel"]["traffic_bytes_per_launch"]
+        roof["traffic_source"] = LIVE_SOURCE.format(leg="train", n=LIVE_TRAFFIC["conv_igemm_kernel"]["launches_profiled"])
     try:
         # counter-based utilisation from the committed PMC passes (busy MFMA cycles / elapsed SIMD cycles at the clock the chip
         # actually ran): a second reading beside `frac`, which divides FLOP/s by the nominal-clock peak
@@ -395,6 +443,9 @@ def calib_leg(wl, steps, calib_images=None, scoring=True):
             source = "profiles/pmc_traffic.json (replayed: PMC passes of the same command, not measured in this run)"
     except Exception:  # noqa: BLE001
         pass
+    if "rcps_hist_kernel" in LIVE_TRAFFIC and not two_plane:
+        traffic = LIVE_TRAFFIC["rcps_hist_kernel"]["traffic_bytes_per_launch"]
+        source = LIVE_SOURCE.format(leg="calib", n=LIVE_TRAFFIC["rcps_hist_kernel"]["launches_profiled"])
     calib["scoring_only"] = {"imgs_per_s": M / ms_score * 1e3, "ms": ms_score,
                              "roofline": {"bound": "hbm", "achieved": score_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                           "frac": score_gbs / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": source,
@@ -493,6 +544,8 @@ def main():
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 (parity mode) companion number")
     ap.add_argument("--no-extras", action="store_true", help="skip the short sub-records (other BASELINE configs, batch 10, "
                     "fastMRI pipeline; N > 1: the strong-scaling companion)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not re-run the legs under rocprofv3 --pmc for roofline.traffic "
+                    "(the committed profiles/pmc_traffic.json is reported instead)")
     ap.add_argument("--legs", default="train,calib", help="which legs to run (profiling: --legs train / --legs calib)")
     ap.add_argument("--uncertainty-type", default="quantiles",
                     choices=["quantiles", "quantiles_l1", "gaussian", "residual_magnitude", "residual_magnitude_l1", "softmax"],
@@ -518,6 +571,9 @@ def main():
         conf["batch"] = args.batch
     default_run = (args.config == "fastmri" and not custom and args.batch is None and args.calib_images is None
                    and args.uncertainty_type == "quantiles" and args.legs == "train,calib" and not args.no_extras)
+
+    if default_run and world == 1 and not args.no_live_pmc:
+        LIVE_TRAFFIC.update(live_pmc_traffic())             # before this process allocates anything: the passes have the GPU to themselves
 
     from im2im_uq_amd import nn_ops
     wl = Workload(job, conf, args.uncertainty_type, strong=args.scaling == "strong")
