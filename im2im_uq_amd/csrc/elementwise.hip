@@ -149,6 +149,17 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict_
 #ifndef IM2IM_STREAM_U
 #define IM2IM_STREAM_U 4
 #endif
+#ifndef IM2IM_NT_LOADS
+#define IM2IM_NT_LOADS 1
+#endif
+// 16-byte load of a tensor the streaming BatchNorm-backward kernels read once per pass
+template <typename T> __device__ __forceinline__ uint4 stream_ld(const T* p) {
+#if IM2IM_NT_LOADS
+  return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)));
+#else
+  return *reinterpret_cast<const uint4*>(p);
+#endif
+}
 constexpr int STREAM_U = IM2IM_STREAM_U;      // vector loads a thread of the streaming BatchNorm-backward kernels keeps in flight (per operand)
 
 template <typename T>
@@ -193,13 +204,13 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
       uint4 rg[STREAM_U], rz[STREAM_U];
 #pragma unroll
       for (int u = 0; u < STREAM_U; ++u) {
-        rg[u] = *reinterpret_cast<const uint4*>(da + (i + u * stride) * N);
-        rz[u] = *reinterpret_cast<const uint4*>(z + (i + u * stride) * N);
+        rg[u] = stream_ld(da + (i + u * stride) * N);
+        rz[u] = stream_ld(z + (i + u * stride) * N);
       }
 #pragma unroll
       for (int u = 0; u < STREAM_U; ++u) one(rg[u], rz[u]);
     }
-    for (; i < v1; i += stride) one(*reinterpret_cast<const uint4*>(da + i * N), *reinterpret_cast<const uint4*>(z + i * N));
+    for (; i < v1; i += stride) one(stream_ld(da + i * N), stream_ld(z + i * N));
   }
 #pragma unroll
   for (int k = 0; k < N; ++k) { s_part[threadIdx.x][k] = s1[k]; s_part[threadIdx.x][N + k] = s2[k]; }
@@ -273,8 +284,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restr
       uint4 rg[STREAM_U], rz[STREAM_U];
 #pragma unroll
       for (int u = 0; u < STREAM_U; ++u) {
-        rg[u] = *reinterpret_cast<const uint4*>(da + (i + u * stride) * N);
-        rz[u] = *reinterpret_cast<const uint4*>(z + (i + u * stride) * N);
+        rg[u] = stream_ld(da + (i + u * stride) * N);
+        rz[u] = stream_ld(z + (i + u * stride) * N);
       }
 #pragma unroll
       for (int u = 0; u < STREAM_U; ++u) one(rg[u], rz[u], i + u * stride);
@@ -282,7 +293,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restr
   }
   for (; i < nvec; i += stride) {
     if (!fixed) { c0 = (int)(i % vpr) * N; load_coef(); }
-    one(*reinterpret_cast<const uint4*>(da + i * N), *reinterpret_cast<const uint4*>(z + i * N), i);
+    one(stream_ld(da + i * N), stream_ld(z + i * N), i);
   }
 }
 
