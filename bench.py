@@ -42,6 +42,11 @@ PEAK_BF16_TFLOPS = 2500.0          # dense MFMA peak, MI355X_MICROARCH.md
 PEAK_FP32_TFLOPS = 157.3           # v_mfma_f32_32x32x2_f32 = the fp32 vector rate
 PEAK_FP8_TFLOPS = 5000.0           # dense MX-scaled fp8 MFMA peak (K = 64 / 128 forms), MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+def nn_ops_mode():
+    from im2im_uq_amd import nn_ops
+    return nn_ops.compute_mode()
+
+
 LIVE_TRAFFIC = {}                  # kernel -> {"traffic_bytes_per_launch", "launches_profiled"}: PMC passes made by THIS run (live_pmc_traffic)
 
 
@@ -247,8 +252,14 @@ class Workload:
         self.x = torch.randn(self.B, self.n_in, self.hw, self.hw, device=dev, generator=self.gen)   # input_normalization: standard
         self.y = torch.rand(self.B, 1, self.hw, self.hw, device=dev, generator=self.gen)          # output_normalization: min-max
         self.allreduce_bytes = int(self.sync.flat.numel() * 4) if self.sync is not None else 0
+        self.graphed = None
 
     def train_step(self):
+        if self.graphed is None:          # the train loop's own rule (GraphedStep.wanted): HIP graph for launch-bound batch shapes
+            from im2im_uq_amd.core.scripts.train import GraphedStep
+            self.graphed = GraphedStep(self.model, self.opt) if GraphedStep.wanted(None, self.y.numel(), self.job.world, nn_ops_mode()) else False
+        if self.graphed:
+            return self.graphed.step((self.x,), self.y)
         pred = self.model(self.x)
         loss = self.model.loss_fn(pred, self.y)
         if self.sync is None:
@@ -278,8 +289,10 @@ class Workload:
         if not overlapped:
             nn_ops.WGRAD_SIDE_STREAM = nn_ops.BWD_PIPELINE = False
         nn_ops.TIMER = nn_ops.KernelTimer()
+        graphed, self.graphed = self.graphed, False          # per-launch events need eager launches
         for _ in range(2):
             self.train_step()
+        self.graphed = graphed
         rows = nn_ops.TIMER.collect()
         nn_ops.TIMER = None
         nn_ops.WGRAD_SIDE_STREAM, nn_ops.BWD_PIPELINE = was
@@ -469,6 +482,7 @@ def sub_record(job, name, steps=4, warmup=2, dtype=None, batch=None, calib=True)
     rec = {"workload": conf["label"], "dtype": conf["dtype"], "per_gpu_batch": wl.B, "steps": steps, "warmup": warmup,
            "value": tr["imgs_per_s"], "unit": "train imgs/s", "ms_per_step": tr["ms_per_step"],
            "host_enqueue_ms_per_step": tr["host_enqueue_ms_per_step"],
+           "hip_graph": bool(wl.graphed),      # the train loop's rule: forward + loss + backward replayed as one HIP graph for launch-bound shapes
            "train_tflops": tr["imgs_per_s"] * wl.train_flop / 1e12,
            "roofline": {k: roof[k] for k in ("achieved", "peak", "frac", "unit", "kernel")},
            "roofline_wgrad": {k: roof_w[k] for k in ("achieved", "peak", "frac", "unit")} if roof_w else None}
@@ -639,7 +653,7 @@ def main():
     if default_run and world == 1:
         others = {}
         for name, kw in (("batch10", dict(config="fastmri", batch=10, steps=10, warmup=3, calib=False)),
-                         ("denoise32", dict(config="denoise32", steps=5)), ("temca1024", dict(config="temca1024", steps=3)),
+                         ("denoise32", dict(config="denoise32", steps=40, warmup=6)), ("temca1024", dict(config="temca1024", steps=3)),
                          ("bsbcm512_fp8", dict(config="bsbcm512", steps=4)), ("bsbcm512_bf16", dict(config="bsbcm512", steps=4, dtype="bf16", calib=False))):
             try:
                 cname = kw.pop("config")

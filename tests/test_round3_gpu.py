@@ -195,3 +195,46 @@ def test_fused_eval_tail_is_bit_identical_to_outconv_plus_heads(utype, shape):
         nn_ops.conv1x1_heads_eval = real
         nn_ops.FUSE_EVAL_TAIL = was
     assert not calls
+
+
+def test_graphed_train_step_is_bit_identical_to_the_eager_loop():
+    """core/scripts/train.py GraphedStep (HIP graph of forward + loss + backward for launch-bound batch shapes, BASELINE
+    configs[0]: 32x32, depth 2): the same batches through the eager loop (train.py:141-165 of the reference) and through the
+    graphed one -- three eager warm-up steps, capture, replays, one short batch of another shape in between (eager fallback)
+    -- give bit-identical losses, parameters and BatchNorm buffers."""
+    from im2im_uq_amd import nn_ops
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from im2im_uq_amd.core.models.trunks.unet import UNet
+    from im2im_uq_amd.core.scripts.train import GraphedStep
+    params = dict(uncertainty_type="quantiles", q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1)
+    nn_ops.set_compute_dtype("bf16")
+    g = torch.Generator().manual_seed(11)
+    batches = [(torch.randn(16 if i != 5 else 7, 1, 32, 32, generator=g), torch.rand(16 if i != 5 else 7, 1, 32, 32, generator=g)) for i in range(9)]
+
+    def run(graph):
+        torch.manual_seed(3)
+        model = add_uncertainty(UNet(1, 1, depth=2), dict(params)).to(DEV).train()
+        opt = nn_ops.FusedAdam(model.parameters(), lr=1e-3)
+        gs = GraphedStep(model, opt) if graph else None
+        losses = []
+        for x, y in batches:
+            x, y = x.to(DEV), y.to(DEV)
+            loss = gs.step((x,), y) if gs else None
+            if loss is None:
+                loss = model.loss_fn(model(x), y)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        if graph:
+            assert gs.graph is not None                       # the step was captured and replayed
+        return torch.stack(losses).cpu(), {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+    le, se = run(False)
+    lg, sg = run(True)
+    assert torch.equal(le, lg), (le, lg)
+    for k in se:
+        assert torch.equal(se[k], sg[k]), k
+    assert GraphedStep.wanted({}, 16 * 32 * 32, 1, "bf16") and not GraphedStep.wanted({}, 10 * 320 * 320, 1, "bf16")
+    assert not GraphedStep.wanted({"hip_graph": True}, 1024, 2, "bf16") and not GraphedStep.wanted({"hip_graph": False}, 1024, 1, "bf16")

@@ -9,13 +9,13 @@ from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
 from im2im_uq_amd.core.models.trunks.unet import UNet
 
 dev = torch.device("cuda:0")
-B = int(os.environ.get("B", 78)); hw = 320
+B = int(os.environ.get("B", 78)); hw = int(os.environ.get("HW", 320)); depth = int(os.environ.get("DEPTH", 4))
 nn_ops.set_compute_dtype("bf16")
 cfg = dict(bench.PARAMS, device=str(dev), batch_size=B, uncertainty_type="quantiles", num_lambdas=100, minimum_lambda=0.0, maximum_lambda=6.0)
 
 def make():
     torch.manual_seed(0)
-    m = add_uncertainty(UNet(1, 1), cfg).to(dev)
+    m = add_uncertainty(UNet(1, 1, depth=depth), cfg).to(dev)
     return m, nn_ops.FusedAdam(m.parameters(), lr=1e-3)
 
 g = torch.Generator(device=dev).manual_seed(1)
@@ -51,5 +51,18 @@ losses_g = []
 def graphed():
     graph.replay(); opt2.step(); losses_g.append(sloss.detach().clone())
 print("graph ms/step, host ms/step:", run(graphed))
+try:
+    m3, opt3 = make()
+    s3 = torch.cuda.Stream(); s3.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s3):
+        for _ in range(3):
+            opt3.zero_grad(set_to_none=True); l3 = m3.loss_fn(m3(x), y); l3.backward(); opt3.step()
+    torch.cuda.current_stream().wait_stream(s3)
+    g3 = torch.cuda.CUDAGraph(); opt3.zero_grad(set_to_none=True)
+    with torch.cuda.graph(g3):
+        sl3 = m3.loss_fn(m3(x), y); sl3.backward(); nn_ops.join_side_streams(); opt3.step()
+    print("graph incl. Adam ms/step, host ms/step:", run(lambda: g3.replay()))
+except Exception as e:  # noqa: BLE001
+    print("graph incl. Adam: failed:", repr(e)[:300])
 le = torch.stack(losses_e).cpu(); lg = torch.stack(losses_g).cpu()
 print("eager losses", le[:6].tolist()); print("graph losses (3 steps later start)", lg[:6].tolist())
