@@ -321,6 +321,9 @@ class GraphedStep:
         for dst, src in zip(self.xs, x):
             dst.copy_(src, non_blocking=True)
         self.y.copy_(labels, non_blocking=True)
+        if self.graph is not None and any(p.data_ptr() != a for p, a in zip(self.params, self.addr)):
+            # the parameters moved (train_net's checkpoint does net.cpu() ... net.to(device)): the captured addresses are stale
+            self.graph, self.done = None, 0
         if self.graph is None and self.done < self.WARM:
             self.stream.wait_stream(cur)
             with torch.cuda.stream(self.stream):
@@ -339,6 +342,7 @@ class GraphedStep:
                 self.loss = self._eager()
                 nn_ops.join_side_streams()
             self.grads = [p.grad for p in self.params]
+            self.addr = [p.data_ptr() for p in self.params]
         self.graph.replay()
         for p, g in zip(self.params, self.grads):            # an eager step in between re-pointed p.grad
             p.grad = g
