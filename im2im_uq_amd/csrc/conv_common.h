@@ -85,14 +85,17 @@ __device__ __forceinline__ void merge_moments_f32(float& n, float& m, float& q, 
 // small-extent ones (40x40, 20x20) so that little of a tile hangs over the image edge while a weight tile is still
 // amortised over 256 output pixels.
 struct TileChoice { int tb, th, tw, bn; };
-inline TileChoice pick_tile(int H, int W, int Co, bool per_image = false) {
+inline TileChoice pick_tile(int B, int H, int W, int Co, bool per_image = false) {
   const bool small = (H < 64 || W < 64) && !per_image;       // per_image: every tile (and its statistics row) lies in ONE image
   const int bn = (Co % 128 == 0) ? 128 : (Co % 64 == 0) ? 64 : 32;
   // 64 output channels (the full-resolution layers): 32 x 16 pixels, so that a wave owns 128 pixels x 64 channels and a weight
   // fragment read from L2 feeds four MFMAs as in the 128-wide tiles (conv_mfma.hip DIRECTW)
   if (!small && bn == 64 && !per_image && H % 32 == 0) return {1, 32, 16, bn};
   if (!small) return {1, 16, 16, bn};
-  return TileChoice{4, 8, 8, bn};
+  // [r3] small batches (the per-GPU share of a strong-scaled job): when four-image tiles would leave the chip's workgroup slots
+  // more than half empty, two-image tiles (M = 128, 64 accumulators, three workgroups per CU) double the launch
+  const long wgs4 = (long)cdiv(B, 4) * cdiv(H, 8) * cdiv(W, 8) * (Co / bn);
+  return TileChoice{wgs4 < 384 ? 2 : 4, 8, 8, bn};
 }
 
 // conv_pp.hip: the 8-wave ping-pong kernel; returns IM2IM_OK / an error, or 1 when the problem is not one of its shapes

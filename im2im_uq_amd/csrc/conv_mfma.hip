@@ -1138,12 +1138,17 @@ int dispatch_conv(const ConvArgs& a, hipStream_t stream, bool per_image = false)
       if (rc != 1) return rc;
     }
   }
-  const TileChoice t = pick_tile(a.H, a.W, a.Co, per_image);
+  const TileChoice t = pick_tile(a.B, a.H, a.W, a.Co, per_image);
   if (t.tb == 1) {
     if (t.bn == 128) return launch_conv<T, 1, 16, 16, 128, 2, 2, TAPS>(a, stream);
     if (t.bn == 64 && t.th == 32) return launch_conv<T, 1, 32, 16, 64, 4, 1, TAPS>(a, stream);
     if (t.bn == 64) return launch_conv<T, 1, 16, 16, 64, 4, 1, TAPS>(a, stream);
     return launch_conv<T, 1, 16, 16, 32, 4, 1, TAPS>(a, stream);
+  }
+  if (t.tb == 2) {
+    if (t.bn == 128) return launch_conv<T, 2, 8, 8, 128, 2, 2, TAPS>(a, stream);
+    if (t.bn == 64) return launch_conv<T, 2, 8, 8, 64, 4, 1, TAPS>(a, stream);
+    return launch_conv<T, 2, 8, 8, 32, 4, 1, TAPS>(a, stream);
   }
   if (t.bn == 128) return launch_conv<T, 4, 8, 8, 128, 2, 2, TAPS>(a, stream);
   if (t.bn == 64) return launch_conv<T, 4, 8, 8, 64, 4, 1, TAPS>(a, stream);
@@ -1153,7 +1158,7 @@ int dispatch_conv(const ConvArgs& a, hipStream_t stream, bool per_image = false)
 }  // namespace
 
 extern "C" int64_t im2im_conv_stats_rows(int32_t B, int32_t H, int32_t W, int32_t Co) {
-  const TileChoice t = pick_tile(H, W, Co);
+  const TileChoice t = pick_tile(B, H, W, Co);
   return im2im::cdiv(B, t.tb) * im2im::cdiv(H, t.th) * im2im::cdiv(W, t.tw);
 }
 

@@ -543,8 +543,8 @@ int launch_conv_pp(const ConvArgs& a, hipStream_t stream) {
   if (a.bn_partial) return 1;
 #endif
   if (!mode || a.in_ss_img) return 1;
-  const TileChoice tc = pick_tile(a.H, a.W, a.Co);
-  if (tc.tb == 1 && tc.th != 16) return 1;                       // a tile shape only the 4-wave kernel has (statistics rows follow it)
+  const TileChoice tc = pick_tile(a.B, a.H, a.W, a.Co);
+  if ((tc.tb == 1 && tc.th != 16) || (tc.tb != 1 && tc.tb != 4)) return 1;                       // a tile shape only the 4-wave kernel has (statistics rows follow it)
   if (tc.bn == 128 && (mode & 1)) {
     if (tc.tb == 1) return launch_pp<1, 16, 16, 128, 2, 2>(a, stream);
     return launch_pp<4, 8, 8, 128, 2, 2>(a, stream);
