@@ -48,6 +48,8 @@ CONV_CASES = [
     (2, 33, 17, 64, 32, 1),       # 1x1, small
     (1, 96, 80, 64, 32, 1),       # 1x1, 16x16 tiles
     (1, 9, 7, 256, 256, 9),       # deep level style
+    (16, 40, 40, 128, 512, 9),    # [r3] 4-image 8x8 tiles (>= 384 workgroups: the shape class of the batch-78 deep levels; smaller
+                                  #      launches now take 2-image tiles, e.g. the first two cases)
     (3, 64, 72, 64, 64, 9),       # [r3] 32x16 tiles of the 64-output-channel layers (H % 32 == 0), overhang in W, odd batch
     (2, 96, 80, 128, 64, 9),      # [r3] 32x16 tiles, 4 K-chunks; data-gradient = 64 -> 128 on the direct-weight 128-wide tile
 ]
