@@ -241,3 +241,32 @@ def test_graphed_train_step_is_bit_identical_to_the_eager_loop():
         assert torch.equal(se[k], sg[k]), k
     assert GraphedStep.wanted({}, 16 * 32 * 32, 1, "bf16") and not GraphedStep.wanted({}, 10 * 320 * 320, 1, "bf16")
     assert not GraphedStep.wanted({"hip_graph": True}, 1024, 2, "bf16") and not GraphedStep.wanted({"hip_graph": False}, 1024, 1, "bf16")
+
+
+def test_train_net_with_and_without_the_hip_graph_gives_the_same_model(tmp_path, monkeypatch):
+    """train_net (core/scripts/train.py, the reference's train loop :141-165) on a 32x32 dataset: IM2IM_HIP_GRAPH=0 (eager loop)
+    and =1 (GraphedStep: warm-up, capture, replays, the short last batch of every epoch eager, re-capture after the per-epoch
+    checkpoint moved the parameters) end in bit-identical state_dicts."""
+    from torch.utils.data import TensorDataset
+    from im2im_uq_amd import nn_ops
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from im2im_uq_amd.core.models.trunks.unet import UNet
+    from im2im_uq_amd.core.scripts.train import train_net
+    params = dict(uncertainty_type="quantiles", q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1, alpha=0.1, delta=0.1,
+                  num_lambdas=50, rcps_loss="fraction_missed", minimum_lambda=0, maximum_lambda=6, device=DEV, dataset="synthetic",
+                  batch_size=8, lr=1e-3, input_normalization="standard", output_normalization="min-max", num_validation_images=2)
+    nn_ops.set_compute_dtype("bf16")
+    g = torch.Generator().manual_seed(5)
+    train = TensorDataset(torch.randn(44, 1, 32, 32, generator=g), torch.rand(44, 1, 32, 32, generator=g))     # 5 full batches + one of 4
+    val = TensorDataset(torch.randn(8, 1, 32, 32, generator=g), torch.rand(8, 1, 32, 32, generator=g))
+    states = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("IM2IM_HIP_GRAPH", flag)
+        torch.manual_seed(9)
+        model = add_uncertainty(UNet(1, 1, depth=2), dict(params))
+        model = train_net(model, train, val, DEV, epochs=3, batch_size=8, lr=1e-3, load_from_checkpoint=False,
+                          checkpoint_dir=str(tmp_path / f"ck{flag}"), checkpoint_every=1, validate_every=10, config=dict(params))
+        torch.cuda.synchronize()
+        states.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    for k in states[0]:
+        assert torch.equal(states[0][k], states[1][k]), k
