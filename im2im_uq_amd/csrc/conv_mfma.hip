@@ -8,8 +8,11 @@
 // K = taps * Cin.  Per workgroup (256 threads = 4 waves):
 //   * the input halo patch (TH+2)x(TW+2) x 32 channels is staged once per Cin-chunk into LDS and
 //     re-used by all 9 taps (a tap is just an LDS address offset);
-//   * the weight tile [BN][32] of one (tap, Cin-chunk) is double-buffered in LDS, the next one is
-//     prefetched into registers while the MFMAs of the current one issue;
+//   * weights: bf16 3x3 tiles whose waves own 128 pixels x 64 channels (the 128-wide tiles, the 32x16x64 tile) read each
+//     32 x 16 operand fragment straight from L2 into registers, one tap ahead, from a fragment-major pack (conv_common.h
+//     wfrag_index) -- no weight LDS traffic, two barriers per chunk [r3]; every other variant (fp32, 1x1, 4 x 1-wave tiles)
+//     double-buffers the weight tile [BN][32] of one (tap, Cin-chunk) in LDS, the next one prefetched into registers while
+//     the MFMAs of the current one issue;
 //   * v_mfma_f32_32x32x16_bf16 (bf16 in, fp32 accumulate) or v_mfma_f32_32x32x2_f32 (exact fp32,
 //     parity mode); operand/result lane maps verified on hardware (tools/hwprobe).
 //   * epilogue: + bias, optional folded-BN affine + ReLU (eval), store, and per-channel partial
