@@ -793,9 +793,16 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
   constexpr int NT = 768;
   constexpr int HH = TH + 2, HWD = TW + 2, HPX = HH * HWD;
   constexpr int M = TH * TW;
-  constexpr int CT = 64, EPP = 8, PPR = 8, PB = 192;   // x: 64 input channels per workgroup, 128 B of data + 64 B pad per pixel
+  // [r3] TH = 16 (256-pixel tiles, COT = 64 only): twice the MFMA work between two barriers, so a tile's loads have twice as long
+  // to arrive (the 320x320 layers wait on HBM at every 128-pixel tile: cache-hot loads ran them 34 % faster), and 1.27x instead of
+  // 1.41x halo.  Two such tiles only fit the LDS unpadded (128 B per pixel): instead of the 64-byte pad, the 64-byte half of a
+  // pixel row is XOR-swizzled with bit 1 of the row index, which gives the transposing reads (4 consecutive rows x 64 B per 32
+  // lanes) four distinct 16-bank windows again.
+  constexpr bool SWZ = TH == 16;
+  static_assert(!SWZ || COT == 64, "swizzled 256-pixel tiles: 64 output channels");
+  constexpr int CT = 64, EPP = 8, PPR = 8, PB = SWZ ? 128 : 192;   // x: 64 input channels per workgroup, 128 B of data (+ 64 B pad) per pixel
   constexpr int CJ = COT / 64;                         // 32-channel co sub-blocks per wave
-  constexpr int PA = COT * 2 + 64;                     // dz pixel pitch: 192 / 320 B (rows land on distinct 16-bank windows)
+  constexpr int PA = SWZ ? COT * 2 : COT * 2 + 64;     // dz pixel pitch: 192 / 320 B (rows land on distinct 16-bank windows), 128 swizzled
   constexpr int PPRA = COT / 8;                        // 16-byte pieces per dz pixel
   constexpr int A_BYTES = M * PA, B_BYTES = HPX * PB, BUF_BYTES = A_BYTES + B_BYTES;
   constexpr int A_ROUNDS = (M * PPRA + NT - 1) / NT, B_ROUNDS = (HPX * PPR + NT - 1) / NT;
@@ -903,7 +910,8 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
     if (abl_first)
 #endif
 #pragma unroll
-    for (int i = 0; i < A_ROUNDS; ++i) if (a_px[i] >= 0) *reinterpret_cast<uint4*>(la + a_px[i] * PA + a_part[i] * 16) = R.a[i];
+    for (int i = 0; i < A_ROUNDS; ++i)
+      if (a_px[i] >= 0) *reinterpret_cast<uint4*>(la + a_px[i] * PA + (SWZ ? (a_part[i] ^ (((a_px[i] >> 1) & 1) << 2)) : a_part[i]) * 16) = R.a[i];
 #if IM2IM_WGRAD_ABL & 16
     abl_first = false;
 #endif
@@ -924,7 +932,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
           }
           Vec16<T>::store(reinterpret_cast<T*>(&v), f);
         }
-        *reinterpret_cast<uint4*>(lb + b_px[i] * PB + b_part[i] * 16) = v;
+        *reinterpret_cast<uint4*>(lb + b_px[i] * PB + (SWZ ? (b_part[i] ^ (((b_px[i] >> 1) & 1) << 2)) : b_part[i]) * 16) = v;
       }
     }
   };
@@ -934,8 +942,13 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
     // k-step ks covers tile row ks (TW == 16): every address below is lane base + compile-time constant, so the fully
     // unrolled loop has no address arithmetic (it was ~5 VALU per MFMA when only partially unrolled)
     static_assert(TW == 16, "k-step == one 16-pixel tile row");
-    const char* pa = la + (half * 8 + tr_row) * PA + wco * (COT / 2) * 2 + tr_col_b;
-    const char* pb = lb + (half * 8 + tr_row) * PB + wci * 64 + tr_col_b;
+    // swizzled tiles: a lane's rows are (multiple of 4) + tr_row [+ 4], so bit 1 of the row index is bit 1 of tr_row for the dz
+    // rows, and bit 1 of (c + tr_row) for halo pixel c + tr_row, c = (tg + ks) * 18 + kw (+ 8 * half): four per-lane variants
+    const char* pa = la + (half * 8 + tr_row) * PA + (SWZ ? ((wco ^ ((tr_row >> 1) & 1)) << 6) : wco * (COT / 2) * 2) + tr_col_b;
+    const char* pb = lb + (half * 8 + tr_row) * PB + (SWZ ? 0 : wci * 64 + tr_col_b);
+    int xo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xo[j] = SWZ ? (((wci ^ (((((j + 2 * tg) & 3) + tr_row) >> 1) & 1)) << 6) + tr_col_b) : 0;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       short8 fa[CJ];
@@ -943,7 +956,8 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
       for (int j = 0; j < CJ; ++j) fa[j] = WFrag<bf16_t>::load(pa + j * 64 + ks * 16 * PA, pa + j * 64 + (ks * 16 + 4) * PA);
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
-        const short8 fb = WFrag<bf16_t>::load(pb + (ks * HWD + kw) * PB, pb + (ks * HWD + kw + 4) * PB);
+        const int xj = xo[(2 * ks + kw) & 3];            // compile-time index after unrolling; 0 unswizzled
+        const short8 fb = WFrag<bf16_t>::load(pb + xj + (ks * HWD + kw) * PB, pb + xj + (ks * HWD + kw + 4) * PB);
 #pragma unroll
         for (int j = 0; j < CJ; ++j) acc[j][kw] = WFrag<bf16_t>::mfma(fa[j], fb, acc[j][kw]);
       }
@@ -1250,6 +1264,7 @@ extern "C" int im2im_conv_dgrad_bn(const void* dz, const void* wd, void* dx, con
 
 namespace {
 int g_wgrad_co128 = 1;      // A/B switch (im2im_set_option "wgrad_co128")
+int g_wgrad_tile16 = 1;     // A/B switch "wgrad_tile16": 256-pixel tiles for the 64-output-channel form
 template <typename T, int TAPS>
 int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float* x_ss_hi, int Ci_lo, const void* dz, float* partial,
                  int64_t partial_bytes, float* dw, int B, int H, int W, int Ci, int Co, hipStream_t stream) {
@@ -1291,6 +1306,23 @@ int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float
       }
       hipLaunchKernelGGL(kern, dim3((unsigned)cb128, (unsigned)nsplit), dim3(768), smem128, stream, a);
       if (int rc = check_launch("conv_wgrad_pipe_kernel<128>")) return rc;
+    } else if (g_wgrad_tile16 && H >= 64 && W >= 64) {
+      // 64 output channels at the large-extent levels: 256-pixel tiles in the swizzled LDS layout (see the kernel)
+      WgradArgs a16 = a;
+      a16.tilesY = (int)cdiv(H, 16); a16.tilesX = (int)cdiv(W, 16);
+      a16.ntiles = B * a16.tilesY * a16.tilesX;
+      if (nsplit > a16.ntiles) nsplit = a16.ntiles;
+      a16.tiles_per_split = (int)cdiv(a16.ntiles, nsplit);
+      nsplit = cdiv(a16.ntiles, a16.tiles_per_split);
+      constexpr size_t smem16 = 2 * ((size_t)16 * 16 * 128 + (size_t)18 * 18 * 128);
+      auto kern = conv_wgrad_pipe_kernel<16, 16, 64>;
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)cblocks, (unsigned)nsplit), dim3(768), smem16, stream, a16);
+      if (int rc = check_launch("conv_wgrad_pipe_kernel<16,16,64>")) return rc;
     } else {
     constexpr size_t smem2 = 2 * smem;                        // double-buffered tiles, one 12-wave workgroup per CU
     auto kern = conv_wgrad_pipe_kernel<TH, TW, 64>;
@@ -1383,6 +1415,7 @@ extern "C" int im2im_set_option(const char* key, int32_t value) {
   IM2IM_REQUIRE(key != nullptr);
   if (std::string(key) == "conv_pp") { im2im::set_conv_pp_mode(value); return IM2IM_OK; }
   if (std::string(key) == "wgrad_co128") { g_wgrad_co128 = value; return IM2IM_OK; }
+  if (std::string(key) == "wgrad_tile16") { g_wgrad_tile16 = value; return IM2IM_OK; }
   return im2im::fail_invalid("unknown option");
 }
 
