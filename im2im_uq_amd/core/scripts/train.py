@@ -302,6 +302,17 @@ class GraphedStep:
             return True
         return labels_numel <= (1 << 18)
 
+    @staticmethod
+    def static_module(net, config):
+        """a replayed graph repeats the kernel sequence of the captured step, so "auto" only applies to networks made of this
+        package's own modules and plain torch.nn layers (a user-supplied trunk or final layer may branch in Python on its data; `hip_graph: true` forces
+        the graph for those as well)."""
+        try:
+            forced = config.get("hip_graph", "auto") is True or os.environ.get("IM2IM_HIP_GRAPH") == "1"
+        except Exception:  # noqa: BLE001
+            forced = os.environ.get("IM2IM_HIP_GRAPH") == "1"
+        return forced or all(type(m).__module__.startswith(("im2im_uq_amd.", "torch.nn.modules.")) for m in net.modules())
+
     def _eager(self):
         pred = self.net(*self.xs)
         loss = self.net.loss_fn(pred, self.y)
@@ -439,7 +450,7 @@ def train_net(net, train_dataset, val_dataset, device, epochs, batch_size, lr, l
 
             if graphed is None:
                 graphed = GraphedStep(net, optimizer) if (torch.device(device).type == "cuda" and GraphedStep.wanted(
-                    config, labels.numel(), world, nn_ops.compute_mode())) else False
+                    config, labels.numel(), world, nn_ops.compute_mode()) and GraphedStep.static_module(net, config)) else False
             if graphed:
                 gl = graphed.step(x, labels)
                 if gl is not None:
