@@ -257,9 +257,11 @@ class Workload:
     def train_step(self):
         if self.graphed is None:          # the train loop's own rule (GraphedStep.wanted): HIP graph for launch-bound batch shapes
             from im2im_uq_amd.core.scripts.train import GraphedStep
-            self.graphed = GraphedStep(self.model, self.opt) if GraphedStep.wanted(None, self.y.numel(), self.job.world, nn_ops_mode()) else False
+            self.graphed = GraphedStep(self.model, self.opt, self.sync) if GraphedStep.wanted(None, self.y.numel(), self.job.world, nn_ops_mode()) else False
         if self.graphed:
-            return self.graphed.step((self.x,), self.y)
+            out = self.graphed.step((self.x,), self.y, self.loss_weight if self.sync is not None else 1.0)
+            if out is not None:
+                return out
         pred = self.model(self.x)
         loss = self.model.loss_fn(pred, self.y)
         if self.sync is None:

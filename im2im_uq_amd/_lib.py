@@ -42,7 +42,7 @@ SIGNATURES = {
     "im2im_hb_mu_plus": (_f64, [_f64, _i64, _f64, _i32]),
     "im2im_hb_mu_plus_batch": (_i32, [_ptr, _i64, _i64, _f64, _i32, _ptr]),
     "im2im_set_option": (_i32, [ctypes.c_char_p, _i32]),
-    "im2im_rcps_scan": (_i32, [_ptr, _i64, _i32, _i64, _i64, _ptr, _f64, _f64, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "im2im_rcps_scan": (_i32, [_ptr, _i64, _i32, _i64, _i64, _ptr, _f64, _f64, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "im2im_pack_conv_weight": (_i32, [_ptr, _i32, _i32, _i32, _i32, _ptr, _ptr, _ptr]),
     "im2im_pack_conv_weights_multi": (_i32, [_i32, _ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr]),
     "im2im_conv_stats_rows": (_i64, [_i32, _i32, _i32, _i32]),
@@ -50,6 +50,9 @@ SIGNATURES = {
     # x, in_ss, x_hi, in_ss_hi, Ci_lo, wf, bias, center, scale, shift, y, y_hi, Co_lo, stats, B, H, W, Ci, Co, taps, relu, dtype, stream
     "im2im_conv_fwd_split": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr,
                                     _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
+    "im2im_conv_splitk_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    "im2im_conv_fwd_split_ws": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr,
+                                       _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr, _i64, _ptr]),
     "im2im_conv_fp8_stats_rows": (_i64, [_i32, _i32, _i32]),
     "im2im_pack_conv_weight_fp8": (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr, _ptr]),
     # x, in_ss, x_hi, in_ss_hi, Ci_lo, wq, wscale, bias, scale, shift, y, stats, B, H, W, Ci, Co, relu, stream
@@ -114,6 +117,7 @@ SIGNATURES = {
     "im2im_fastmri_abs_normalize": (_i32, [_ptr, _ptr, _i32, _i32, _i32, _i32, _f32, _f32, _ptr]),
     "im2im_center_crop_affine": (_i32, [_ptr, _ptr, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _ptr]),
     "im2im_adam_step": (_i32, [_i32, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _f32, _f32, _i64, _ptr]),
+    "im2im_adam_step_dev": (_i32, [_i32, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _f32, _f32, _ptr, _ptr, _ptr]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)

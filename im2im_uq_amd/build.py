@@ -25,8 +25,8 @@ SOURCES = {
     "common.cpp": [],
     "hb_bound.cpp": ["-ffp-contract=off"],
     "rcps.hip": ["-ffp-contract=off"],
-    "conv_mfma.hip": ["-ffp-contract=off"],
-    "conv_pp.hip": ["-ffp-contract=off"],     # lazy BatchNorm+ReLU in the operand staging must round exactly like bn_relu_apply
+    "conv_mfma.hip": ["-ffp-contract=off"],   # lazy BatchNorm+ReLU in the operand staging must round exactly like bn_relu_apply
+    "conv_wgrad.hip": ["-ffp-contract=off"],  # (the same lazy transform on the weight gradient's x operand)
     "elementwise.hip": ["-ffp-contract=off"],
     "smallconv.hip": ["-ffp-contract=off"],
     "fastmri.hip": ["-ffp-contract=off"],

@@ -24,8 +24,10 @@ from .eval import eval_net, get_images
 
 
 def _dist():
+    """torch.distributed when this process is one of several ranks (IM2IM_DIST_SINGLE_RANK=1: also for a world of ONE rank, so
+    that every collective call site can be executed on RCCL by a one-GPU box -- tests/test_graph_ddp_gpu.py)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("IM2IM_DIST_SINGLE_RANK") == "1"):
         return dist
     return None
 
@@ -92,16 +94,18 @@ class GradSync:
         self.launched = [None] * len(self.buckets)
         self.ready = [False] * len(self.buckets)
         self.next_bucket = 0                    # buckets [0, next_bucket) are launched
+        self.deferred = False                   # True: the hooks only count; nothing is launched before pack_all() / finish()
+        self.hook_handles = []
         if self.dist is not None:
             for i, p in enumerate(self.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+                self.hook_handles.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
 
     def _make_hook(self, i):
         def hook(_p):
             b = self.bucket_of[i]
             self.fired.add(i)
             self.seen[b] += 1
-            if self.expected is not None and self.seen[b] == self.expected[b]:
+            if self.expected is not None and self.seen[b] == self.expected[b] and not self.deferred:
                 self.ready[b] = True
                 # drain in index order; a bucket that is not complete yet (or whose parameters got no gradient on the
                 # learning step, expected == -1) holds back the later ones until it completes / until finish()
@@ -143,6 +147,39 @@ class GradSync:
         for p in self.params:
             p.grad = None
 
+    def own_hook_ids(self):
+        """ids of the post-accumulate hooks this object registered (GraphedStep.static_module tells them from a user's)."""
+        return {h.id for h in self.hook_handles}
+
+    def _reset(self):
+        if self.expected is None:                                  # learnt on the first step: parameters per bucket that get a gradient
+            exp = [0] * len(self.buckets)
+            for i in self.fired:
+                exp[self.bucket_of[i]] += 1
+            self.expected = [e if e > 0 else -1 for e in exp]
+        self.seen = [0] * len(self.buckets)
+        self.fired = set()
+        self.launched = [None] * len(self.buckets)
+        self.ready = [False] * len(self.buckets)
+        self.next_bucket = 0
+
+    def pack_all(self):
+        """deferred mode, after backward(): every bucket's gradients copied into the flat buffer on the current stream, no
+        collective (GraphedStep captures exactly this; the exchange follows outside the graph with reduce_all)."""
+        for b in range(len(self.buckets)):
+            self._pack(b)
+        self._reset()
+
+    def reduce_all(self):
+        """all-reduce the packed flat buffer bucket by bucket (index order, asynchronous, then waited for) and point every
+        p.grad at its slice."""
+        if self.dist is not None:
+            hs = [self.dist.all_reduce(self.flat[lo:hi], async_op=True) for lo, hi, _ in self.buckets]
+            for h in hs:
+                h.wait()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
     def finish(self):
         """call after backward(): every bucket reduced, visible to the current stream, and p.grad = its flat slice."""
         if self.dist is not None:
@@ -150,16 +187,7 @@ class GradSync:
                 self._launch(b)                                    # no local images) -- still in index order
             for h in self.launched:
                 h.wait()
-            if self.expected is None:
-                exp = [0] * len(self.buckets)
-                for i in self.fired:
-                    exp[self.bucket_of[i]] += 1
-                self.expected = [e if e > 0 else -1 for e in exp]
-            self.seen = [0] * len(self.buckets)
-            self.fired = set()
-            self.launched = [None] * len(self.buckets)
-            self.ready = [False] * len(self.buckets)
-            self.next_bucket = 0
+            self._reset()
         else:
             for b in range(len(self.buckets)):
                 self._pack(b)
@@ -197,7 +225,8 @@ def broadcast_module_state(net, src=0, buffers_only=False):
     with torch.no_grad():
         for t in ([] if buffers_only else list(net.parameters())) + list(net.buffers()):
             if t.numel():
-                dist.broadcast(t.data, src=src)
+                dist.broadcast(t.detach(), src=src)      # detach() shares the version counter (`.data` would not bump it:
+                                                         # the packed-weight caches of nn_ops key on it)
 
 
 class GlobalBatchSampler(torch.utils.data.Sampler):
@@ -264,30 +293,51 @@ def run_validation(net, val_loader, val_dataset, device, global_step, epoch, con
 
 
 class GraphedStep:
-    """Forward + loss + backward of one fixed batch shape as ONE HIP graph (the launch-bound regime: a 32x32 depth-2 step is
-    ~150 kernel launches of a few microseconds each, 2.9 ms of host enqueue for 1.2 ms of GPU work; replaying the captured
-    graph costs the host 0.5 ms -- 11 k -> 26 k img/s, `profiles/r03_ab_experiments.txt`).  Same arithmetic, same kernels, same
-    order: the losses are bit-identical to the eager loop's (tools/graph_probe.py, tests/test_round3_gpu.py).
+    """One training step of a fixed batch shape as ONE HIP graph (the launch-bound regime: a 32x32 depth-2 step is ~150 kernel
+    launches of a few microseconds each, 2.9 ms of host enqueue for 1.2 ms of GPU work; replaying the captured graph costs the
+    host 0.5 ms -- 11 k -> 26 k img/s, `profiles/r03_ab_experiments.txt`).  Same arithmetic, same kernels, same order: losses,
+    parameters and buffers are bit-identical to the eager loop's (tests/test_round3_gpu.py, tests/test_round4_gpu.py).
+
+    What is in the graph: forward, loss, backward (weight re-packing, BatchNorm running statistics and `num_batches_tracked`
+    are kernels), and -- [r4] -- the optimizer step: FusedAdam is switched to `capturable` (step count on the device,
+    im2im_adam_step_dev), so a replayed update has the right bias correction.  Another optimizer stays outside the graph.
+
+    Data parallelism [r4] (`sync`: this rank's GradSync): the graph holds forward + backward + the packing of the gradients
+    into GradSync's flat buffer; the all-reduce of the buckets is issued by the host right after the replay (any backend: gloo
+    cannot be captured) and FusedAdam runs after it.  With backend nccl and IM2IM_GRAPH_COLLECTIVES=1 the RCCL all-reduces are
+    captured too (they are launched from the backward hooks, so the exchange overlaps the rest of the backward inside the
+    graph) and the whole step is one replay.
 
     The first WARM steps run eagerly on the capture stream (they are real training steps), then the step is captured once and
-    replayed; Adam stays outside the graph (its bias correction takes the step count as a host scalar).  A batch of another
-    shape (the short last one of an epoch) makes `step` return None and the caller runs it eagerly.  Weight re-packing,
-    BatchNorm running statistics and `num_batches_tracked` are kernels and are part of the graph.  Single process, bf16 / fp32
-    (the fp8 mode rotates its amax slots on the host)."""
+    replayed.  A batch of another shape (the short last one of an epoch) or another loss weight makes `step` return None and
+    the caller runs it eagerly.  A capture that fails (a module that synchronises, a hook that reads a tensor) is abandoned:
+    the optimizer's counters are put back, `failed` is set and every later call returns None.  fp8 mode is not captured (it
+    rotates its amax slots on the host)."""
     WARM = 3
 
-    def __init__(self, net, optimizer):
-        self.net, self.opt = net, optimizer
+    def __init__(self, net, optimizer, sync=None):
+        self.net, self.opt, self.sync = net, optimizer, sync
         self.params = [p for p in net.parameters() if p.requires_grad]
         self.stream = torch.cuda.Stream()
         self.graph = None
         self.key = None
         self.done = 0
+        self.failed = False
+        self.adam_in_graph = isinstance(optimizer, nn_ops.FusedAdam)
+        if self.adam_in_graph:
+            optimizer.capturable = True              # from its first step on: eager and replayed steps use the same kernels
+        backend = None
+        if sync is not None and sync.dist is not None:
+            backend = sync.dist.get_backend()
+        self.collectives_in_graph = (sync is not None and sync.dist is not None and backend == "nccl"
+                                     and os.environ.get("IM2IM_GRAPH_COLLECTIVES", "0") == "1")
+        self.replays = 0
 
     @staticmethod
     def wanted(config, labels_numel, world, dtype_name):
         """config key `hip_graph` (True / False / "auto", default auto; env IM2IM_HIP_GRAPH=0/1 overrides): auto = batches of at
-        most 2^18 label pixels -- above that the step is GPU-bound and a graph gains nothing (batch 10 at 320x320: 7.7 vs 7.3 ms)."""
+        most IM2IM_HIP_GRAPH_MAX_PIXELS label pixels (default 2^18) in a single process -- above that the step is GPU-bound and
+        a graph gains nothing (`profiles/r04_ab_experiments.txt`); with several ranks only when asked for (True / env 1)."""
         env = os.environ.get("IM2IM_HIP_GRAPH")
         if env is not None:
             want = {"0": False, "1": True}.get(env, "auto")
@@ -296,34 +346,127 @@ class GraphedStep:
                 want = config.get("hip_graph", "auto")
             except Exception:  # noqa: BLE001  (no config / a config object without .get)
                 want = "auto"
-        if world > 1 or dtype_name == "fp8" or want is False or str(want).lower() in ("false", "0"):
+        if dtype_name == "fp8" or want is False or str(want).lower() in ("false", "0"):
             return False
         if want is True or str(want).lower() in ("true", "1"):
             return True
-        return labels_numel <= (1 << 18)
+        return world == 1 and labels_numel <= int(os.environ.get("IM2IM_HIP_GRAPH_MAX_PIXELS", str(1 << 18)))
 
     @staticmethod
-    def static_module(net, config):
+    def has_foreign_hooks(net, sync=None):
+        """a replayed graph runs no Python: forward / backward hooks on a module and tensor hooks on a parameter (wandb.watch
+        registers both) would silently stop firing.  GradSync's own post-accumulate hooks are accounted for by this class."""
+        own = sync.own_hook_ids() if sync is not None else set()
+        for m in net.modules():
+            for name in ("_forward_hooks", "_forward_pre_hooks", "_backward_hooks", "_backward_pre_hooks"):
+                if getattr(m, name, None):
+                    return True
+        for p in net.parameters():
+            if getattr(p, "_backward_hooks", None):
+                return True
+            post = getattr(p, "_post_accumulate_grad_hooks", None)
+            if post and any(k not in own for k in post):
+                return True
+        return False
+
+    @staticmethod
+    def static_module(net, config, sync=None):
         """a replayed graph repeats the kernel sequence of the captured step, so "auto" only applies to networks made of this
-        package's own modules and plain torch.nn layers (a user-supplied trunk or final layer may branch in Python on its data; `hip_graph: true` forces
-        the graph for those as well)."""
+        package's own modules and plain torch.nn layers (a user-supplied trunk or final layer may branch in Python on its data)
+        that carry no hooks; `hip_graph: true` forces the graph for those as well."""
         try:
             forced = config.get("hip_graph", "auto") is True or os.environ.get("IM2IM_HIP_GRAPH") == "1"
         except Exception:  # noqa: BLE001
             forced = os.environ.get("IM2IM_HIP_GRAPH") == "1"
-        return forced or all(type(m).__module__.startswith(("im2im_uq_amd.", "torch.nn.modules.")) for m in net.modules())
+        if forced:
+            return True
+        return (all(type(m).__module__.startswith(("im2im_uq_amd.", "torch.nn.modules.")) for m in net.modules())
+                and not GraphedStep.has_foreign_hooks(net, sync))
 
-    def _eager(self):
+    # ------------------------------------------------------------------ the pieces of a step
+    def _fwd_bwd(self):
         pred = self.net(*self.xs)
         loss = self.net.loss_fn(pred, self.y)
-        self.opt.zero_grad(set_to_none=True)
-        loss.backward()
+        if self.sync is None:
+            self.opt.zero_grad(set_to_none=True)
+            loss.backward()
+        else:
+            self.sync.zero_grad()
+            (loss * self.weight).backward()
         return loss
 
-    def step(self, x, labels):
-        key = (tuple((tuple(t.shape), t.dtype) for t in x), tuple(labels.shape), labels.dtype)
+    def _eager(self):
+        """exactly the step train_net's plain loop runs (the WARM steps)."""
+        loss = self._fwd_bwd()
+        if self.sync is not None:
+            self.sync.finish()
+        nn_ops.join_side_streams()
+        self.opt.step()
+        return loss.detach() * self.weight if self.sync is not None else loss.detach()
+
+    def _addresses(self):
+        return (tuple(p.data_ptr() for p in self.params), tuple(b.data_ptr() for b in self.net.buffers() if b is not None),
+                nn_ops._Scratch.addresses())
+
+    def _capture(self, cur):
+        nn_ops._Scratch.pinned = True
+        steps_before = [(p, self.opt.state[p].get("step")) for p in self.params if self.opt.state.get(p)] if self.adam_in_graph else []
+        ctrs_before = dict(self.opt._ctrs) if self.adam_in_graph else None
+        graph = torch.cuda.CUDAGraph()
+        try:
+            if self.sync is None:
+                self.opt.zero_grad(set_to_none=True)
+            else:
+                self.sync.zero_grad()
+                self.sync.deferred = not self.collectives_in_graph
+            self.stream.wait_stream(cur)
+            with torch.cuda.graph(graph, stream=self.stream):
+                loss = self._fwd_bwd()
+                if self.sync is not None:
+                    if self.collectives_in_graph:
+                        self.sync.finish()
+                    else:
+                        self.sync.pack_all()
+                nn_ops.join_side_streams()
+                self.in_graph_opt = self.adam_in_graph and (self.sync is None or self.collectives_in_graph)
+                if self.in_graph_opt:
+                    self.opt.step()
+                self.loss = loss.detach() * self.weight if self.sync is not None else loss.detach()
+        except Exception as e:  # noqa: BLE001
+            self.failed = True
+            self.error = f"{type(e).__name__}: {e}"
+            if self.sync is not None:
+                self.sync.deferred = False
+                self.sync._reset()
+            for p, st in steps_before:                        # the optimizer's host bookkeeping of the step that never ran
+                self.opt.state[p]["step"] = st
+            if ctrs_before is not None:
+                self.opt._ctrs = ctrs_before
+            for p in self.params:
+                p.grad = None
+            try:
+                torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001
+                pass
+            logging.warning("HIP graph capture of the training step failed (%s); continuing eagerly", self.error)
+            return False
+        finally:
+            if self.sync is not None:
+                self.sync.deferred = False
+        self.graph = graph
+        self.grads = [p.grad for p in self.params]            # without a GradSync: the graph's own gradient tensors
+        self.addr = self._addresses()
+        self.fresh = True                                      # the capture did the host bookkeeping of its first replay
+        return True
+
+    def step(self, x, labels, weight=1.0):
+        """-> the step's (weighted) loss as a 0-dim tensor, or None when this batch has to run eagerly."""
+        if self.failed:
+            return None
+        key = (tuple((tuple(t.shape), t.dtype) for t in x), tuple(labels.shape), labels.dtype, float(weight))
         if self.key is None:
             self.key = key
+            self.weight = float(weight)
             self.xs = tuple(torch.empty_like(t) for t in x)
             self.y = torch.empty_like(labels)
         if key != self.key:
@@ -332,33 +475,36 @@ class GraphedStep:
         for dst, src in zip(self.xs, x):
             dst.copy_(src, non_blocking=True)
         self.y.copy_(labels, non_blocking=True)
-        if self.graph is not None and any(p.data_ptr() != a for p, a in zip(self.params, self.addr)):
-            # the parameters moved (train_net's checkpoint does net.cpu() ... net.to(device)): the captured addresses are stale
+        if self.graph is not None and self._addresses() != self.addr:
+            # parameters / buffers moved (train_net's checkpoint does net.cpu() ... net.to(device)) or a scratch buffer grew:
+            # the captured addresses are stale
             self.graph, self.done = None, 0
         if self.graph is None and self.done < self.WARM:
             self.stream.wait_stream(cur)
             with torch.cuda.stream(self.stream):
-                loss = self._eager()
-                nn_ops.join_side_streams()
-                self.opt.step()
-                out = loss.detach()
+                out = self._eager()
             cur.wait_stream(self.stream)
             self.done += 1
             return out
-        if self.graph is None:
-            self.opt.zero_grad(set_to_none=True)
-            self.graph = torch.cuda.CUDAGraph()
-            self.stream.wait_stream(cur)
-            with torch.cuda.graph(self.graph, stream=self.stream):
-                self.loss = self._eager()
-                nn_ops.join_side_streams()
-            self.grads = [p.grad for p in self.params]
-            self.addr = [p.data_ptr() for p in self.params]
+        if self.graph is None and not self._capture(cur):
+            return None
         self.graph.replay()
-        for p, g in zip(self.params, self.grads):            # an eager step in between re-pointed p.grad
-            p.grad = g
-        self.opt.step()
-        return self.loss.detach()
+        self.replays += 1
+        if self.sync is None:
+            for p, g in zip(self.params, self.grads):        # an eager step in between re-pointed p.grad
+                p.grad = g
+        elif self.collectives_in_graph:
+            for p, v in zip(self.sync.params, self.sync.views):
+                p.grad = v
+        else:
+            self.sync.reduce_all()                            # the exchange itself: outside the graph (any backend)
+        if self.in_graph_opt:
+            if not self.fresh:
+                self.opt.advance(self.params)                 # host bookkeeping of the step the graph just took
+            self.fresh = False
+        else:
+            self.opt.step()
+        return self.loss
 
 
 def train_net(net, train_dataset, val_dataset, device, epochs, batch_size, lr, load_from_checkpoint, checkpoint_dir,
@@ -448,11 +594,12 @@ def train_net(net, train_dataset, val_dataset, device, epochs, batch_size, lr, l
             labels = batch[-1].to(device=device)
             x = tuple([batch[i].to(device=device, dtype=torch.float32) for i in range(len(batch) - 1)])
 
+            weight = (labels.shape[0] / global_n if global_n else 1.0 / world) if sync is not None else 1.0
             if graphed is None:
-                graphed = GraphedStep(net, optimizer) if (torch.device(device).type == "cuda" and GraphedStep.wanted(
-                    config, labels.numel(), world, nn_ops.compute_mode()) and GraphedStep.static_module(net, config)) else False
+                graphed = GraphedStep(net, optimizer, sync) if (torch.device(device).type == "cuda" and GraphedStep.wanted(
+                    config, labels.numel(), world, nn_ops.compute_mode()) and GraphedStep.static_module(net, config, sync)) else False
             if graphed:
-                gl = graphed.step(x, labels)
+                gl = graphed.step(x, labels, weight)
                 if gl is not None:
                     epoch_loss += gl
                     global_step += 1
@@ -468,7 +615,6 @@ def train_net(net, train_dataset, val_dataset, device, epochs, batch_size, lr, l
                 loss.backward()
             else:
                 # summed over ranks, (n_local / n_global) * local mean == the global batch mean DataParallel's GPU-0 loss is
-                weight = labels.shape[0] / global_n if global_n else 1.0 / world
                 epoch_loss += loss.detach() * weight
                 sync.zero_grad()
                 (loss * weight).backward()

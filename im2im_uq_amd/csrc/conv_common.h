@@ -1,5 +1,5 @@
-// Shared pieces of the MFMA implicit-GEMM convolution kernels (conv_mfma.hip: the 4-wave kernel; conv_pp.hip: the 8-wave
-// ping-pong kernel): argument block, operand-fragment traits, moment merging, tile choice.
+// Shared pieces of the MFMA implicit-GEMM convolution kernels (conv_mfma.hip, conv_fp8.hip): argument block, operand-fragment
+// traits, moment merging, tile choice.
 #pragma once
 #include "common.h"
 #include "dtypes.h"
@@ -34,8 +34,11 @@ struct ConvArgs {
   // GroupNorm producers have one (scale, shift) pair per IMAGE and channel: in_ss then points at [B][2][Ci] and this is the
   // stride between images (2*Ci); 0 = one pair per channel for the whole batch (BatchNorm).  Needs one image per tile.
   int in_ss_img;
-  // conv_pp.hip (8-wave ping-pong kernel), filled by its launcher: LDS bytes per group, number of pixel tiles
-  int pp_group_bytes, pp_ntiles, pp_flags;
+  // split-K (conv_mfma.hip EPI 4): number of K splits (1 = off), input-channel chunks of 32 per split, fp32 partial sums
+  // [ksplit][B*H*W][Co]
+  int ksplit, kchunks;
+  float* kpartial;
+  int64_t kws_bytes;    // size of the caller's workspace behind kpartial
 };
 
 // Packed bf16 3x3 weights are FRAGMENT-MAJOR: the 32 rows x 16 reduction channels one lane-set of v_mfma_f32_32x32x16_bf16
@@ -98,10 +101,7 @@ inline TileChoice pick_tile(int B, int H, int W, int Co, bool per_image = false)
   return TileChoice{wgs4 < 384 ? 2 : 4, 8, 8, bn};
 }
 
-// conv_pp.hip: the 8-wave ping-pong kernel; returns IM2IM_OK / an error, or 1 when the problem is not one of its shapes
-// (the caller then launches the 4-wave kernel)
-int launch_conv_pp(const ConvArgs& a, hipStream_t stream);
-int conv_pp_mode();
-void set_conv_pp_mode(int mode);
+// conv_mfma.hip: A/B switch of the split-K path (im2im_set_option "conv_splitk", conv_wgrad.hip)
+void set_conv_splitk(int v);
 
 }  // namespace im2im

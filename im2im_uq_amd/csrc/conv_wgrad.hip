@@ -1,0 +1,807 @@
+// Weight gradients of the MFMA convolutions and the weight packing for gfx950 (split from conv_mfma.hip so that the two
+// halves compile in parallel): conv_wgrad_kernel (fp32, 1x1), conv_wgrad_pipe_kernel (bf16 3x3, software-pipelined 12-wave
+// workgroups), the deterministic split-K reduction, and the packers of the forward / data-gradient weight operands.
+// Replaces the weight half of autograd's backward of nn.Conv2d (core/models/trunks/unet_parts.py:16,19,90 under
+// loss.backward(), core/scripts/train.py:159).
+#include "conv_common.h"
+#ifndef IM2IM_WGRAD_XCD
+#define IM2IM_WGRAD_XCD 1
+#endif
+#ifndef IM2IM_WGRAD_ABL      // measurement-only: bit 0 = no global loads after the first tile, bit 1 = no LDS writes, bit 2 = no MFMA phase, bit 3 = loads of the same (cache-hot) tile, bit 4 = the dz half of the staging only for the first tile
+#define IM2IM_WGRAD_ABL 0
+#endif
+#include <string>
+#include <type_traits>
+#include <vector>
+
+namespace {
+
+using namespace im2im;
+
+// ------------------------------------------------------------------------------------------------
+// wgrad:  dW[co][tap][ci] = sum over pixels of dz[p][co] * x[p + tap][ci]
+// Block = 64 co x 64 ci x all taps; K runs over pixel tiles (TH x TW), split across blockIdx.y.
+// bf16: both operands need k (= pixel) contiguous per lane but live channel-contiguous in LDS, so
+// they are fetched with ds_read_b64_tr_b16 (hardware 4x16 transpose, semantics verified by
+// tools/hwprobe): lane q of a 16-lane group supplies row q>>2, 8-byte quad q&3 and receives column
+// l&15.  fp32: v_mfma_f32_32x32x2_f32 takes one scalar per lane, read directly.
+struct WgradArgs {
+  const void* x;     // [B][H][W][Ci] T  (layer input)
+  const void* dz;    // [B][H][W][Co] T
+  float* partial;    // [nsplit][Co][TAPS][Ci] fp32
+  int B, H, W, Ci, Co, tilesY, tilesX, ntiles, tiles_per_split;
+  const float* x_ss; // [2][Ci] or null: x is the producer's pre-BatchNorm z; staging applies max(z*scale+shift, 0)
+  const void* x_hi;  // null, or: input channels [Ci_lo, Ci) live here (see ConvArgs); x_ss_hi = its lazy coefficients
+  const float* x_ss_hi;
+  int Ci_lo;
+};
+
+// source tensor of a 64-channel input block: base pointer (at the block's first channel), pixel stride, lazy coefficients
+template <typename T> struct WgradSrc {
+  const T* x; int stride; const float* sc; const float* sh;
+  __device__ __forceinline__ WgradSrc(const WgradArgs& a, int ci0) {
+    const bool split = a.x_hi != nullptr, hi = split && ci0 >= a.Ci_lo;
+    stride = split ? a.Ci_lo : a.Ci;
+    const int c = hi ? ci0 - a.Ci_lo : ci0;
+    x = reinterpret_cast<const T*>(hi ? a.x_hi : a.x) + c;
+    const float* ss = hi ? a.x_ss_hi : a.x_ss;
+    sc = ss ? ss + c : nullptr;
+    sh = ss ? ss + stride + c : nullptr;
+  }
+};
+
+template <typename T> struct WFrag;
+template <> struct WFrag<bf16_t> {
+  using AB = short8;
+  static constexpr int KPX = 16;                    // pixels per MFMA k-step
+  // rowbase: LDS byte address of pixel-row 0 of this k-step's 16-pixel run for this lane's half;
+  // rows[i] = byte offset of pixel i (0..7) of the half relative to lds; col_b = byte offset of channel
+  static __device__ __forceinline__ AB load(const char* p0, const char* p1) {
+    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(lds_char*)p0);
+    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(lds_char*)p1);
+    AB r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
+  static __device__ __forceinline__ f32x16 mfma(AB a, AB b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
+  }
+};
+
+template <typename T, int TH, int TW, int TAPS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int PAD = (TAPS == 9) ? 1 : 0;
+  constexpr int HH = TH + 2 * PAD, HWD = TW + 2 * PAD, HPX = HH * HWD;
+  constexpr int M = TH * TW;
+  constexpr int CT = 64;                            // channels per tile (both co and ci)
+  constexpr bool IS_BF16 = sizeof(T) == 2;
+  constexpr int EPP = 16 / (int)sizeof(T);
+  constexpr int PPR = CT / EPP;                     // 8 (bf16) or 16 (fp32)
+  constexpr int PB = IS_BF16 ? 192 : 272;           // LDS row pitch (bytes)
+  constexpr int A_BYTES = M * PB;
+  constexpr int A_ROUNDS = (M * PPR + 255) / 256, B_ROUNDS = (HPX * PPR + 255) / 256;
+  constexpr int KPX = IS_BF16 ? 16 : 2;
+  constexpr int KSTEPS = M / KPX;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsA = smem;                                // dz tile  [M][64 co]
+  char* ldsB = smem + A_BYTES;                      // x halo   [HPX][64 ci]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wco = wave >> 1, wci = wave & 1;        // 2 x 2 waves, 32 co x 32 ci each
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ci_tiles = (a.Ci + CT - 1) / CT;
+  const int co0 = (blockIdx.x / ci_tiles) * CT, ci0 = (blockIdx.x % ci_tiles) * CT;   // Co / Ci may be 32 mod 64: masked
+  const WgradSrc<T> xs(a, ci0);
+  const T* __restrict__ xg = xs.x;
+  const T* __restrict__ dzg = reinterpret_cast<const T*>(a.dz);
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // lane-constant pieces of the operand addresses
+  //   bf16 tr-read: group g = lane>>4 -> channel sub-block (g&1)*16; lane q = lane&15 supplies
+  //   pixel row (q>>2) of its 4-row block and the 8-byte quad (q&3).
+  const int q = lane & 15;
+  const int tr_col_b = (((lane >> 4) & 1) * 16 + (q & 3) * 4) * 2;   // byte offset of the quad's first channel
+  const int tr_row = q >> 2;
+
+  const int t_begin = blockIdx.y * a.tiles_per_split;
+  const int t_end = min(t_begin + a.tiles_per_split, a.ntiles);
+  // The next tile is fetched into registers while this one's MFMAs run, and only written to LDS after the barrier that ends
+  // them -- the single-buffered loop spent its time waiting for loads (OutConv's 1x1 weight gradient: 0.51 -> 0.35 ms for
+  // 1.5 GB; the fp32 3x3 weight gradients, one workgroup per CU with its 84 KB of LDS: 124 ms of the 305 ms fp32 step).
+  // fp32 3x3 holds 20 pieces = 80 registers: fine, a lone workgroup per CU may use all 512.  bf16 3x3 is
+  // conv_wgrad_pipe_kernel's job; this kernel is only its fallback there and stages straight into LDS.
+  constexpr bool PREFETCH = (TAPS == 1) || !IS_BF16;
+  uint4 ra[PREFETCH ? A_ROUNDS : 1], rb[PREFETCH ? B_ROUNDS : 1];
+  auto fetch = [&](int t, auto&& put_a, auto&& put_b) {
+    int tt = t;
+    const int tx_id = tt % a.tilesX; tt /= a.tilesX;
+    const int ty_id = tt % a.tilesY;
+    const int b = tt / a.tilesY;
+    const int y0 = ty_id * TH, x0 = tx_id * TW;
+    const T* xb = xg + (size_t)b * a.H * a.W * xs.stride;
+    const T* dzb = dzg + (size_t)b * a.H * a.W * a.Co;
+#pragma unroll
+    for (int i = 0; i < A_ROUNDS; ++i) {
+      const int p = i * 256 + tid;
+      const int px = p / PPR, part = p % PPR;
+      const int yy = y0 + px / TW, xx = x0 + px % TW;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (px < M && yy < a.H && xx < a.W && co0 + part * EPP < a.Co)
+        v = *reinterpret_cast<const uint4*>(dzb + ((size_t)yy * a.W + xx) * a.Co + co0 + part * EPP);
+      put_a(i, px, part, v);
+    }
+#pragma unroll
+    for (int i = 0; i < B_ROUNDS; ++i) {
+      const int p = i * 256 + tid;
+      const int px = p / PPR, part = p % PPR;
+      const int yy = y0 + px / HWD - PAD, xx = x0 + px % HWD - PAD;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      bool real = false;
+      if (px < HPX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && ci0 + part * EPP < a.Ci) {
+        v = *reinterpret_cast<const uint4*>(xb + ((size_t)yy * a.W + xx) * xs.stride + part * EPP);
+        real = true;
+      }
+      put_b(i, px, part, v, real);
+    }
+  };
+  auto lazy = [&](uint4& v, int part) {
+    if (xs.sc) {
+      float f[EPP];
+      Vec16<T>::load(reinterpret_cast<const T*>(&v), f);
+#pragma unroll
+      for (int k = 0; k < EPP; ++k) f[k] = fmaxf(f[k] * xs.sc[part * EPP + k] + xs.sh[part * EPP + k], 0.f);
+      Vec16<T>::store(reinterpret_cast<T*>(&v), f);
+    }
+  };
+  unsigned b_real = 0;
+  if constexpr (PREFETCH) {
+    if (t_begin < t_end)
+      fetch(t_begin, [&](int i, int, int, const uint4& v) { ra[i] = v; },
+            [&](int i, int, int, const uint4& v, bool real) { rb[i] = v; b_real = real ? (b_real | (1u << i)) : (b_real & ~(1u << i)); });
+  }
+  for (int t = t_begin; t < t_end; ++t) {
+    if (t != t_begin) __syncthreads();
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int i = 0; i < A_ROUNDS; ++i) {
+        const int p = i * 256 + tid;
+        if (p / PPR < M) *reinterpret_cast<uint4*>(ldsA + (p / PPR) * PB + (p % PPR) * 16) = ra[i];
+      }
+#pragma unroll
+      for (int i = 0; i < B_ROUNDS; ++i) {
+        const int p = i * 256 + tid;
+        if (p / PPR < HPX) {
+          uint4 v = rb[i];
+          if ((b_real >> i) & 1) lazy(v, p % PPR);
+          *reinterpret_cast<uint4*>(ldsB + (p / PPR) * PB + (p % PPR) * 16) = v;
+        }
+      }
+    } else {
+      fetch(t, [&](int, int px, int part, const uint4& v) { if (px < M) *reinterpret_cast<uint4*>(ldsA + px * PB + part * 16) = v; },
+            [&](int, int px, int part, uint4 v, bool real) {
+              if (real) lazy(v, part);
+              if (px < HPX) *reinterpret_cast<uint4*>(ldsB + px * PB + part * 16) = v;
+            });
+    }
+    __syncthreads();
+    if constexpr (PREFETCH) {
+      if (t + 1 < t_end)
+        fetch(t + 1, [&](int i, int, int, const uint4& v) { ra[i] = v; },
+              [&](int i, int, int, const uint4& v, bool real) { rb[i] = v; b_real = real ? (b_real | (1u << i)) : (b_real & ~(1u << i)); });
+    }
+#pragma unroll 2
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      if constexpr (IS_BF16) {
+        // this lane's two 4-pixel row groups of the k-step: pixels m = ks*16 + half*8 + {0..3, 4..7} (+ tr_row)
+        const int m0 = ks * 16 + half * 8 + tr_row, m1 = m0 + 4;
+        const char* pa0 = ldsA + m0 * PB + wco * 64 + tr_col_b;
+        const char* pa1 = ldsA + m1 * PB + wco * 64 + tr_col_b;
+        const short8 fa = WFrag<bf16_t>::load(pa0, pa1);
+        const int h0 = ((m0 / TW) * HWD + (m0 % TW)) * PB + wci * 64 + tr_col_b;
+        const int h1 = ((m1 / TW) * HWD + (m1 % TW)) * PB + wci * 64 + tr_col_b;
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) {
+          const int toff = (TAPS == 9) ? ((tp / 3) * HWD + (tp % 3)) * PB : 0;
+          const short8 fb = WFrag<bf16_t>::load(ldsB + h0 + toff, ldsB + h1 + toff);
+          acc[tp] = WFrag<bf16_t>::mfma(fa, fb, acc[tp]);
+        }
+      } else {
+        const int m = ks * 2 + half;
+        const float fa = *reinterpret_cast<const float*>(ldsA + m * PB + (wco * 32 + l31) * 4);
+        const int hb = ((m / TW) * HWD + (m % TW)) * PB + (wci * 32 + l31) * 4;
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) {
+          const int toff = (TAPS == 9) ? ((tp / 3) * HWD + (tp % 3)) * PB : 0;
+          const float fb = *reinterpret_cast<const float*>(ldsB + hb + toff);
+          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[tp], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // partial[split][co][tap][ci]
+  float* out = a.partial + (size_t)blockIdx.y * a.Co * TAPS * a.Ci;
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int ci = ci0 + wci * 32 + l31;
+      if (co < a.Co && ci < a.Ci) out[((size_t)co * TAPS + tp) * a.Ci + ci] = acc[tp][r];
+    }
+}
+
+// bf16 3x3 wgrad, software-pipelined: one workgroup of 12 waves per CU = 2x2 (co, ci) quadrants x 3 tap groups
+// (kernel rows).  Each wave keeps only its 3 taps' accumulators (48 registers), so there is room to prefetch the
+// NEXT pixel tile into registers while the MFMAs of the current one run from LDS; the tile is then written to the
+// other LDS buffer and one barrier per tile separates the two.  (The single-buffered kernel above spends 63 % of
+// its wave cycles waiting on memory; SQ_WAIT_ANY, profiles/.)
+// COT = output channels per workgroup: 64 (a wave = 32 co x 32 ci x 3 taps, 48 accumulators) or 128 [r3] (a wave = 64 co x 32 ci x
+// 3 taps, 96 accumulators: every x fragment feeds two MFMAs, 1.7 transposing LDS reads per MFMA instead of 2.7, and an x tile is
+// fetched once per 128 output channels instead of once per 64).
+template <int TH, int TW, int COT>
+__global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
+  using T = bf16_t;
+  constexpr int NT = 768;
+  constexpr int HH = TH + 2, HWD = TW + 2, HPX = HH * HWD;
+  constexpr int M = TH * TW;
+  // [r3] TH = 16 (256-pixel tiles, COT = 64 only): twice the MFMA work between two barriers, so a tile's loads have twice as long
+  // to arrive (the 320x320 layers wait on HBM at every 128-pixel tile: cache-hot loads ran them 34 % faster), and 1.27x instead of
+  // 1.41x halo.  Two such tiles only fit the LDS unpadded (128 B per pixel): instead of the 64-byte pad, the 64-byte half of a
+  // pixel row is XOR-swizzled with bit 1 of the row index, which gives the transposing reads (4 consecutive rows x 64 B per 32
+  // lanes) four distinct 16-bank windows again.
+  constexpr bool SWZ = TH == 16;
+  static_assert(!SWZ || COT == 64, "swizzled 256-pixel tiles: 64 output channels");
+  constexpr int CT = 64, EPP = 8, PPR = 8, PB = SWZ ? 128 : 192;   // x: 64 input channels per workgroup, 128 B of data (+ 64 B pad) per pixel
+  constexpr int CJ = COT / 64;                         // 32-channel co sub-blocks per wave
+  constexpr int PA = SWZ ? COT * 2 : COT * 2 + 64;     // dz pixel pitch: 192 / 320 B (rows land on distinct 16-bank windows), 128 swizzled
+  constexpr int PPRA = COT / 8;                        // 16-byte pieces per dz pixel
+  constexpr int A_BYTES = M * PA, B_BYTES = HPX * PB, BUF_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_ROUNDS = (M * PPRA + NT - 1) / NT, B_ROUNDS = (HPX * PPR + NT - 1) / NT;
+  constexpr int KSTEPS = M / 16;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tg = wave >> 2;                          // tap group = kernel row kh
+  const int wco = (wave >> 1) & 1, wci = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ci_tiles = a.Ci / CT;
+  // Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest).  All channel blocks of one pixel
+  // split read the same dz / x pixels, so they are renumbered to sit on ONE XCD and share them through its L2
+  // instead of each XCD fetching them from HBM.
+  int cb = blockIdx.x, split = blockIdx.y;
+#if IM2IM_WGRAD_XCD
+  if ((gridDim.y & 7) == 0) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, j = lin >> 3;
+    split = (j / (int)gridDim.x) * 8 + xcd;
+    cb = j % (int)gridDim.x;
+  }
+#endif
+  const int co0 = (cb / ci_tiles) * COT, ci0 = (cb % ci_tiles) * CT;
+  const WgradSrc<T> xs(a, ci0);
+  const T* __restrict__ xg = xs.x;
+  const T* __restrict__ dzg = reinterpret_cast<const T*>(a.dz);
+
+  f32x16 acc[CJ][3];
+#pragma unroll
+  for (int j = 0; j < CJ; ++j)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
+
+  const int q = lane & 15;
+  const int tr_col_b = (((lane >> 4) & 1) * 16 + (q & 3) * 4) * 2;
+  const int tr_row = q >> 2;
+
+  // staging pieces of this thread (tile-independent parts)
+  int a_px[A_ROUNDS], a_part[A_ROUNDS], b_px[B_ROUNDS], b_part[B_ROUNDS];
+#pragma unroll
+  for (int i = 0; i < A_ROUNDS; ++i) { const int p = i * NT + tid; a_px[i] = (p < M * PPRA) ? p / PPRA : -1; a_part[i] = p % PPRA; }
+#pragma unroll
+  for (int i = 0; i < B_ROUNDS; ++i) { const int p = i * NT + tid; b_px[i] = (p < HPX * PPR) ? p / PPR : -1; b_part[i] = p % PPR; }
+  struct Stage { uint4 a[A_ROUNDS], b[B_ROUNDS]; unsigned valid; };   // one tile in flight; valid bit i: b[i] holds real pixels (not zero padding)
+  // lazy BatchNorm coefficients of the 64 input channels: in registers (COT = 64) or, where the 96 accumulators leave no room
+  // for 16 more live values, in LDS behind the tile buffers and read back per tile (COT = 128)
+  constexpr bool SS_LDS = COT > 64;
+  float xsc[SS_LDS ? 1 : EPP], xsh[SS_LDS ? 1 : EPP];   // this thread's pieces always cover channels ci0 + (tid % 8)*8 ...
+  float* ldsSS = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);
+  const bool lazy_x = xs.sc != nullptr;
+  if (lazy_x) {
+    if constexpr (SS_LDS) {
+      if (tid < CT) { ldsSS[tid] = xs.sc[tid]; ldsSS[CT + tid] = xs.sh[tid]; }
+      __syncthreads();
+    } else {
+#pragma unroll
+      for (int k = 0; k < EPP; ++k) { xsc[k] = xs.sc[(tid % PPR) * EPP + k]; xsh[k] = xs.sh[(tid % PPR) * EPP + k]; }
+    }
+  }
+
+  bool abl_first = true; (void)abl_first;
+  auto gload = [&](int t, Stage& R) __attribute__((always_inline)) {
+    int tt = t;
+    const int tx_id = tt % a.tilesX; tt /= a.tilesX;
+    const int ty_id = tt % a.tilesY;
+    const int b = tt / a.tilesY;
+    const int y0 = ty_id * TH, x0 = tx_id * TW;
+    const T* xb = xg + (size_t)b * a.H * a.W * xs.stride;
+    const T* dzb = dzg + (size_t)b * a.H * a.W * a.Co + co0;
+#if IM2IM_WGRAD_ABL & 16
+    if (abl_first)
+#endif
+#pragma unroll
+    for (int i = 0; i < A_ROUNDS; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (a_px[i] >= 0) {
+        const int yy = y0 + a_px[i] / TW, xx = x0 + a_px[i] % TW;
+        if (yy < a.H && xx < a.W && co0 + a_part[i] * EPP < a.Co)
+          v = *reinterpret_cast<const uint4*>(dzb + ((size_t)yy * a.W + xx) * a.Co + a_part[i] * EPP);
+      }
+      R.a[i] = v;
+    }
+    R.valid = 0;
+#pragma unroll
+    for (int i = 0; i < B_ROUNDS; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (b_px[i] >= 0) {
+        const int yy = y0 + b_px[i] / HWD - 1, xx = x0 + b_px[i] % HWD - 1;
+        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+          v = *reinterpret_cast<const uint4*>(xb + ((size_t)yy * a.W + xx) * xs.stride + b_part[i] * EPP);
+          R.valid |= 1u << i;
+        }
+      }
+      R.b[i] = v;
+    }
+  };
+  auto swrite = [&](int buf, const Stage& R) __attribute__((always_inline)) {
+    char* la = smem + buf * BUF_BYTES;
+    char* lb = la + A_BYTES;
+#if IM2IM_WGRAD_ABL & 16
+    if (abl_first)
+#endif
+#pragma unroll
+    for (int i = 0; i < A_ROUNDS; ++i)
+      if (a_px[i] >= 0) *reinterpret_cast<uint4*>(la + a_px[i] * PA + (SWZ ? (a_part[i] ^ (((a_px[i] >> 1) & 1) << 2)) : a_part[i]) * 16) = R.a[i];
+#if IM2IM_WGRAD_ABL & 16
+    abl_first = false;
+#endif
+#pragma unroll
+    for (int i = 0; i < B_ROUNDS; ++i) {
+      if (b_px[i] >= 0) {
+        uint4 v = R.b[i];
+        if (lazy_x && ((R.valid >> i) & 1)) {
+          float f[EPP];
+          Vec16<T>::load(reinterpret_cast<const T*>(&v), f);
+          if constexpr (SS_LDS) {
+            const int c0 = (tid % PPR) * EPP;
+#pragma unroll
+            for (int k = 0; k < EPP; ++k) f[k] = fmaxf(f[k] * ldsSS[c0 + k] + ldsSS[CT + c0 + k], 0.f);
+          } else {
+#pragma unroll
+            for (int k = 0; k < EPP; ++k) f[k] = fmaxf(f[k] * xsc[k] + xsh[k], 0.f);
+          }
+          Vec16<T>::store(reinterpret_cast<T*>(&v), f);
+        }
+        *reinterpret_cast<uint4*>(lb + b_px[i] * PB + (SWZ ? (b_part[i] ^ (((b_px[i] >> 1) & 1) << 2)) : b_part[i]) * 16) = v;
+      }
+    }
+  };
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    const char* la = smem + buf * BUF_BYTES;
+    const char* lb = la + A_BYTES + tg * HWD * PB;           // this wave's kernel row
+    // k-step ks covers tile row ks (TW == 16): every address below is lane base + compile-time constant, so the fully
+    // unrolled loop has no address arithmetic (it was ~5 VALU per MFMA when only partially unrolled)
+    static_assert(TW == 16, "k-step == one 16-pixel tile row");
+    // swizzled tiles: a lane's rows are (multiple of 4) + tr_row [+ 4], so bit 1 of the row index is bit 1 of tr_row for the dz
+    // rows, and bit 1 of (c + tr_row) for halo pixel c + tr_row, c = (tg + ks) * 18 + kw (+ 8 * half): four per-lane variants
+    const char* pa = la + (half * 8 + tr_row) * PA + (SWZ ? ((wco ^ ((tr_row >> 1) & 1)) << 6) : wco * (COT / 2) * 2) + tr_col_b;
+    const char* pb = lb + (half * 8 + tr_row) * PB + (SWZ ? 0 : wci * 64 + tr_col_b);
+    int xo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xo[j] = SWZ ? (((wci ^ (((((j + 2 * tg) & 3) + tr_row) >> 1) & 1)) << 6) + tr_col_b) : 0;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      short8 fa[CJ];
+#pragma unroll
+      for (int j = 0; j < CJ; ++j) fa[j] = WFrag<bf16_t>::load(pa + j * 64 + ks * 16 * PA, pa + j * 64 + (ks * 16 + 4) * PA);
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int xj = xo[(2 * ks + kw) & 3];            // compile-time index after unrolling; 0 unswizzled
+        const short8 fb = WFrag<bf16_t>::load(pb + xj + (ks * HWD + kw) * PB, pb + xj + (ks * HWD + kw + 4) * PB);
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) acc[j][kw] = WFrag<bf16_t>::mfma(fa[j], fb, acc[j][kw]);
+      }
+    }
+  };
+
+  const int t_begin = split * a.tiles_per_split;
+  const int t_end = min(t_begin + a.tiles_per_split, a.ntiles);
+  if (t_begin < t_end) {
+    Stage R;
+    gload(t_begin, R);
+    swrite(0, R);
+    __syncthreads();
+    int cur = 0;
+    for (int t = t_begin; t < t_end; ++t) {
+      const bool more = t + 1 < t_end;
+#if IM2IM_WGRAD_ABL & 8
+      if (more) gload(t_begin, R);                     // same instruction stream, data always cache-hot
+#elif !(IM2IM_WGRAD_ABL & 1)
+      if (more) gload(t + 1, R);                       // in flight during the MFMAs below
+#endif
+#if !(IM2IM_WGRAD_ABL & 4)
+      compute(cur);
+#endif
+#if !(IM2IM_WGRAD_ABL & 2)
+      if (more) swrite(cur ^ 1, R);
+#endif
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  float* out = a.partial + (size_t)split * a.Co * 9 * a.Ci;
+#pragma unroll
+  for (int j = 0; j < CJ; ++j)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wco * (COT / 2) + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int ci = ci0 + wci * 32 + l31;
+        if (co < a.Co) out[((size_t)co * 9 + tg * 3 + kw) * a.Ci + ci] = acc[j][kw][r];
+      }
+}
+
+// sum partial[nsplit][Co][TAPS][Ci] over splits and write torch layout dw[Co][Ci][TAPS].  Block = 64 outputs x 4 split
+// lanes (lane s adds splits s, s+4, ... in order, the four partial sums are combined in a fixed order): deterministic,
+// and the many-split / few-output case (the 1x1 OutConv) does not serialise on one thread per output.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int Co, int Ci,
+                                                            int taps, float* __restrict__ dw) {
+  // thread (ol, sl): FOUR consecutive outputs (one 16-byte load per split slab), the slabs sl, sl+4, ... in ascending order;
+  // the four slab groups are then added as (0+1)+(2+3) -- the order of the one-float-per-thread version it replaces, so the
+  // bits are the same; up to four slabs' loads are in flight per thread.
+  __shared__ float4 s_acc[4][64];
+  const size_t total = (size_t)Co * taps * Ci;            // a multiple of 4 (Ci % 32 == 0)
+  const size_t total4 = total / 4;
+  const float4* __restrict__ p4 = reinterpret_cast<const float4*>(partial);
+  const int ol = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  for (size_t base = (size_t)blockIdx.x * 64; base < total4; base += (size_t)gridDim.x * 64) {
+    const size_t i = base + ol;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < total4) {
+      int k = sl;
+      for (; k + 12 < nsplit; k += 16) {
+        const float4 a = p4[(size_t)k * total4 + i], b = p4[(size_t)(k + 4) * total4 + i];
+        const float4 c = p4[(size_t)(k + 8) * total4 + i], d = p4[(size_t)(k + 12) * total4 + i];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+        s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+        s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+      }
+      for (; k < nsplit; k += 4) {
+        const float4 a = p4[(size_t)k * total4 + i];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      }
+    }
+    s_acc[sl][ol] = s;
+    __syncthreads();
+    if (sl == 0 && i < total4) {
+      const float4 a = s_acc[0][ol], b = s_acc[1][ol], c = s_acc[2][ol], d = s_acc[3][ol];
+      const float v[4] = {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w)};
+      const size_t e = i * 4;                               // four consecutive ci of one (co, tap): Ci % 4 == 0
+      const int ci = (int)(e % Ci);
+      const size_t r = e / Ci;
+      const int tp = (int)(r % taps);
+      const size_t co = r / taps;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dw[(co * Ci + ci + j) * taps + tp] = v[j];
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, int Co, int Ci, int taps,
+                                                           T* __restrict__ wf, T* __restrict__ wd) {
+  const size_t total = (size_t)Co * Ci * taps;
+  const bool frag = sizeof(T) == 2 && taps == 9 && Co % 32 == 0 && Ci % 32 == 0;      // wfrag_layout (conv_common.h)
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    // i indexes the logical wf: (co, tp, ci)
+    const int ci = (int)(i % Ci);
+    const size_t r = i / Ci;
+    const int tp = (int)(r % taps);
+    const size_t co = r / taps;
+    const T v = from_float<T>(w[(co * Ci + ci) * taps + tp]);
+    if (frag) {
+      wf[wfrag_index((int)co, tp, ci, Ci)] = v;
+      if (wd) wd[wfrag_index(ci, taps - 1 - tp, (int)co, Co)] = v;
+    } else {
+      wf[i] = v;
+      if (wd) wd[((size_t)ci * taps + (taps - 1 - tp)) * Co + co] = v;
+    }
+  }
+}
+
+// every conv weight of a model in ONE launch (18 per-layer pack launches per training step were 6 % of the launches of a
+// batch-10 step): block = a 1024-element chunk of one tensor, found through the prefix table
+constexpr int PACK_MAX_TENSORS = 32;
+struct PackMultiArgs {
+  const float* w[PACK_MAX_TENSORS]; void* wf[PACK_MAX_TENSORS]; void* wd[PACK_MAX_TENSORS];
+  int Co[PACK_MAX_TENSORS], Ci[PACK_MAX_TENSORS], taps[PACK_MAX_TENSORS];
+  int start[PACK_MAX_TENSORS + 1];          // prefix sums of sizes in 1024-element chunks
+  int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(PackMultiArgs a) {
+  const int chunk = blockIdx.x;
+  int t = 0;
+  while (t + 1 < a.n && chunk >= a.start[t + 1]) ++t;
+  const int Co = a.Co[t], Ci = a.Ci[t], taps = a.taps[t];
+  const bool frag = sizeof(T) == 2 && taps == 9 && Co % 32 == 0 && Ci % 32 == 0;
+  const size_t total = (size_t)Co * Ci * taps;
+  const float* __restrict__ w = a.w[t];
+  T* __restrict__ wf = reinterpret_cast<T*>(a.wf[t]);
+  T* __restrict__ wd = reinterpret_cast<T*>(a.wd[t]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const size_t i = (size_t)(chunk - a.start[t]) * 1024 + k * 256 + threadIdx.x;      // indexes wf: (co, tp, ci)
+    if (i < total) {
+      const int ci = (int)(i % Ci);
+      const size_t r = i / Ci;
+      const int tp = (int)(r % taps);
+      const size_t co = r / taps;
+      const T v = from_float<T>(w[(co * Ci + ci) * taps + tp]);
+      if (frag) {
+        wf[wfrag_index((int)co, tp, ci, Ci)] = v;
+        if (wd) wd[wfrag_index(ci, taps - 1 - tp, (int)co, Co)] = v;
+      } else {
+        wf[i] = v;
+        if (wd) wd[((size_t)ci * taps + (taps - 1 - tp)) * Co + co] = v;
+      }
+    }
+  }
+}
+
+// Fragment-major (bf16 3x3, Co % 32 == 0, Ci % 32 == 0) tensors: one block per 32 co x 32 ci x 9 taps.  The 32 x 288 source
+// floats are contiguous per output channel (w[co][ci][tap]) and are read as whole rows into LDS; every 16-byte piece of the
+// two packed operands (wf: 8 consecutive ci of one co; wd: 8 consecutive co of one ci, taps reversed -- conv_common.h
+// wfrag_index) is then written by one thread, a tap's 2 KiB fragment pair as one contiguous run.  The element-per-thread
+// kernel above read with stride 9 and scattered 2-byte stores: 152 us for the 17 M weights of the UNet, this one ~35.
+__global__ __launch_bounds__(256) void pack_weight_frag_multi_kernel(PackMultiArgs a) {
+  constexpr int PITCH = 289;                                   // floats per co row in LDS (odd: the strided reads spread over the banks)
+  __shared__ float sw[32 * PITCH];
+  const int blk = blockIdx.x;
+  int t = 0;
+  while (t + 1 < a.n && blk >= a.start[t + 1]) ++t;
+  const int Co = a.Co[t], Ci = a.Ci[t];
+  const int local = blk - a.start[t];
+  const int nci = Ci >> 5;
+  const int cob = local / nci, cib = local % nci;
+  const float* __restrict__ w = a.w[t] + ((size_t)cob * 32 * Ci + (size_t)cib * 32) * 9;
+  for (int e = threadIdx.x; e < 32 * 288; e += 256) {
+    const int r = e / 288, c = e % 288;
+    sw[r * PITCH + c] = w[(size_t)r * Ci * 9 + c];
+  }
+  __syncthreads();
+  bf16_t* __restrict__ wf = reinterpret_cast<bf16_t*>(a.wf[t]);
+  bf16_t* __restrict__ wd = reinterpret_cast<bf16_t*>(a.wd[t]);
+  const int nco = Co >> 5;
+  for (int e = threadIdx.x; e < 9 * 128; e += 256) {
+    const int tp = e >> 7, p = e & 127;
+    const int ks = p >> 6, lane = p & 63, n = lane & 31, k0 = ks * 16 + (lane >> 5) * 8;
+    {   // wf: row n = co, k = ci
+      alignas(16) bf16_t v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = from_float<bf16_t>(sw[n * PITCH + (k0 + j) * 9 + tp]);
+      *reinterpret_cast<uint4*>(wf + ((((size_t)cob * 9 + tp) * nci + cib) << 10) + (p << 3)) = *reinterpret_cast<const uint4*>(v);
+    }
+    if (wd) {   // wd: row n = ci, k = co, tap reversed
+      alignas(16) bf16_t v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = from_float<bf16_t>(sw[(k0 + j) * PITCH + n * 9 + tp]);
+      *reinterpret_cast<uint4*>(wd + ((((size_t)cib * 9 + (8 - tp)) * nco + cob) << 10) + (p << 3)) = *reinterpret_cast<const uint4*>(v);
+    }
+  }
+}
+
+}  // namespace
+
+namespace {
+int g_wgrad_co128 = 1;      // A/B switch (im2im_set_option "wgrad_co128")
+int g_wgrad_tile16 = 1;     // A/B switch "wgrad_tile16": 256-pixel tiles for the 64-output-channel form
+template <typename T, int TAPS>
+int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float* x_ss_hi, int Ci_lo, const void* dz, float* partial,
+                 int64_t partial_bytes, float* dw, int B, int H, int W, int Ci, int Co, hipStream_t stream) {
+  constexpr int TH = 8, TW = 16;
+  constexpr int PAD = (TAPS == 9) ? 1 : 0;
+  constexpr bool IS_BF16 = sizeof(T) == 2;
+  constexpr int PB = IS_BF16 ? 192 : 272;
+  constexpr size_t smem = (size_t)(TH * TW + (TH + 2 * PAD) * (TW + 2 * PAD)) * PB;
+  WgradArgs a{x, dz, partial, B, H, W, Ci, Co, (int)cdiv(H, TH), (int)cdiv(W, TW), 0, 0, x_ss, x_hi, x_ss_hi, Ci_lo};
+  a.ntiles = B * a.tilesY * a.tilesX;
+  const int cblocks = (int)cdiv(Co, 64) * (int)cdiv(Ci, 64);
+  const size_t wsz = (size_t)Co * TAPS * Ci * sizeof(float);
+  int64_t max_split = partial_bytes / (int64_t)wsz;
+  if (max_split < 1) return fail_invalid("wgrad: workspace smaller than one weight-sized slab");
+  int64_t nsplit = cdiv((IS_BF16 && TAPS == 9) ? 256 : (TAPS == 1 ? 1536 : 512), cblocks);   // pipelined kernel: one workgroup per CU; 1x1: latency-bound, many small blocks
+  if (nsplit > a.ntiles) nsplit = a.ntiles;
+  if (nsplit > max_split) nsplit = max_split;
+  if (nsplit < 1) nsplit = 1;
+  a.tiles_per_split = (int)cdiv(a.ntiles, nsplit);
+  nsplit = cdiv(a.ntiles, a.tiles_per_split);
+  const bool pipe = IS_BF16 && TAPS == 9 && Ci % 64 == 0;   // the pipelined kernel has no channel masking
+  if (pipe) {
+   if constexpr (IS_BF16 && TAPS == 9) {
+    const bool wide = g_wgrad_co128 && Co % 128 == 0;         // 128 output channels per workgroup (see the kernel)
+    if (wide) {
+      const int cb128 = (Co / 128) * (Ci / 64);
+      nsplit = cdiv(256, cb128);
+      if (nsplit > a.ntiles) nsplit = a.ntiles;
+      if (nsplit > max_split) nsplit = max_split;
+      if (nsplit < 1) nsplit = 1;
+      a.tiles_per_split = (int)cdiv(a.ntiles, nsplit);
+      nsplit = cdiv(a.ntiles, a.tiles_per_split);
+      constexpr size_t smem128 = 2 * ((size_t)TH * TW * (128 * 2 + 64) + (size_t)(TH + 2) * (TW + 2) * 192) + 512;
+      auto kern = conv_wgrad_pipe_kernel<TH, TW, 128>;
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem128);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)cb128, (unsigned)nsplit), dim3(768), smem128, stream, a);
+      if (int rc = check_launch("conv_wgrad_pipe_kernel<128>")) return rc;
+    } else if (g_wgrad_tile16 && H >= 64 && W >= 64) {
+      // 64 output channels at the large-extent levels: 256-pixel tiles in the swizzled LDS layout (see the kernel)
+      WgradArgs a16 = a;
+      a16.tilesY = (int)cdiv(H, 16); a16.tilesX = (int)cdiv(W, 16);
+      a16.ntiles = B * a16.tilesY * a16.tilesX;
+      if (nsplit > a16.ntiles) nsplit = a16.ntiles;
+      a16.tiles_per_split = (int)cdiv(a16.ntiles, nsplit);
+      nsplit = cdiv(a16.ntiles, a16.tiles_per_split);
+      constexpr size_t smem16 = 2 * ((size_t)16 * 16 * 128 + (size_t)18 * 18 * 128);
+      auto kern = conv_wgrad_pipe_kernel<16, 16, 64>;
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)cblocks, (unsigned)nsplit), dim3(768), smem16, stream, a16);
+      if (int rc = check_launch("conv_wgrad_pipe_kernel<16,16,64>")) return rc;
+    } else {
+    constexpr size_t smem2 = 2 * smem;                        // double-buffered tiles, one 12-wave workgroup per CU
+    auto kern = conv_wgrad_pipe_kernel<TH, TW, 64>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)cblocks, (unsigned)nsplit), dim3(768), smem2, stream, a);
+    if (int rc = check_launch("conv_wgrad_pipe_kernel")) return rc;
+    }
+   }
+  } else {
+    auto kern = conv_wgrad_kernel<T, TH, TW, TAPS>;
+    static bool attr_set = false;
+    if (!attr_set && smem > 64 * 1024) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)cblocks, (unsigned)nsplit), dim3(256), smem, stream, a);
+    if (int rc = check_launch("conv_wgrad_kernel")) return rc;
+  }
+  const size_t total = (size_t)Co * TAPS * Ci;
+  int blocks = (int)std::min<size_t>(cdiv(total / 4, 64), 8192);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, (int)nsplit, Co, Ci, TAPS, dw);
+  return check_launch("wgrad_reduce_kernel");
+}
+}  // namespace
+
+extern "C" int64_t im2im_conv_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t taps) {
+  if (Ci <= 0 || Co <= 0 || Ci % 32 || Co % 32) return -1;
+  const int64_t ntiles = (int64_t)B * im2im::cdiv(H, 8) * im2im::cdiv(W, 16);
+  const int64_t cblocks = im2im::cdiv(Co, 64) * im2im::cdiv(Ci, 64);
+  int64_t nsplit = im2im::cdiv(taps == 1 ? 1536 : 512, cblocks);
+  if (nsplit > ntiles) nsplit = ntiles;
+  if (nsplit < 1) nsplit = 1;
+  return nsplit * (int64_t)Co * taps * Ci * (int64_t)sizeof(float);
+}
+
+extern "C" int im2im_conv_wgrad(const void* x, const float* x_scale_shift, const void* dz, float* dw, void* workspace,
+                                int64_t workspace_bytes,
+                                int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t taps, int32_t dtype,
+                                im2im_stream_t stream_) {
+  return im2im_conv_wgrad_split(x, x_scale_shift, nullptr, nullptr, Ci, dz, dw, workspace, workspace_bytes, B, H, W, Ci, Co, taps,
+                                dtype, stream_);
+}
+
+extern "C" int im2im_conv_wgrad_split(const void* x, const float* x_scale_shift, const void* x_hi, const float* x_scale_shift_hi,
+                                      int32_t Ci_lo, const void* dz, float* dw, void* workspace, int64_t workspace_bytes,
+                                      int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t taps, int32_t dtype,
+                                      im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(x && dz && dw && workspace);
+  if (x_hi) {
+    IM2IM_REQUIRE(Ci_lo > 0 && Ci_lo % 64 == 0 && Ci == 2 * Ci_lo);   // a 64-channel block never straddles the two sources
+  } else {
+    IM2IM_REQUIRE(x_scale_shift_hi == nullptr);
+    Ci_lo = Ci;
+  }
+  IM2IM_REQUIRE(B > 0 && H > 0 && W > 0);
+  IM2IM_REQUIRE(Ci > 0 && Ci % 32 == 0);
+  IM2IM_REQUIRE(Co > 0 && Co % 32 == 0);
+  IM2IM_REQUIRE(taps == 9 || taps == 1);
+  IM2IM_REQUIRE(dtype == IM2IM_F32 || dtype == IM2IM_BF16);
+  float* partial = reinterpret_cast<float*>(workspace);
+  if (dtype == IM2IM_BF16)
+    return taps == 9 ? launch_wgrad<bf16_t, 9>(x, x_scale_shift, x_hi, x_scale_shift_hi, Ci_lo, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream)
+                     : launch_wgrad<bf16_t, 1>(x, x_scale_shift, x_hi, x_scale_shift_hi, Ci_lo, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream);
+  return taps == 9 ? launch_wgrad<float, 9>(x, x_scale_shift, x_hi, x_scale_shift_hi, Ci_lo, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream)
+                   : launch_wgrad<float, 1>(x, x_scale_shift, x_hi, x_scale_shift_hi, Ci_lo, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream);
+}
+
+extern "C" int im2im_pack_conv_weight(const float* w, int32_t Co, int32_t Ci, int32_t taps, int32_t dtype, void* wf,
+                                      void* wd, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(w && wf && Co > 0 && Ci > 0 && taps > 0);
+  IM2IM_REQUIRE(dtype == IM2IM_F32 || dtype == IM2IM_BF16);
+  const size_t total = (size_t)Co * Ci * taps;
+  int blocks = (int)std::min<size_t>(im2im::cdiv(total, 256), 4096);
+  if (dtype == IM2IM_BF16)
+    hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, w, Co, Ci, taps, (bf16_t*)wf, (bf16_t*)wd);
+  else
+    hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, stream, w, Co, Ci, taps, (float*)wf, (float*)wd);
+  return im2im::check_launch("pack_weight_kernel");
+}
+
+// run-time switches for within-process A/B measurements (tools/, bench).  Not a reference interface.
+extern "C" int im2im_set_option(const char* key, int32_t value) {
+  IM2IM_REQUIRE(key != nullptr);
+  if (std::string(key) == "conv_splitk") { im2im::set_conv_splitk(value); return IM2IM_OK; }
+  if (std::string(key) == "wgrad_co128") { g_wgrad_co128 = value; return IM2IM_OK; }
+  if (std::string(key) == "wgrad_tile16") { g_wgrad_tile16 = value; return IM2IM_OK; }
+  return im2im::fail_invalid("unknown option");
+}
+
+extern "C" int im2im_pack_conv_weights_multi(int32_t n_tensors, const float* const* w, const int32_t* Co, const int32_t* Ci,
+                                             const int32_t* taps, int32_t dtype, void* const* wf, void* const* wd,
+                                             im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || (w && Co && Ci && taps && wf && wd)));
+  IM2IM_REQUIRE(dtype == IM2IM_F32 || dtype == IM2IM_BF16);
+  // fragment-major tensors (bf16 3x3, multiples of 32 channels) go to the block-per-32x32 kernel, the rest to the chunked one
+  std::vector<int> frag, plain;
+  for (int i = 0; i < n_tensors; ++i) {
+    IM2IM_REQUIRE(w[i] && wf[i] && Co[i] > 0 && Ci[i] > 0 && taps[i] > 0);
+    (dtype == IM2IM_BF16 && wfrag_layout(2, taps[i], Co[i], Ci[i]) ? frag : plain).push_back(i);
+  }
+  for (int pass = 0; pass < 2; ++pass) {
+    const std::vector<int>& idx = pass == 0 ? frag : plain;
+    for (size_t base = 0; base < idx.size(); base += PACK_MAX_TENSORS) {
+      PackMultiArgs a;
+      a.n = (int)std::min<size_t>(PACK_MAX_TENSORS, idx.size() - base);
+      int units = 0;
+      for (int i = 0; i < a.n; ++i) {
+        const int j = idx[base + i];
+        a.w[i] = w[j]; a.wf[i] = wf[j]; a.wd[i] = wd[j];
+        a.Co[i] = Co[j]; a.Ci[i] = Ci[j]; a.taps[i] = taps[j];
+        a.start[i] = units;
+        units += pass == 0 ? (Co[j] / 32) * (Ci[j] / 32) : (int)im2im::cdiv((int64_t)Co[j] * Ci[j] * taps[j], 1024);
+      }
+      a.start[a.n] = units;
+      if (units == 0) continue;
+      if (pass == 0) hipLaunchKernelGGL(pack_weight_frag_multi_kernel, dim3((unsigned)units), dim3(256), 0, stream, a);
+      else if (dtype == IM2IM_BF16) hipLaunchKernelGGL(pack_weight_multi_kernel<bf16_t>, dim3((unsigned)units), dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL(pack_weight_multi_kernel<float>, dim3((unsigned)units), dim3(256), 0, stream, a);
+      if (int rc = im2im::check_launch("pack_weight_multi_kernel")) return rc;
+    }
+  }
+  return IM2IM_OK;
+}

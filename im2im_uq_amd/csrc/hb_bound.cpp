@@ -181,13 +181,17 @@ extern "C" int im2im_hb_mu_plus_batch(const float* muhat, int64_t count, int64_t
 //         if Rhat >= alpha or RhatPlus > alpha: lhat = lam; break      (fp32 Rhat against fp32(alpha); the bound in float64)
 // table(i, j) = table[i * row_stride + j * col_stride], host memory, fp32 (row-major [N][L]: strides (L, 1); the transposed
 // copy the Python caller makes: (1, N)).  Rhat is the correctly rounded fp32 mean of the column (float64 accumulation, one
-// rounding); torch's own fp32 summation order depends on the host's vector width and differs from it by at most one ulp.
+// rounding); torch's own fp32 summation order depends on the host's vector width and may differ from it in the last bits.
+// rhat_in (optional, [L], NaN = not given): a column mean supplied by the caller is used INSTEAD of the computed one --
+// the Python caller passes torch's own `losses.mean()` for every column whose decision a last-bit change could flip, so that
+// lambda-hat is the reference's on the same host (core/calibration/calibrate_model.py scan_loss_table).
 // Outputs: *stop_index = the column the scan stopped at (L when it never stopped, i.e. visited all and fell through -> 0
 // is reported with *stopped = 0), *lhat, *visited = number of lambdas evaluated; rhat[L] / rhat_plus[L] (optional) receive
 // the values of the visited columns (others untouched).
 extern "C" int im2im_rcps_scan(const float* table, int64_t N, int32_t L, int64_t row_stride, int64_t col_stride,
                                const float* lambdas, double alpha, double delta, int32_t maxiters, int32_t* stop_index,
-                               int32_t* stopped, float* lhat, int32_t* visited, float* rhat, double* rhat_plus) {
+                               int32_t* stopped, float* lhat, int32_t* visited, float* rhat, double* rhat_plus,
+                               const float* rhat_in) {
   if (!table || !lambdas || !stop_index || !lhat || N <= 0 || L < 2) return -1;
   const float dlambda = lambdas[1] - lambdas[0];
   float lh = lambdas[L - 1] + dlambda;
@@ -196,9 +200,14 @@ extern "C" int im2im_rcps_scan(const float* table, int64_t N, int32_t L, int64_t
   int32_t stop = 0, did_stop = 0, count = 0;
   for (int32_t j = L - 1; j >= 0; --j) {
     const float* col = table + (int64_t)j * col_stride;
-    double s = 0.0;
-    for (int64_t i = 0; i < N; ++i) s += (double)col[i * row_stride];
-    const float r = (float)(s / (double)N);
+    float r;
+    if (rhat_in && rhat_in[j] == rhat_in[j]) {
+      r = rhat_in[j];
+    } else {
+      double s = 0.0;
+      for (int64_t i = 0; i < N; ++i) s += (double)col[i * row_stride];
+      r = (float)(s / (double)N);
+    }
     const double rp = im2im_hb_mu_plus((double)r, N, delta, maxiters);
     if (rhat) rhat[j] = r;
     if (rhat_plus) rhat_plus[j] = rp;

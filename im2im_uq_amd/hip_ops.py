@@ -131,21 +131,43 @@ def set_option(key: str, value: int) -> None:
     check(lib.im2im_set_option(key.encode(), int(value)), "im2im_set_option")
 
 
-def rcps_scan(cols: torch.Tensor, lambdas: torch.Tensor, alpha: float, delta: float, maxiters: int = 1000):
+def rcps_scan(cols: torch.Tensor, lambdas: torch.Tensor, alpha: float, delta: float, maxiters: int = 1000, torch_means: bool = True):
     """the reference's descending lambda scan (calibrate_model.py:130-144) in the C library: `cols` [L, N] fp32 host tensor
     whose row j holds the N losses at lambdas[j] - dlambda.  Returns (stop_index, stopped, lhat, trace) with trace =
-    [(j, Rhat, RhatPlus)] in visiting order."""
+    [(j, Rhat, RhatPlus)] in visiting order.
+
+    torch_means: the C scan's Rhat is the correctly rounded mean; the reference's is torch's fp32 `losses.mean()`, whose last
+    bits depend on the host's vector width.  Every visited column whose decision a change of a few ulp could flip (Rhat next
+    to alpha, n * Rhat next to an integer -- the floor inside HB_mu_plus --, RhatPlus next to alpha) gets torch's own mean of
+    that row and the scan is repeated with it, until no such column is left: lambda-hat is then what the reference's loop
+    yields on this host, at the cost of a handful of row means instead of one per visited lambda."""
     import ctypes
+    import math
     cols = cols.to(torch.float32).contiguous().cpu()
     lam = lambdas.to(torch.float32).contiguous().cpu()
     L, n = cols.shape
-    stop, stopped, visited = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
-    lhat = ctypes.c_float(0.0)
-    rhat = torch.zeros((L,), dtype=torch.float32)
-    rplus = torch.zeros((L,), dtype=torch.float64)
-    check(lib.im2im_rcps_scan(cols.data_ptr(), int(n), int(L), 1, int(n), lam.data_ptr(), float(alpha), float(delta), int(maxiters),
-                              ctypes.byref(stop), ctypes.byref(stopped), ctypes.byref(lhat), ctypes.byref(visited), rhat.data_ptr(),
-                              rplus.data_ptr()), "im2im_rcps_scan")
+    given = torch.full((L,), float("nan"), dtype=torch.float32)
+    a32 = float(torch.tensor(alpha, dtype=torch.float32))
+    while True:
+        stop, stopped, visited = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        lhat = ctypes.c_float(0.0)
+        rhat = torch.zeros((L,), dtype=torch.float32)
+        rplus = torch.zeros((L,), dtype=torch.float64)
+        check(lib.im2im_rcps_scan(cols.data_ptr(), int(n), int(L), 1, int(n), lam.data_ptr(), float(alpha), float(delta), int(maxiters),
+                                  ctypes.byref(stop), ctypes.byref(stopped), ctypes.byref(lhat), ctypes.byref(visited), rhat.data_ptr(),
+                                  rplus.data_ptr(), given.data_ptr() if torch_means else None), "im2im_rcps_scan")
+        if not torch_means:
+            break
+        r = rhat[stop.value:].double()
+        slack = 32.0 * 2.0 ** -24 * r.clamp_min(2.0 ** -100)                  # far more than any fp32 summation order moves a mean
+        nr = r * n
+        close = ((r - a32).abs() <= slack) | ((rplus[stop.value:] - alpha).abs() <= 1e-4 * max(alpha, 1e-12)) \
+            | (torch.floor(nr - slack * n) != torch.floor(nr + slack * n))
+        todo = [stop.value + int(i) for i in torch.nonzero(close).flatten() if math.isnan(float(given[stop.value + int(i)]))]
+        if not todo:
+            break
+        for j in todo:
+            given[j] = cols[j].mean()                                         # the reference's `losses.mean()` on this host
     trace = [(j, float(rhat[j]), float(rplus[j])) for j in range(L - 1, stop.value - 1, -1)]
     return stop.value, bool(stopped.value), lhat.value, trace
 

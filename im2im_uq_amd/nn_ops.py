@@ -13,6 +13,7 @@ import os
 import weakref
 
 import torch
+from torch.utils.weak import WeakTensorKeyDictionary
 
 from . import _lib
 from ._lib import check, dptr, lib, stream_ptr
@@ -61,17 +62,28 @@ def nchw(y: torch.Tensor) -> torch.Tensor:
 
 class _Scratch:
     """one growing byte buffer per device; every kernel runs on the same stream, so consecutive users
-    of the scratch are ordered."""
+    of the scratch are ordered.
+
+    A captured HIP graph holds the ADDRESSES of the buffers its kernels used.  Once a graph exists (`pinned`), a buffer that
+    has to grow is retired, not freed: the graph may go on writing to it, so its memory must not be handed to anyone else."""
     bufs = {}
+    pinned = False
+    retired = []
 
     @classmethod
     def get(cls, nbytes: int, device, key: str = "a") -> torch.Tensor:
         key = (torch.device(device).index, key)
         buf = cls.bufs.get(key)
         if buf is None or buf.numel() < nbytes:
+            if buf is not None and cls.pinned:
+                cls.retired.append(buf)
             buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
             cls.bufs[key] = buf
         return buf
+
+    @classmethod
+    def addresses(cls):
+        return tuple(sorted((k, b.data_ptr()) for k, b in cls.bufs.items()))
 
 
 class KernelTimer:
@@ -134,9 +146,28 @@ def pack_weight(w: torch.Tensor, dtype, want_wd=True):
 # A conv's forward asks for its packed operands (wf, wd).  The first request after the weights changed (the optimizer bumps
 # their version counters) packs EVERY registered weight that is stale in one multi-tensor launch; the other layers of the
 # step then find theirs ready.  Weights register themselves at their first use.
+# Staleness is detected by (storage address, version counter).  In-place writes through `p.data` (legacy optimizers written as
+# `p.data.add_`, EMA swaps as `p.data.copy_`, `dist.broadcast(p.data)`) do NOT bump the counter: call invalidate_packed()
+# (or touched(p)) after such a write, write through `p.detach()` / under torch.no_grad() instead, or set IM2IM_BATCH_PACK=0 to
+# re-pack on every forward.  The package's own writers (FusedAdam, broadcast_module_state, load_state_dict) all bump it.
 BATCH_WEIGHT_PACKING = os.environ.get("IM2IM_BATCH_PACK", "1") != "0"
 _pack_registry = {}        # id(weight) -> weakref(weight)
 _pack_cache = {}           # (id(weight), dtype) -> (data_ptr, version, wf, wd)
+
+
+def invalidate_packed(*weights) -> None:
+    """forget the packed conv operands (training cache and the eval-mode per-module caches) of `weights` -- of every weight when
+    called without arguments.  For code that changed parameters behind autograd's back (`p.data.copy_`, a raw-pointer write)."""
+    if not weights:
+        _pack_cache.clear()
+        _EVAL_CACHE.clear()
+        _TAIL_CACHE.clear()
+        return
+    ids = {id(w) for w in weights}
+    for k in [k for k in _pack_cache if k[0] in ids]:
+        _pack_cache.pop(k, None)
+    for w in weights:
+        touched(w)                                           # the eval caches key on the version counter
 
 
 def packed_pair(weight: torch.Tensor, dtype):
@@ -221,11 +252,16 @@ def pack_weight_fp8_dgrad(w: torch.Tensor):
 FP8_DGRAD = os.environ.get("IM2IM_FP8_DGRAD", "1") != "0"     # fp8 mode: data-gradients on the fp8 kernel too (e5m2 operand)
 
 
+_fp8_grad_scales = WeakTensorKeyDictionary()        # conv weight -> Fp8GradScale; NOT an attribute of the Parameter: Parameter.__reduce_ex__
+                                                    # pickles extra attributes, and the whole-module checkpoint (train.py, reference :191)
+                                                    # must not embed a CUDA tensor or depend on this class to load
+
+
 class Fp8GradScale:
     """delayed-scaling state of ONE gradient tensor (the dz a conv's data-gradient consumes): three device floats rotated
     step by step -- max |dz| of the previous step (sets this step's scale), this step's accumulator, the next one's (zeroed
     by this step's kernel).  Seeded from the tensor itself the first time."""
-    __slots__ = ("amax", "step")
+    __slots__ = ("amax", "step", "__weakref__")
 
     def __init__(self):
         self.amax, self.step = None, 0
@@ -320,9 +356,17 @@ def conv_fwd(x, wf, bias=None, scale_shift=None, relu=False, want_stats=False, i
     if scale_shift is not None:
         sc, sh = scale_shift[0], scale_shift[1]
     ev = TIMER.wrap(_tile_name("igemm", h, w_, co, taps, x.dtype), 2.0 * b * h * w_ * co * ci * taps, x.device) if TIMER else None
-    check(lib.im2im_conv_fwd_split(dptr(x), dptr(in_ss), dptr(x_hi), dptr(in_ss_hi), ci_lo, dptr(wf), dptr(bias), dptr(center),
-                                   dptr(sc), dptr(sh), dptr(y), dptr(y_hi), int(split_out), dptr(stats), b, h, w_, ci, co,
-                                   taps, int(relu), _DT[x.dtype], stream_ptr(x.device)), "im2im_conv_fwd_split")
+    # under-filled launches (a strong-scaled job's ~10 images per GPU at the 40x40 / 20x20 levels) split their reduction
+    # through an fp32 workspace; 0 bytes = this shape is never split
+    ws, ws_bytes = None, 0
+    if sc is None:
+        ws_bytes = lib.im2im_conv_splitk_workspace_bytes(b, h, w_, ci, co, taps)
+        if ws_bytes > 0:
+            ws = _Scratch.get(ws_bytes, x.device, "splitk")
+    check(lib.im2im_conv_fwd_split_ws(dptr(x), dptr(in_ss), dptr(x_hi), dptr(in_ss_hi), ci_lo, dptr(wf), dptr(bias), dptr(center),
+                                      dptr(sc), dptr(sh), dptr(y), dptr(y_hi), int(split_out), dptr(stats), b, h, w_, ci, co,
+                                      taps, int(relu), _DT[x.dtype], dptr(ws), ws.numel() if ws is not None else 0,
+                                      stream_ptr(x.device)), "im2im_conv_fwd_split_ws")
     if ev is not None:
         ev.record(torch.cuda.current_stream(x.device))
     if split_out:
@@ -723,11 +767,11 @@ class ConvStats(torch.autograd.Function):
                 if FP8_DGRAD and ci % 128 == 0 and (x.requires_grad or xin_hi is not None):
                     # ... and the data-gradient too (e5m2 dz under delayed scaling); the weight gradient stays bf16
                     fp8_d = pack_weight_fp8_dgrad(weight)
-                    gs = getattr(weight, "_im2im_fp8_gs", None)
+                    gs = _fp8_grad_scales.get(weight)
                     if gs is None:
                         gs = Fp8GradScale()
                         if isinstance(weight, torch.nn.Parameter):
-                            weight._im2im_fp8_gs = gs
+                            _fp8_grad_scales[weight] = gs
                     ctx.fp8_gs = gs
                 else:
                     wd = packed_pair(weight, cdt)[1]
@@ -1649,10 +1693,45 @@ class QuantileLossPacked(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------- optimizer
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam(params, lr) semantics (defaults betas=(0.9,0.999), eps=1e-8, no weight decay) in one
-    multi-tensor HIP launch per 24 tensors.  Drop-in for `optim.Adam(net.parameters(), lr=lr)` at train.py:120."""
+    multi-tensor HIP launch per 24 tensors.  Drop-in for `optim.Adam(net.parameters(), lr=lr)` at train.py:120.
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    capturable=True (torch.optim.Adam's flag of the same name): the step count that sets the bias correction lives on the
+    device and is advanced by the update itself (im2im_adam_step_dev), so `step()` may be captured in a HIP graph and replayed
+    (core/scripts/train.py GraphedStep); a replay is followed by `advance(params)`, the host-side bookkeeping of that step.
+    `state[p]["step"]` stays a host int either way (what state_dict() holds)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.capturable = bool(capturable)
+        self._ctrs = {}            # (device index, steps taken so far) -> (int64[1] device counter, float32[2] coefficient scratch)
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.__dict__.setdefault("capturable", False)
+        self.__dict__.setdefault("_ctrs", {})
+
+    def _counter(self, device, taken):
+        key = (torch.device(device).index, int(taken))
+        ctr = self._ctrs.pop(key, None)
+        if ctr is None:
+            ctr = (torch.full((1,), int(taken), dtype=torch.int64, device=device), torch.zeros(2, dtype=F32, device=device))
+        self._ctrs[(key[0], key[1] + 1)] = ctr                # where the next step will look for it
+        return ctr
+
+    def advance(self, params):
+        """host-side bookkeeping of ONE optimizer step that a replayed HIP graph performed on the device: step counts, the
+        counter table, and the parameters' version counters (the packed-weight caches key on them)."""
+        moved = set()
+        for p in params:
+            st = self.state.get(p)
+            if st:
+                moved.add((p.device.index, int(st["step"])))
+                st["step"] += 1
+        for key in moved:
+            ctr = self._ctrs.pop(key, None)
+            if ctr is not None:
+                self._ctrs[(key[0], key[1] + 1)] = ctr
+        touched(*params)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -1679,15 +1758,20 @@ class FusedAdam(torch.optim.Optimizer):
                     g = g.to(F32).contiguous()
                 if not p.is_contiguous():
                     raise _lib.Im2ImError("FusedAdam: non-contiguous parameter")
-                by_step.setdefault(int(st["step"]), []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
+                by_step.setdefault((p.device, int(st["step"])), []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
             b1, b2 = group["betas"]
-            for step, items in by_step.items():
+            for (dev, step), items in by_step.items():
                 n = len(items)
                 arr = ctypes.c_void_p * n
                 sizes = (ctypes.c_int64 * n)(*[it[0].numel() for it in items])
-                check(lib.im2im_adam_step(n, arr(*[it[0].data_ptr() for it in items]), arr(*[it[1].data_ptr() for it in items]),
-                                          arr(*[it[2].data_ptr() for it in items]), arr(*[it[3].data_ptr() for it in items]), sizes,
-                                          float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(step),
-                                          stream_ptr(items[0][0].device)), "im2im_adam_step")
+                ptrs = (arr(*[it[0].data_ptr() for it in items]), arr(*[it[1].data_ptr() for it in items]),
+                        arr(*[it[2].data_ptr() for it in items]), arr(*[it[3].data_ptr() for it in items]))
+                if self.capturable:
+                    ctr, coef = self._counter(dev, step - 1)
+                    check(lib.im2im_adam_step_dev(n, *ptrs, sizes, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                  dptr(ctr), dptr(coef), stream_ptr(dev)), "im2im_adam_step_dev")
+                else:
+                    check(lib.im2im_adam_step(n, *ptrs, sizes, float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(step),
+                                              stream_ptr(dev)), "im2im_adam_step")
                 touched(*(it[0] for it in items))
         return loss

@@ -118,13 +118,15 @@ int im2im_hb_mu_plus_batch(const float* muhat, int64_t count, int64_t n, double 
  *   lambdas   [L] fp32 ascending grid (torch.linspace(minimum_lambda, maximum_lambda, num_lambdas))
  *   outputs   *stop_index: first visited column; *stopped: 0 when the scan ran off the grid; *lhat; *visited: columns
  *             evaluated; rhat [L] fp32 / rhat_plus [L] float64 (either may be NULL): the visited columns' values.
- * Rhat is the correctly rounded fp32 mean of a column (float64 accumulation). */
+ * Rhat is the correctly rounded fp32 mean of a column (float64 accumulation) unless rhat_in (NULL, or [L] with NaN = "not
+ * given") supplies the caller's own mean for that column (torch's `losses.mean()`, :135, whose last bits depend on the host). */
 int im2im_rcps_scan(const float* table, int64_t N, int32_t L, int64_t row_stride, int64_t col_stride,
                     const float* lambdas, double alpha, double delta, int32_t maxiters, int32_t* stop_index,
-                    int32_t* stopped, float* lhat, int32_t* visited, float* rhat, double* rhat_plus);
+                    int32_t* stopped, float* lhat, int32_t* visited, float* rhat, double* rhat_plus, const float* rhat_in);
 
 /* Run-time switch for within-process A/B measurements of kernel variants (tools/, bench.py); no reference counterpart.
- * "conv_pp": bit 0 = 8-wave ping-pong conv kernel for the 128-channel-wide tiles (default on), bit 1 = for the 64-wide. */
+ * "wgrad_co128" / "wgrad_tile16": 0 switches the 128-output-channel / 256-pixel-tile forms of the weight gradient off;
+ * "conv_splitk": 0 = im2im_conv_fwd_split_ws never splits. */
 int im2im_set_option(const char* key, int32_t value);
 
 /* ---------------------------------------------------------------------------------------------
@@ -185,6 +187,22 @@ int im2im_conv_fwd_split(const void* x, const float* in_scale_shift, const void*
                          const float* center, const float* scale, const float* shift, void* y, void* y_hi,
                          int32_t Co_lo, float* stats, int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co,
                          int32_t taps, int32_t relu, int32_t dtype, im2im_stream_t stream);
+
+/* The same convolution with a caller-provided workspace, which lets UNDER-FILLED launches split their reduction (split-K):
+ * a strong-scaled data-parallel job leaves ~10 images per GPU (core/scripts/train.py:112-115 with
+ * experiments/fastmri_test/config.yml:44-45, batch 78 over 8 devices), and at the 40x40 / 20x20 levels the convolution is
+ * then 180-250 workgroups for 256 CUs, each reducing K = 9*Ci = 4,608-9,216 alone.  With a workspace of at least
+ * im2im_conv_splitk_workspace_bytes(...) bytes (0 = this shape is never split) such a launch is cut into 2-8 input-channel
+ * ranges whose fp32 partial sums go to the workspace and are added in a fixed order by a second kernel that also applies
+ * the bias, rounds, stores y (/ y_hi) and takes the BatchNorm statistics (same `stats` rows as the one-kernel path;
+ * deterministic; scale/shift == NULL only).  workspace == NULL: exactly im2im_conv_fwd_split. */
+int64_t im2im_conv_splitk_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t taps);
+int im2im_conv_fwd_split_ws(const void* x, const float* in_scale_shift, const void* x_hi,
+                            const float* in_scale_shift_hi, int32_t Ci_lo, const void* wf, const float* bias,
+                            const float* center, const float* scale, const float* shift, void* y, void* y_hi,
+                            int32_t Co_lo, float* stats, int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                            int32_t taps, int32_t relu, int32_t dtype, void* workspace, int64_t workspace_bytes,
+                            im2im_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * fp8 forward convolution (BASELINE configs[4] "fp8 MFMA conv path"): 3x3 pad-1 conv whose operands are OCP e4m3 on
@@ -500,6 +518,13 @@ int im2im_center_crop_affine(const float* in, float* out, int64_t B, int32_t Hin
 int im2im_adam_step(int32_t n_tensors, float* const* params, const float* const* grads,
                     float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes, float lr,
                     float beta1, float beta2, float eps, int64_t step, im2im_stream_t stream);
+/* The same update with the step count kept ON THE DEVICE (step_dev: int64, the number of steps taken so far; incremented by
+ * the call; coef_dev: 2 floats of scratch owned by the caller for the lifetime of the launches): nothing about the launch
+ * depends on a host-side counter, so it can be captured in a HIP graph and replayed -- torch.optim.Adam(capturable=True). */
+int im2im_adam_step_dev(int32_t n_tensors, float* const* params, const float* const* grads,
+                        float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes, float lr,
+                        float beta1, float beta2, float eps, int64_t* step_dev, float* coef_dev,
+                        im2im_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -68,7 +68,7 @@ def test_rcps_scan_c_abi_on_reference_tables_g7(case):
     rhat = np.zeros(L, np.float32)
     rplus = np.zeros(L, np.float64)
     rc = lib.im2im_rcps_scan(table.ctypes.data, n, L, L, 1, lambdas.ctypes.data, alpha, delta, 1000, ctypes.byref(stop),
-                             ctypes.byref(stopped), ctypes.byref(lhat), ctypes.byref(visited), rhat.ctypes.data, rplus.ctypes.data)
+                             ctypes.byref(stopped), ctypes.byref(lhat), ctypes.byref(visited), rhat.ctypes.data, rplus.ctypes.data, None)
     assert rc == 0
     ref = g["trace"]
     assert visited.value == len(ref) and stop.value == int(ref[-1][0])
@@ -82,5 +82,46 @@ def test_rcps_scan_c_abi_on_reference_tables_g7(case):
     cols = np.ascontiguousarray(table.T)
     stop2, lhat2 = ctypes.c_int32(-1), ctypes.c_float(0.0)
     assert lib.im2im_rcps_scan(cols.ctypes.data, n, L, 1, n, lambdas.ctypes.data, alpha, delta, 1000, ctypes.byref(stop2), None,
-                               ctypes.byref(lhat2), None, None, None) == 0
+                               ctypes.byref(lhat2), None, None, None, None) == 0
     assert stop2.value == stop.value and lhat2.value == lhat.value
+
+
+def test_rcps_scan_takes_torch_means_where_a_last_bit_decides():
+    """the reference decides `Rhat >= alpha` on torch's fp32 `losses.mean()`; the C scan's correctly rounded mean may
+    differ from it in the last bit.  hip_ops.rcps_scan re-decides every column whose outcome a few ulp could flip on torch's own
+    mean of that row (im2im_rcps_scan's rhat_in), so the stop column is the reference loop's.  Column 2's mean is pushed across
+    alpha by one ulp through rhat_in directly; the Python wrapper must agree with a plain torch re-statement of the loop."""
+    import ctypes
+    import torch
+    from im2im_uq_amd import hip_ops
+    from im2im_uq_amd._lib import lib
+    torch.manual_seed(3)
+    n, L = 997, 6
+    lambdas = torch.linspace(0, 5, L)
+    alpha, delta = 0.25, 0.9999                            # delta ~ 1: the HB bound hugs Rhat, so `Rhat >= alpha` is what decides
+    cols = torch.rand(L, n) * 0.2                          # means ~0.1
+    cols[2] = 0.25                                         # mean == alpha to the bit in exact arithmetic
+    cols[2, ::2] += 3e-8; cols[2, 1::2] -= 3e-8            # ... and noise that only a summation order can see
+    # the reference loop, restated with torch's means
+    want = None
+    for j in range(L - 1, -1, -1):
+        r = cols[j].mean()
+        rp = hip_ops.hb_mu_plus(r.item(), n, delta)
+        if r >= alpha or rp > alpha:
+            want = j
+            break
+    stop, stopped, lhat, trace = hip_ops.rcps_scan(cols, lambdas, alpha, delta)
+    assert stopped and stop == want
+    assert trace[-1][1] == float(cols[want].mean())        # the deciding Rhat is torch's, bit for bit
+    # rhat_in is honoured by the C entry itself: a mean above alpha handed in for column 4 (visited before `want`) stops the scan
+    # there and is reported back as that column's Rhat; NaN entries mean "compute it"
+    assert want < 4
+    given = np.full(L, np.nan, np.float32)
+    given[4] = 0.9
+    s_, st, lh = ctypes.c_int32(-1), ctypes.c_int32(-1), ctypes.c_float(0)
+    rh = np.zeros(L, np.float32)
+    c = cols.numpy()
+    assert lib.im2im_rcps_scan(c.ctypes.data, n, L, 1, n, lambdas.numpy().ctypes.data, alpha, delta, 1000, ctypes.byref(s_),
+                               ctypes.byref(st), ctypes.byref(lh), None, rh.ctypes.data, None, given.ctypes.data) == 0
+    assert s_.value == 4 and st.value == 1 and rh[4] == np.float32(0.9) and lh.value == float(lambdas[4])
+    assert abs(float(rh[5]) - float(cols[5].mean())) <= 1.2e-7 * float(cols[5].mean())

@@ -1,0 +1,172 @@
+"""Round-4 kernels against CPU restatements and against the one-kernel paths they replace:
+  * split-K convolution for under-filled launches (im2im_conv_fwd_split_ws, csrc/conv_mfma.hip EPI 4 + conv_splitk_reduce_kernel)
+    vs F.conv2d on the CPU and vs the unsplit kernel (reference op: nn.Conv2d of unet_parts.py:16,19 at the per-GPU batch of a
+    data-parallel job, train.py:112-115);
+  * the block-per-32x32 weight packer vs the element-per-thread one (bit-equal);
+  * the two-stage BatchNorm reductions whose second stage now runs in the last block of the first (tickets): many launches of
+    changing shapes in a row against float64 sums (a ticket that was not put back to zero would break the next launch)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def merged_moments(stats):
+    st = stats.double().cpu()
+    n = st[:, 2].sum(0)
+    mean = (st[:, 2] * st[:, 0]).sum(0) / n
+    m2 = st[:, 1].sum(0) + (st[:, 2] * (st[:, 0] - mean) ** 2).sum(0)
+    return n, mean, m2
+
+
+SPLITK_CASES = [
+    # B, H, W, Ci, Co, split_in, split_out      (all: 8x8 tiles of two images, < 384 workgroups, K = 9*Ci >= 4608)
+    (10, 20, 20, 512, 512, False, 0),       # the 20x20 level at the per-GPU batch of 78/8: 180 workgroups -> 4 splits
+    (10, 40, 40, 512, 256, False, 0),       # 40x40, 250 workgroups -> 3 splits of 6/6/4 chunks
+    (3, 24, 20, 1024, 128, True, 0),        # split INPUT (the Up block's [skip, upsampled]), overhanging tiles, odd batch
+    (4, 16, 24, 512, 256, False, 128),      # split OUTPUT (a data-gradient landing in d(skip), d(up))
+]
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("case", SPLITK_CASES)
+def test_splitk_conv_vs_cpu_and_vs_unsplit(case, dt):
+    from im2im_uq_amd import hip_ops, nn_ops
+    from im2im_uq_amd._lib import lib
+    b, h, w_, ci, co, split_in, split_out = case
+    assert lib.im2im_conv_splitk_workspace_bytes(b, h, w_, ci, co, 9) > 0, "case must be one the library splits"
+    g = torch.Generator().manual_seed(11)
+    cin = ci // 2 if split_in else ci
+    x = torch.randn(b, h, w_, cin, generator=g)
+    xh = torch.randn(b, h, w_, cin, generator=g) if split_in else None
+    wt = torch.randn(co, ci, 3, 3, generator=g) * (1.0 / (3 * ci ** 0.5))
+    bias = torch.randn(co, generator=g)
+    ss = torch.stack([torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3])
+    xd, xhd = x.to(DEV, dt), (xh.to(DEV, dt) if split_in else None)
+    wf, _ = nn_ops.pack_weight(wt.to(DEV), dt)
+    want_stats = not split_out
+    kw = dict(bias=None if split_out else bias.to(DEV), want_stats=want_stats, in_ss=None if split_out else ss.to(DEV),
+              x_hi=xhd, in_ss_hi=None, split_out=split_out)
+    try:
+        hip_ops.set_option("conv_splitk", 0)
+        ref = nn_ops.conv_fwd(xd, wf, **kw)
+        hip_ops.set_option("conv_splitk", 1)
+        got = nn_ops.conv_fwd(xd, wf, **kw)
+        got2 = nn_ops.conv_fwd(xd, wf, **kw)
+    finally:
+        hip_ops.set_option("conv_splitk", 1)
+    # CPU restatement on the operands as the kernel sees them (rounded to the compute dtype, lazy BatchNorm+ReLU on the low half)
+    xq = x.to(dt).float()
+    if not split_out:
+        xq = torch.clamp_min(xq * ss[0] + ss[1], 0).to(dt).float()
+    xin = torch.cat([xq, xh.to(dt).float()], -1) if split_in else xq
+    want = F.conv2d(xin.permute(0, 3, 1, 2), wt.to(dt).float(), None if split_out else bias, padding=1).permute(0, 2, 3, 1)
+    tol = 2e-5 if dt == F32 else 6e-3
+    if split_out:
+        y = torch.cat([got[0], got[1]], -1).float().cpu()
+        yr = torch.cat([ref[0], ref[1]], -1).float().cpu()
+        assert torch.equal(got[0], got2[0]) and torch.equal(got[1], got2[1])           # deterministic
+    else:
+        y, yr = got[0].float().cpu(), ref[0].float().cpu()
+        assert torch.equal(got[0], got2[0]) and torch.equal(got[1], got2[1])
+    assert rel_l2(y, want) < tol, rel_l2(y, want)
+    assert rel_l2(y, yr) < (3e-6 if dt == F32 else 3e-3)        # same sums, another order: fp32 noise / one bf16 rounding apart
+    if want_stats:
+        n, mean, m2 = merged_moments(got[1])
+        yv = got[0].double().cpu().reshape(-1, co)              # statistics describe the STORED values
+        assert torch.equal(n, torch.full_like(n, float(b * h * w_)))
+        assert torch.allclose(mean, yv.mean(0), rtol=0, atol=2e-5 * float(yv.abs().max()))
+        assert torch.allclose(m2, ((yv - yv.mean(0)) ** 2).sum(0), rtol=2e-4)
+        assert got[1].shape == ref[1].shape                     # one row per conv tile, as the one-kernel epilogue
+
+
+def test_splitk_model_step_matches_unsplit_step():
+    """a whole train step of the depth-4 UNet at the per-GPU batch 10 with and without split-K: the 20x20 / 40x40 levels take the
+    split path (forward and data-gradient); losses equal to fp32-rounding, gradients to the bf16 / fp32 noise of a re-ordered sum."""
+    from im2im_uq_amd import hip_ops, nn_ops
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from im2im_uq_amd.core.models.trunks.unet import UNet
+    from oracle import model as om
+    params = dict(uncertainty_type="quantiles", q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1)
+    nn_ops.set_compute_dtype("fp32")
+    try:
+        x, y = om.det_images(10, 1, 160, 160, salt=5)           # 160 -> 10x10 at the bottom: every level below 64 px is "small"
+        out = {}
+        for mode in (0, 1):
+            hip_ops.set_option("conv_splitk", mode)
+            model = add_uncertainty(UNet(1, 1), dict(params))
+            model.load_state_dict(om.det_state(1, 1))
+            model = model.to(DEV).train()
+            loss = model.loss_fn(model(x.to(DEV)), y.to(DEV))
+            loss.backward()
+            torch.cuda.synchronize()
+            out[mode] = (loss.item(), {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None})
+    finally:
+        hip_ops.set_option("conv_splitk", 1)
+        nn_ops.set_compute_dtype("bf16")
+    assert abs(out[0][0] - out[1][0]) < 1e-5 * abs(out[0][0])
+    worst = max(rel_l2(out[1][1][k], out[0][1][k]) for k in out[0][1] if float(out[0][1][k].abs().max()) > 0)
+    assert worst < 2e-3, worst                                 # fp32 re-association through 18 layers of an ill-conditioned net
+
+
+def test_pack_frag_multi_bit_equal_to_single_tensor_pack():
+    from im2im_uq_amd import nn_ops
+    torch.manual_seed(2)
+    shapes = [(64, 64), (128, 64), (64, 128), (512, 1024), (32, 96), (256, 32)]
+    ws = [torch.nn.Parameter(torch.randn(co, ci, 3, 3, device=DEV)) for co, ci in shapes]
+    ws.append(torch.nn.Parameter(torch.randn(32, 64, 1, 1, device=DEV)))          # 1x1: the chunked kernel in the same call
+    for w in ws:
+        nn_ops.packed_pair(w, BF16)                           # registers it; the LAST call packs all of them in one batch
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(1.5)                                       # bumps the version counters: everything is stale
+    got = [nn_ops.packed_pair(w, BF16) for w in ws]
+    for w, (wf, wd) in zip(ws, got):
+        rf, rd = nn_ops.pack_weight(w, BF16)
+        assert torch.equal(wf, rf) and torch.equal(wd, rd), tuple(w.shape)
+
+
+def test_ticketed_bn_reductions_many_launches():
+    from im2im_uq_amd import nn_ops
+    g = torch.Generator().manual_seed(4)
+    for it in range(40):
+        c = [32, 64, 128, 192, 512, 1024][it % 6]
+        rows = int(torch.randint(1, 3000, (1,), generator=g))
+        stats = torch.empty(rows, 3, c)
+        stats[:, 0] = torch.randn(rows, c, generator=g) * 2 + 5
+        stats[:, 1] = torch.rand(rows, c, generator=g) * 30
+        stats[:, 2] = torch.randint(1, 257, (rows, 1), generator=g).float()
+        gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+        rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+        mi, ss = nn_ops.bn_finalize(stats.to(DEV), int(stats[:, 2, 0].sum()), gamma.to(DEV), beta.to(DEV), rm, rv, 0.1, 1e-5,
+                                    num_batches_tracked=nbt)
+        n, mean, m2 = merged_moments(stats)
+        var = m2 / n
+        assert int(nbt) == 1
+        assert torch.allclose(mi[0].double().cpu(), mean, rtol=1e-6, atol=1e-6), it
+        assert torch.allclose(mi[1].double().cpu(), 1 / torch.sqrt(var + 1e-5), rtol=2e-6), it
+        assert torch.allclose(ss[0].double().cpu(), gamma.double() / torch.sqrt(var + 1e-5), rtol=2e-6), it
+        assert torch.allclose(rm.double().cpu(), 0.1 * mean, rtol=2e-6, atol=1e-7), it
+        # backward sums on a small activation of this width
+        m = int(torch.randint(64, 6000, (1,), generator=g))
+        z = torch.randn(m, c, generator=g)
+        da = torch.randn(m, c, generator=g)
+        mu, istd = z.mean(0), 1 / torch.sqrt(z.var(0, unbiased=False) + 1e-5)
+        sc, sh = gamma * istd, beta - mu * gamma * istd
+        dz, dg, db = nn_ops.bn_relu_bwd(da.to(DEV).view(1, 1, m, c), z.to(DEV).view(1, 1, m, c), torch.stack([sc, sh]).to(DEV),
+                                        torch.stack([mu, istd]).to(DEV))
+        gg = (da * ((z * sc + sh) > 0)).double()
+        xhat = ((z - mu) * istd).double()
+        assert torch.allclose(db.double().cpu(), gg.sum(0), rtol=1e-4, atol=1e-3), it
+        assert torch.allclose(dg.double().cpu(), (gg * xhat).sum(0), rtol=1e-4, atol=1e-3), it
+        want = sc.double() * (gg - gg.mean(0) - xhat * (gg * xhat).mean(0))
+        assert rel_l2(dz.double().cpu().view(m, c), want) < 2e-5, it

@@ -1,6 +1,6 @@
-"""within-process A/B of conv kernel variants on the BASELINE layer shapes (batch 78, bf16): the 4-wave kernel
-(conv_pp = 0) against the 8-wave ping-pong kernel (conv_pp = 3), interleaved rounds, median of the per-round times.
-    python tools/bench_conv_ab.py [batch] [rounds] [modes, e.g. 0,3] [option key, default conv_pp; e.g. conv_persistent]"""
+"""within-process A/B of conv kernel variants on the BASELINE layer shapes (batch 78, bf16): values of one im2im_set_option
+key (default "conv_splitk": 0 = off, 1 = auto), interleaved rounds, median of the per-round times.
+    python tools/bench_conv_ab.py [batch] [rounds] [modes, e.g. 0,1] [option key]"""
 import os
 import statistics
 import sys
@@ -13,8 +13,8 @@ from im2im_uq_amd import hip_ops, nn_ops
 dev = "cuda:0"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 78
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 7
-modes = [int(m) for m in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 3]
-KEY = sys.argv[4] if len(sys.argv) > 4 else "conv_pp"
+modes = [int(m) for m in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 1]
+KEY = sys.argv[4] if len(sys.argv) > 4 else "conv_splitk"
 # (h, ci, co, split_in, kind)  kind: fwd = forward + statistics + lazy input; dgrad = plain store
 LAYERS = [(320, 64, 64, False, "fwd"), (320, 128, 64, True, "fwd"), (320, 64, 64, False, "dgrad"), (320, 64, 128, False, "dgrad_split"),
           (160, 64, 128, False, "fwd"), (160, 128, 128, False, "fwd"), (160, 256, 128, True, "fwd"), (160, 128, 128, False, "dgrad"),
@@ -59,5 +59,5 @@ for (h, ci, co, split, kind) in LAYERS:
     print(f"{kind:11s} {h:3d}x{h:<3d} {ci:4d}->{co:<3d} " + "  ".join(f"mode{m}: {med[m]:.3f} ms {fl / med[m] / 1e9:6.0f} TF" for m in modes)
           + (f"   x{med[modes[0]] / med[modes[-1]]:.3f}" if len(modes) > 1 else ""), flush=True)
     del x, xh
-hip_ops.set_option("conv_pp", 0)
+hip_ops.set_option(KEY, modes[0])
 print("total: " + "  ".join(f"mode{m}: {tot[m]:.2f} ms {flops_tot / tot[m] / 1e9:6.0f} TF" for m in modes))
