@@ -308,6 +308,72 @@ class Workload:
         torch.cuda.empty_cache()
 
 
+def distributed_record(job, wl, backend, steps=10):
+    """what lets a reader of the line check that N ranks on N devices really exchanged gradients: every rank's
+    device (index, name, uuid / PCI bus id, gathered over the job's own process group), the RCCL version, ONE standalone
+    all-reduce of the gradient-sized buffer (ms, algorithm and bus bandwidth: bus = 2(N-1)/N * bytes / time, the number to hold
+    against the xGMI links) and how much of the exchange a training step does NOT hide: the same step with and without GradSync."""
+    import torch.distributed as tdist
+    dev, world = job.dev, job.world
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": job.rank, "local_device_index": dev.index, "name": props.name,
+          "uuid": str(getattr(props, "uuid", "")) or None,
+          "pci_bus_id": ("%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))),
+          "pid": os.getpid()}
+    ranks = [me]
+    if world > 1:
+        ranks = [None] * world
+        tdist.all_gather_object(ranks, me)
+    rec = {"backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else None, "world_size": world,
+           "allreduce_bytes_per_step": wl.allreduce_bytes, "gpus_visible": torch.cuda.device_count(),
+           "under_torch_distributed_run": os.environ.get("TORCHELASTIC_RUN_ID") is not None, "ranks": ranks,
+           "distinct_devices": len({(r["uuid"], r["pci_bus_id"], r["local_device_index"]) for r in ranks})}
+    try:
+        rec["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001
+        rec["rccl_version"] = None
+    if world == 1 or wl.sync is None:
+        return rec
+    # one standalone all-reduce of the flat gradient buffer (a copy: the optimizer's gradients stay untouched)
+    buf = torch.zeros_like(wl.sync.flat)
+    for _ in range(3):
+        tdist.all_reduce(buf)
+    job.barrier()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        tdist.all_reduce(buf)
+    torch.cuda.synchronize()
+    dt = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
+    tdist.all_reduce(dt, op=tdist.ReduceOp.MAX)
+    ms = float(dt.item()) * 1e3
+    nbytes = buf.numel() * 4
+    rec["allreduce_ms"] = ms
+    rec["allreduce_algbw_gbs"] = nbytes / ms / 1e6
+    rec["allreduce_busbw_gbs"] = 2.0 * (world - 1) / world * nbytes / ms / 1e6
+    del buf
+    # the same training step with and without the gradient exchange (second: every rank on its own, weights restored afterwards)
+    state = [p.detach().clone() for p in wl.model.parameters()]
+    with_sync = wl.train_leg(steps, 2)["ms_per_step"]
+    sync, wl.sync, graphed, wl.graphed = wl.sync, None, wl.graphed, False
+    hooks, sync.hook_handles = sync.hook_handles, []
+    for h in hooks:
+        h.remove()
+    for p in wl.model.parameters():
+        p.grad = None
+    without = wl.train_leg(steps, 2)["ms_per_step"]
+    for i, p in enumerate(sync.params):                      # GradSync back in place
+        sync.hook_handles.append(p.register_post_accumulate_grad_hook(sync._make_hook(i)))
+    wl.sync, wl.graphed = sync, graphed
+    with torch.no_grad():
+        for p, q in zip(wl.model.parameters(), state):
+            p.copy_(q)
+    rec["step_ms_with_grad_exchange"] = with_sync
+    rec["step_ms_without_grad_exchange"] = without
+    rec["grad_exchange_exposed_ms"] = with_sync - without
+    return rec
+
+
 def _agg(v, peak):
     n, f, t = sum(a for a, _, _ in v), sum(b for _, b, _ in v), sum(c for _, _, c in v)
     return {"bound": "mfma", "achieved": f / t / 1e9, "peak": peak, "unit": "TFLOP/s", "frac": f / t / 1e9 / peak,
@@ -358,13 +424,14 @@ def roofline_leg(wl, config_name, full=True):
     try:
         # counter-based utilisation from the committed PMC passes (busy MFMA cycles / elapsed SIMD cycles at the clock the chip
         # actually ran): a second reading beside `frac`, which divides FLOP/s by the nominal-clock peak
-        name = "r03_pmc_mfma_busy.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_mfma_busy.json")) else "r02_pmc_mfma_busy.json"
+        name = next(n for n in ("r04_pmc_mfma_busy.json", "r02_pmc_mfma_busy.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
         with open(os.path.join(ROOT, "profiles", name)) as f:
             busy = json.load(f)
         if conf["dtype"] == "bf16" and config_name == "fastmri":
             roof["mfma_busy_cycle_frac_pmc"] = {k: round(v["mfma_busy_frac"], 3) for k, v in busy.items()
                                                 if isinstance(v, dict) and k.startswith(("conv_igemm", "conv_ws"))}
-            roof["mfma_busy_cycle_frac_pmc"]["source"] = f"profiles/{name} (replayed)"
+            roof["mfma_busy_cycle_frac_pmc"]["source"] = (f"profiles/{name} (replayed: SQ counter passes over tools/bench_conv.py of "
+                                                          + ("this round's kernels)" if name.startswith("r04") else "ROUND-2 kernels -- stale)"))
     except Exception:  # noqa: BLE001
         pass
     return roof, roof_w, per_kernel, roof_dgrad
@@ -413,14 +480,28 @@ def calib_leg(wl, steps, calib_images=None, scoring=True):
             calibrate_model(model, ds, ccfg)
     dt_cal = job.timed(calib_step, steps, 1)
     calib_ips = M * job.world * steps / dt_cal
+
+    # the eval forward alone (what the leg is bound by): conv FLOPs of the forward pass against the MFMA peak of the dtype
+    def fwd_step():
+        with torch.no_grad():
+            for s in range(0, M, ccfg["batch_size"]):
+                model(xc[s:s + ccfg["batch_size"]])
+    dt_fwd = job.timed(fwd_step, max(1, steps), 1)
+    fwd_tflops = M * max(1, steps) * wl.fwd_flop / dt_fwd / 1e12
+    fwd_peak = {"fp32": PEAK_FP32_TFLOPS, "fp8": PEAK_FP8_TFLOPS}.get(conf["dtype"], PEAK_BF16_TFLOPS)
     lhat = float(model.lhat)
     lam_grid = torch.linspace(conf["lam"][0], conf["lam"][1], conf["num_lambdas"])
     visited = int((lam_grid >= lhat - 1e-9).sum())
-    del xc, yc, ds
-    torch.cuda.empty_cache()
     L = conf["num_lambdas"]
     calib = {"value": calib_ips, "unit": "calib imgs/s (end-to-end calibrate_model: eval forward + all-lambda scoring + HB scan)",
-             "ms_per_step": dt_cal / steps * 1e3, "images_per_gpu": M, "num_lambdas": L, "lhat": lhat, "lambdas_visited_by_scan": visited}
+             "ms_per_step": dt_cal / steps * 1e3, "images_per_gpu": M, "num_lambdas": L, "lhat": lhat, "lambdas_visited_by_scan": visited,
+             "forward_roofline": {"bound": "mfma", "achieved": fwd_tflops, "peak": fwd_peak, "unit": "TFLOP/s", "frac": fwd_tflops / fwd_peak,
+                                  "imgs_per_s_forward_only": M * max(1, steps) / dt_fwd, "share_of_leg": (dt_fwd / max(1, steps)) / (dt_cal / steps),
+                                  "gflop_per_image_forward": wl.fwd_flop / 1e9,
+                                  "note": "eval forward of this rank's calibration shard alone, same batches as calibrate_model; in fp8 mode only the "
+                                          "eligible 3x3 convs run on the fp8 MFMA, the peak is the fp8 one"}}
+    del xc, yc, ds
+    torch.cuda.empty_cache()
     if not scoring:
         return calib
     # scoring kernel alone on outputs shaped like SURVEY 8(d): lhat lands mid-grid
@@ -622,9 +703,7 @@ def main():
                 "frac_of_fp32_peak_whole_step": ips32 * wl.train_flop / 1e12 / PEAK_FP32_TFLOPS,
                 "note": "same step in the parity mode (v_mfma_f32_32x32x2_f32, fp32 storage): the reference's own precision"}
 
-    dist_info = {"backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else None,
-                 "world_size": world, "allreduce_bytes_per_step": wl.allreduce_bytes,
-                 "gpus_visible": torch.cuda.device_count(), "under_torch_distributed_run": os.environ.get("TORCHELASTIC_RUN_ID") is not None}
+    dist_info = distributed_record(job, wl, backend) if "train" in legs else {"world_size": world}
 
     if "calib" not in legs:
         if rank == 0:

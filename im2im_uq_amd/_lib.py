@@ -98,7 +98,6 @@ SIGNATURES = {
     "im2im_upsample2x_concat_bwd": (_i32, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_smallconv_tiles": (_i64, [_i32, _i32, _i32]),
     "im2im_smallconv_s2l_fwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
-    "im2im_conv1x1_heads_fwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_smallconv_l2s_fwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_smallconv_wgrad_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "im2im_smallconv_wgrad": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr, _i64, _ptr]),

@@ -53,20 +53,6 @@ class ModelWithUncertainty(nn.Module):
         self.params = params
 
     def forward(self, x):
-        if not self.training and not torch.is_grad_enabled():
-            from ... import nn_ops
-            if nn_ops.FUSE_EVAL_TAIL:
-                # opt-in (measured slower, nn_ops.FUSE_EVAL_TAIL): OutConv (unet_parts.py:87-94) and the final layer's 3x3 heads in
-                # one kernel when the trunk and the layer are this package's.  Off (the default), inference goes through
-                # baseModel.__call__ like training does, so forward hooks and a subclass's forward() are honoured in both modes.
-                heads = getattr(self.last_layer, "im2im_heads", None)
-                feats = getattr(self.baseModel, "features", None)
-                tail = getattr(getattr(self.baseModel, "out", None), "conv", None)
-                if heads is not None and feats is not None and tail is not None and not self.baseModel.training:
-                    convs, act = heads()
-                    h = feats(x)
-                    out = nn_ops.conv1x1_heads_eval(h, tail, convs, act)
-                    return out if out is not None else self.last_layer(self.baseModel.out(h))
         x = self.baseModel(x)
         return self.last_layer(x)
 

@@ -51,10 +51,6 @@ class QuantileRegressionLayer(nn.Module):
         self.upper = nn.Conv2d(n_channels_middle, n_channels_out, kernel_size=3, padding=1)
         self.compute_dtype = None
 
-    def im2im_heads(self):
-        """(the head convolutions in output-plane order, activation on plane 1) for the fused eval-mode tail kernel"""
-        return [self.lower, self.prediction, self.upper], None
-
     def forward(self, x):
         cdt = getattr(self, "compute_dtype", None) or nn_ops.get_compute_dtype()
         if x.dtype in (torch.float32, torch.bfloat16) and x.permute(0, 2, 3, 1).is_contiguous():

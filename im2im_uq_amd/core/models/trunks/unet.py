@@ -46,8 +46,7 @@ class UNet(nn.Module):
         return self.out(self.features(x))
 
     def features(self, x):
-        """everything but the final 1x1 OutConv: the last Up block's activation (ModelWithUncertainty's eval-mode forward
-        feeds it to the fused OutConv + heads kernel)."""
+        """everything but the final 1x1 OutConv: the last Up block's activation."""
         # lazy=True: between these blocks activations stay "pre-BatchNorm + (scale, shift)"; every consumer below is one
         # of this package's kernels and applies BatchNorm+ReLU on the fly (see DoubleConv.forward).
         # pool=True: a skip block also hands back MaxPool2d(2) of its output for the next Down block (pooled=True), so the

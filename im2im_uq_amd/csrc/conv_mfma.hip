@@ -653,13 +653,13 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs a, int
   }
 }
 
-int g_conv_splitk = 1;      // A/B switch (im2im_set_option "conv_splitk"): 0 = never split
+int g_conv_splitk = 3;      // A/B switch (im2im_set_option "conv_splitk"): 0 = never split, n = aim at n * 256 workgroups
 // K splits for a launch of `wgs` workgroups reducing `nchunks` 32-channel chunks: only launches that leave most of the chip's
 // 512 workgroup slots empty AND carry a long reduction (K = 9*Ci >= 4,608) -- the fp32 partial sums cost 8*ksplit bytes per
 // output element, which a short reduction does not pay back
 inline int splitk_choice(long wgs, int nchunks) {
-  if (!g_conv_splitk || wgs >= 384 || nchunks < 16) return 1;
-  long ks = (768 + wgs / 2) / wgs;
+  if (g_conv_splitk <= 0 || wgs >= 384 || nchunks < 16) return 1;
+  long ks = (256L * g_conv_splitk + wgs / 2) / wgs;
   if (ks > nchunks / 4) ks = nchunks / 4;
   if (ks > 8) ks = 8;
   return ks < 2 ? 1 : (int)ks;

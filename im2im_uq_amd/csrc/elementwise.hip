@@ -22,75 +22,11 @@ __device__ __forceinline__ Moments merge_moments(const Moments& a, const Moments
   return Moments{n, (a.n * a.mean + b.n * b.mean) / n, a.m2 + b.m2 + d * d * (a.n * b.n / n)};
 }
 
-// "Last block finishes" tickets: a two-stage reduction whose second stage is a few hundred flops used to be two launches of
-// ~5 us each (36 of the 232 launches of a batch-10 step).  The blocks of stage 1 publish their rows, fence, and take a ticket per
-// output column; the block that draws the last ticket of its column runs stage 2 for that column in the same launch -- same
-// values, same order, same bits.  Counters are zero at load and put back to zero by the block that finishes; launches rotate
-// through TICKET_SLOTS rows so that two launches in flight on different streams never share counters.
-constexpr int TICKET_SLOTS = 64, TICKET_COLS = 64;
-__device__ unsigned int g_tickets[TICKET_SLOTS][TICKET_COLS];
-inline int next_ticket_slot() { static unsigned n = 0; return (int)(n++ % TICKET_SLOTS); }
-// true for every thread of the block that arrived last at ticket (slot, col) out of `expected` blocks.  All earlier global
-// writes of this block are visible to that block afterwards (release on the way in, acquire on the way out, agent scope:
-// the XCDs' L2s are not coherent with each other without it).
-__device__ __forceinline__ bool last_block_at_ticket(int slot, int col, unsigned expected) {
-  __shared__ int s_last;
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned t = atomicAdd(&g_tickets[slot][col], 1u);
-    s_last = (t == expected - 1u);
-    if (s_last) atomicExch(&g_tickets[slot][col], 0u);
-  }
-  __syncthreads();
-  const bool last = s_last != 0;
-  if (last) __threadfence();
-  return last;
-}
-
-// stage 2 of the statistics for ONE channel, run by one wave: tmp[S][3][C] -> mean_invstd[2][C], scale_shift[2][C]
-// (scale = gamma*invstd, shift = beta - mean*scale), running stats (unbiased variance, as torch).  Lane i holds split-row i
-// (S <= 64); the xor butterfly applies the (symmetric) merge, so every lane ends with the same, order-fixed result.
-__device__ __forceinline__ void bn_finalize_channel(const double* __restrict__ tmp, int S, int C, int c, int lane,
-                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                    float momentum, float eps, int centered, float* __restrict__ mean_invstd,
-                                                    float* __restrict__ scale_shift) {
-  Moments m{0.0, 0.0, 0.0};
-  if (lane < S) { const double* row = tmp + (size_t)lane * 3 * C; m = Moments{row[c], row[C + c], row[2 * C + c]}; }
-  for (int off = 32; off > 0; off >>= 1) {
-    const Moments o{__shfl_xor(m.n, off, 64), __shfl_xor(m.mean, off, 64), __shfl_xor(m.m2, off, 64)};
-    m = merge_moments(m, o);
-  }
-  if (lane != 0) return;
-  const double mean = m.mean;
-  const double var = m.n > 0.0 ? m.m2 / m.n : 0.0;
-  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  mean_invstd[c] = (float)mean;
-  mean_invstd[C + c] = invstd;
-  const float sc = gamma[c] * invstd;
-  scale_shift[c] = sc;
-  scale_shift[C + c] = beta[c] - (float)mean * sc;
-  if (running_mean) {
-    const double unbiased = m.n > 1.0 ? m.m2 / (m.n - 1.0) : var;
-    // centered: the statistics describe z - running_mean(old); the true batch mean adds it back
-    const float true_mean = (float)mean + (centered ? running_mean[c] : 0.f);
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * true_mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-  }
-}
-
 // stage 1: partial[R][3][C] fp32 (mean, M2, n) -> tmp[S][3][C] fp64 (n, mean, M2) per split of rows.  Two passes over the
 // split's rows (the second one hits L2): N and the split mean first, then M2 = sum M2_t + n_t (mean_t - mean)^2 -- plain
 // fp64 sums in a fixed order, no division inside the loops.  Block = 64 channels x 16 row lanes.
-// Stage 2 (bn_finalize_channel) is run for the block's 64 channels by whichever block of the column finishes last.
-__global__ __launch_bounds__(1024) void bn_stats_kernel(const float* __restrict__ partial, int64_t R, int C,
-                                                         int64_t rows_per_split, double* __restrict__ tmp, int slot,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                         float momentum, float eps, int centered,
-                                                         float* __restrict__ mean_invstd, float* __restrict__ scale_shift,
-                                                         long long* __restrict__ num_batches_tracked) {
+__global__ __launch_bounds__(1024) void bn_stats_stage1_kernel(const float* __restrict__ partial, int64_t R, int C,
+                                                                int64_t rows_per_split, double* __restrict__ tmp) {
   __shared__ double sh[2][16][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -127,14 +63,45 @@ __global__ __launch_bounds__(1024) void bn_stats_kernel(const float* __restrict_
     double* o = tmp + (int64_t)blockIdx.y * 3 * C;
     o[c] = N; o[C + c] = mean; o[2 * C + c] = Q;
   }
-  if (!last_block_at_ticket(slot, blockIdx.x, gridDim.y)) return;
+}
+
+// stage 2: tmp[S][3][C] -> mean_invstd[2][C], scale_shift[2][C] (scale = gamma*invstd, shift = beta - mean*scale),
+//   running stats (unbiased variance, as torch).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ tmp, int S, int C, double count,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           float momentum, float eps, int centered,
+                                                           float* __restrict__ mean_invstd, float* __restrict__ scale_shift,
+                                                           long long* __restrict__ num_batches_tracked) {
+  // one wave per channel: lane i holds split-row i (S <= 64); the xor butterfly applies the (symmetric) merge, so every
+  // lane ends with the same, order-fixed result
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   // BatchNorm2d's `num_batches_tracked += 1` (torch does it in the module's forward; 18 one-element add launches per step)
   if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
-  const int S = (int)gridDim.y;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {                             // 16 waves x 4 channels
-    const int cc = blockIdx.x * 64 + rl + 16 * j;
-    if (cc < C) bn_finalize_channel(tmp, S, C, cc, cl, gamma, beta, running_mean, running_var, momentum, eps, centered, mean_invstd, scale_shift);
+  if (c >= C) return;
+  Moments m{0.0, 0.0, 0.0};
+  if (lane < S) { const double* row = tmp + (size_t)lane * 3 * C; m = Moments{row[c], row[C + c], row[2 * C + c]}; }
+  for (int off = 32; off > 0; off >>= 1) {
+    const Moments o{__shfl_xor(m.n, off, 64), __shfl_xor(m.mean, off, 64), __shfl_xor(m.m2, off, 64)};
+    m = merge_moments(m, o);
+  }
+  if (lane != 0) return;
+  (void)count;                                             // == m.n (kept in the ABI for the caller's bookkeeping)
+  const double mean = m.mean;
+  const double var = m.n > 0.0 ? m.m2 / m.n : 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  mean_invstd[c] = (float)mean;
+  mean_invstd[C + c] = invstd;
+  const float sc = gamma[c] * invstd;
+  scale_shift[c] = sc;
+  scale_shift[C + c] = beta[c] - (float)mean * sc;
+  if (running_mean) {
+    const double unbiased = m.n > 1.0 ? m.m2 / (m.n - 1.0) : var;
+    // centered: the statistics describe z - running_mean(old); the true batch mean adds it back
+    const float true_mean = (float)mean + (centered ? running_mean[c] : 0.f);
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * true_mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
   }
 }
 
@@ -257,49 +224,21 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(const T* __rest
   }
 }
 
-// stages 1 + 2 of the BatchNorm-backward sums in one launch: partial[R][2][C] fp32 -> tmp[S][2][C] fp64 per split of rows
-// (reduce.h's stage 1: thread (rl, k) adds rows r0+rl, +4, ... in order, the four row lanes are then added 0+1+2+3), and the
-// block that finishes a column of 32 channels last sums the S rows of tmp (lane = split row, xor butterfly) into
-// dbeta = sum g, dgamma = sum g*xhat, coef[2][C] = {dbeta/M, dgamma/M}.  Block = (2 sums x 32 channels) x 4 row lanes.
-__global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restrict__ partial, int64_t R, int C,
-                                                           int64_t rows_per_split, double* __restrict__ tmp, int slot, double count,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           float* __restrict__ coef) {
-  __shared__ double s_acc[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int which = cl >> 5, ch = blockIdx.x * 32 + (cl & 31);
-  const int64_t K = 2 * (int64_t)C, k = (int64_t)which * C + ch;
-  const int64_t r0 = (int64_t)blockIdx.y * rows_per_split;
-  const int64_t r1 = (r0 + rows_per_split < R) ? r0 + rows_per_split : R;
-  double acc = 0.0;
-  if (ch < C)
-    for (int64_t r = r0 + rl; r < r1; r += 4) acc += (double)partial[r * K + k];
-  s_acc[rl][cl] = acc;
-  __syncthreads();
-  if (rl == 0 && ch < C) tmp[(int64_t)blockIdx.y * K + k] = s_acc[0][cl] + s_acc[1][cl] + s_acc[2][cl] + s_acc[3][cl];
-  if (!last_block_at_ticket(slot, blockIdx.x, gridDim.y)) return;
-  const int S = (int)gridDim.y;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {                             // 4 waves x 8 channels
-    const int c = blockIdx.x * 32 + rl + 4 * j;
-    if (c >= C) continue;
-    double s1 = (cl < S) ? tmp[((size_t)cl * 2 + 0) * C + c] : 0.0;
-    double s2 = (cl < S) ? tmp[((size_t)cl * 2 + 1) * C + c] : 0.0;
-    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
-    if (cl == 0) {
-      dbeta[c] = (float)s1;
-      dgamma[c] = (float)s2;
-      coef[c] = (float)(s1 / count);
-      coef[C + c] = (float)(s2 / count);
-    }
-  }
-}
-inline int launch_bn_bwd_sums(const float* partial, int64_t R, int C, double* tmp, double count, float* dgamma, float* dbeta,
-                              float* coef, hipStream_t stream) {
-  const int S = reduce_splits(R);
-  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((unsigned)cdiv(C, 32), (unsigned)S), dim3(256), 0, stream, partial, R, C, cdiv(R, S),
-                     tmp, next_ticket_slot(), count, dgamma, dbeta, coef);
-  return check_launch("bn_bwd_sums_kernel");
+// stage 2: dgamma = sum g*xhat, dbeta = sum g; coef[3][C] = {scale, dbeta/M, dgamma/M}
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ tmp, int S, int C, double count,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ coef) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= C) return;
+  double s1 = (lane < S) ? tmp[((size_t)lane * 2 + 0) * C + c] : 0.0;
+  double s2 = (lane < S) ? tmp[((size_t)lane * 2 + 1) * C + c] : 0.0;
+  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+  if (lane != 0) return;
+  dbeta[c] = (float)s1;
+  dgamma[c] = (float)s2;
+  coef[c] = (float)(s1 / count);
+  coef[C + c] = (float)(s2 / count);
 }
 
 // backward pass 2: dz = scale * (g - dbeta/M - xhat * dgamma/M); per-thread channel vector as in bn_relu_apply
@@ -1601,12 +1540,14 @@ extern "C" int im2im_bn_finalize(const float* partial, int64_t R, int32_t C, int
   IM2IM_REQUIRE(partial && gamma && beta && mean_invstd && scale_shift && ws && R > 0 && C > 0 && count > 0);
   IM2IM_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
   IM2IM_REQUIRE(!centered || running_mean);
-  IM2IM_REQUIRE(C <= 64 * TICKET_COLS);
   const int S = reduce_splits(R);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)cdiv(C, 64), (unsigned)S), dim3(1024), 0, stream, partial, R, (int)C,
-                     cdiv(R, S), (double*)ws, next_ticket_slot(), gamma, beta, running_mean, running_var, momentum, eps,
-                     (int)centered, mean_invstd, scale_shift, (long long*)num_batches_tracked);
-  return check_launch("bn_stats_kernel");
+  hipLaunchKernelGGL(bn_stats_stage1_kernel, dim3((unsigned)cdiv(C, 64), (unsigned)S), dim3(1024), 0, stream, partial, R, (int)C,
+                     cdiv(R, S), (double*)ws);
+  if (int rc = check_launch("bn_stats_stage1_kernel")) return rc;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, stream, (const double*)ws, S, (int)C,
+                     (double)count, gamma, beta, running_mean, running_var, momentum, eps, (int)centered, mean_invstd, scale_shift,
+                     (long long*)num_batches_tracked);
+  return check_launch("bn_finalize_kernel");
 }
 
 extern "C" int im2im_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
@@ -1652,7 +1593,12 @@ extern "C" int im2im_bn_relu_bwd(const void* da, const void* z, const float* sca
     hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<T>, dim3((unsigned)cdiv(M, rpb)), dim3(256), 0, stream,
                        (const T*)da, (const T*)z, scale_shift, mean_invstd, M, (int)C, rpb, partial);
     if (int rc = check_launch("bn_relu_bwd_reduce_kernel")) return rc;
-    if (int rc = launch_bn_bwd_sums(partial, cdiv(M, rpb), (int)C, tmp, (double)M, dgamma, dbeta, coef, stream)) return rc;
+    int rc;
+    const int S = launch_reduce_stage1(partial, cdiv(M, rpb), 2 * (int64_t)C, tmp, stream, &rc);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, stream, (const double*)tmp, S, (int)C,
+                       (double)M, dgamma, dbeta, coef);
+    if (int rc2 = check_launch("bn_bwd_finalize_kernel")) return rc2;
     const int64_t nvec = M * C / Vec16<T>::N;
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, stream, (const T*)da, (const T*)z,
                        scale_shift, mean_invstd, coef, (T*)dz, nvec, (int)C);
@@ -1697,7 +1643,12 @@ extern "C" int im2im_bn_relu_bwd_phase(const void* da, const void* z, const floa
       return check_launch("bn_relu_bwd_reduce_kernel");
     }
     if (phase == 2) {
-      return launch_bn_bwd_sums(partial, cdiv(M, rpb), (int)C, tmp, (double)M, dgamma, dbeta, coef, stream);
+      int rc;
+      const int S = launch_reduce_stage1(partial, cdiv(M, rpb), 2 * (int64_t)C, tmp, stream, &rc);
+      if (rc) return rc;
+      hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, stream, (const double*)tmp, S, (int)C,
+                         (double)M, dgamma, dbeta, coef);
+      return check_launch("bn_bwd_finalize_kernel");
     }
     const int64_t nvec = (row1 - row0) * C / Vec16<T>::N;
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, stream, (const T*)da + row0 * C,
@@ -1745,7 +1696,12 @@ extern "C" int im2im_bn_relu_pool_bwd(const void* da, const void* dpool, const v
     hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<T, false>), grid, dim3(256), 0, stream, (const T*)da, (const T*)dpool, (const T*)z,
                        scale_shift, mean_invstd, (const float*)nullptr, (T*)nullptr, partial, B, H, W, (int)C, rv);
     if (int rc = check_launch("bn_relu_pool_bwd_kernel<reduce>")) return rc;
-    if (int rc = launch_bn_bwd_sums(partial, nblk, (int)C, tmp, count, dgamma, dbeta, coef, stream)) return rc;
+    int rc;
+    const int S = launch_reduce_stage1(partial, nblk, 2 * (int64_t)C, tmp, stream, &rc);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, stream, (const double*)tmp, S, (int)C,
+                       count, dgamma, dbeta, coef);
+    if (int rc2 = check_launch("bn_bwd_finalize_kernel")) return rc2;
     hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<T, true>), grid, dim3(256), 0, stream, (const T*)da, (const T*)dpool, (const T*)z,
                        scale_shift, mean_invstd, (const float*)coef, (T*)dz, (float*)nullptr, B, H, W, (int)C, rv);
     return check_launch("bn_relu_pool_bwd_kernel<apply>");
@@ -1763,7 +1719,12 @@ extern "C" int im2im_bn_relu_bwd_from_partial(const void* da, const void* z, con
   float* coef = (float*)((char*)tmp + reduce_tmp_bytes(2 * (int64_t)C));
   return for_dtype(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
-    if (int rc = launch_bn_bwd_sums(partial, R, (int)C, tmp, (double)M, dgamma, dbeta, coef, stream)) return rc;
+    int rc;
+    const int S = launch_reduce_stage1(partial, R, 2 * (int64_t)C, tmp, stream, &rc);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, stream, (const double*)tmp, S, (int)C,
+                       (double)M, dgamma, dbeta, coef);
+    if (int rc2 = check_launch("bn_bwd_finalize_kernel")) return rc2;
     const int64_t nvec = M * C / Vec16<T>::N;
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, stream, (const T*)da, (const T*)z,
                        scale_shift, mean_invstd, coef, (T*)dz, nvec, (int)C);

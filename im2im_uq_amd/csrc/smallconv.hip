@@ -404,164 +404,6 @@ __global__ __launch_bounds__(256) void smallconv_l2s_mfma_kernel(L2SArgs a) {
   }
 }
 
-// ---- eval-mode fusion of OutConv (1x1, 64 -> 32, unet_parts.py:87-94) with the heads (3x3, 32 -> CS planes,
-// finallayers/quantile_layer.py:15-20): the 32-channel feature map lives only in LDS.  Per 16x16 output tile the 18x18 halo
-// of the 64-channel input is staged, the 1x1 conv is evaluated on those 324 pixels with the SAME MFMA sequence as
-// conv_igemm_kernel<bf16, taps = 1> (two chunks of 32 channels, two k-steps each, + bias, one rounding to bf16), pixels
-// outside the image become zeros (the 3x3's padding acts on the FEATURE map), and the heads run on the LDS tile exactly
-// as smallconv_l2s_mfma_kernel does -- so the result is bit-identical to the two-kernel path while 64 B/px of feature-map
-// write + ~80 B/px of halo re-read never reach HBM.  bf16 only (fp32 tiles would need > 160 KB of LDS).
-struct C1HArgs {
-  const bf16_t* x;      // [B][H][W][64]
-  const bf16_t* w1;     // [32][64]  (im2im_pack_conv_weight's wf for taps = 1)
-  const float* b1;      // [32] | null
-  const float* w;       // heads [CS][9][32] fp32
-  const float* bias;    // [CS] | null
-  float* out;           // [B][CS][H][W]
-  int B, H, W, CS, tilesY, tilesX;
-};
-
-constexpr int C1H_CI = 64, C1H_CL = 32;
-constexpr int C1H_PX = C1H_CI * 2 + 16;                               // input halo pixel pitch (bytes)
-constexpr int C1H_XROWS = ((HS * HS + 31) / 32) * 32;                 // 352: whole 32-pixel MFMA row tiles
-constexpr int C1H_PF = C1H_CL * 2 + 16;
-constexpr int C1H_HROWB = HS * C1H_PF + 96;
-constexpr int C1H_F_BYTES = HS * C1H_HROWB;
-constexpr int C1H_PW = 9 * C1H_CL * 2 + 16;
-constexpr int C1H_W_BYTES = 2 * 8 * C1H_PW;
-constexpr size_t c1h_smem() {
-  return (size_t)C1H_XROWS * C1H_PX + (size_t)C1H_CL * C1H_PX + C1H_F_BYTES + C1H_W_BYTES + 8 * 256 * sizeof(float);
-}
-
-__global__ __launch_bounds__(256) void conv1x1_heads_kernel(C1HArgs a) {
-  using T = bf16_t;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* ldsX = smem;                                               // [352][64 ch] input halo
-  char* ldsW1 = ldsX + C1H_XROWS * C1H_PX;                         // [32][64] 1x1 weights
-  char* ldsF = ldsW1 + C1H_CL * C1H_PX;                            // feature halo tile, smallconv_l2s_mfma_kernel's layout
-  char* ldsW = ldsF + C1H_F_BYTES;                                 // heads weights, hi + lo
-  float* ldsO = reinterpret_cast<float*>(ldsW + C1H_W_BYTES);      // [8][256]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, l31 = lane & 31;
-  for (int i = tid; i < 8 * 9 * C1H_CL; i += 256) {                // heads weights -> bf16 hi + lo, rows beyond CS zero
-    const int srow = i / (9 * C1H_CL), k = i % (9 * C1H_CL);
-    const float v = srow < a.CS ? a.w[(size_t)srow * 9 * C1H_CL + k] : 0.f;
-    const bf16_t hi = (bf16_t)v;
-    const bf16_t lo = (bf16_t)(v - (float)hi);
-    *reinterpret_cast<bf16_t*>(ldsW + srow * C1H_PW + k * 2) = hi;
-    *reinterpret_cast<bf16_t*>(ldsW + 8 * C1H_PW + srow * C1H_PW + k * 2) = lo;
-  }
-  for (int i = tid; i < C1H_CL * 8; i += 256)                      // 1x1 weights, 16-byte pieces
-    *reinterpret_cast<uint4*>(ldsW1 + (i >> 3) * C1H_PX + (i & 7) * 16) = *reinterpret_cast<const uint4*>(a.w1 + (size_t)(i >> 3) * C1H_CI + (i & 7) * 8);
-  for (int i = tid; i < (C1H_XROWS - HS * HS) * 8; i += 256)       // rows of the last MFMA row tile beyond the halo: zeros, once
-    *reinterpret_cast<uint4*>(ldsX + (HS * HS + (i >> 3)) * C1H_PX + (i & 7) * 16) = make_uint4(0, 0, 0, 0);
-  const float b1v = a.b1 ? a.b1[l31] : 0.f;
-  constexpr int ROUNDS = (HS * HS * 8 + 255) / 256;                // 16-byte pieces of the input halo per thread
-  uint4 r[ROUNDS];
-  const int ntiles = a.B * a.tilesY * a.tilesX;
-  auto gload = [&](int tile) {
-    int t = tile;
-    const int tx_id = t % a.tilesX; t /= a.tilesX;
-    const int ty_id = t % a.tilesY;
-    const int b = t / a.tilesY;
-    const int y0 = ty_id * TS, x0 = tx_id * TS;
-    const T* inb = a.x + (size_t)b * a.H * a.W * C1H_CI;
-#pragma unroll
-    for (int i = 0; i < ROUNDS; ++i) {
-      const int p = i * 256 + tid;
-      const int px = p >> 3, part = p & 7;
-      const int yy = y0 + px / HS - 1, xx = x0 + px % HS - 1;
-      r[i] = make_uint4(0, 0, 0, 0);
-      if (px < HS * HS && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
-        r[i] = *reinterpret_cast<const uint4*>(inb + ((size_t)yy * a.W + xx) * C1H_CI + part * 8);
-    }
-  };
-  int aoff[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) aoff[j] = (4 * wave + 2 * j + l31 / TS) * C1H_HROWB + (l31 % TS) * C1H_PF;
-  const int boff = (l31 & 7) * C1H_PW;
-  if ((int)blockIdx.x < ntiles) gload(blockIdx.x);
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    int t = tile;
-    const int tx_id = t % a.tilesX; t /= a.tilesX;
-    const int ty_id = t % a.tilesY;
-    const int b = t / a.tilesY;
-    const int y0 = ty_id * TS, x0 = tx_id * TS;
-#pragma unroll
-    for (int i = 0; i < ROUNDS; ++i) {
-      const int p = i * 256 + tid;
-      if ((p >> 3) < HS * HS) *reinterpret_cast<uint4*>(ldsX + (p >> 3) * C1H_PX + (p & 7) * 16) = r[i];
-    }
-    __syncthreads();                                    // input halo (and, first time, the weights) visible
-    if (tile + (int)gridDim.x < ntiles) gload(tile + gridDim.x);
-    // ---- OutConv on the halo: 11 row tiles of 32 pixels x 32 feature channels, K = 64 in conv_igemm's order
-    for (int rt = wave; rt < C1H_XROWS / 32; rt += 4) {
-      f32x16 fac;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) fac[q] = 0.f;
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int koff = c * 64 + ks * 32 + half * 16;
-          const short8 fa = *reinterpret_cast<const short8*>(ldsX + (rt * 32 + l31) * C1H_PX + koff);
-          const short8 fb = *reinterpret_cast<const short8*>(ldsW1 + l31 * C1H_PX + koff);
-          fac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fa), as_bf16x8(fb), fac, 0, 0, 0);
-        }
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int p = rt * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;    // halo pixel of this accumulator row
-        if (p < HS * HS) {
-          const int hy = p / HS, hx = p % HS;
-          const int yy = y0 + hy - 1, xx = x0 + hx - 1;
-          const bool in_img = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-          const T v = in_img ? (T)(fac[q] + b1v) : (T)0.f;           // the 3x3's zero padding is on the feature map
-          *reinterpret_cast<T*>(ldsF + hy * C1H_HROWB + hx * C1H_PF + l31 * 2) = v;
-        }
-      }
-    }
-    __syncthreads();                                    // feature tile complete
-    // ---- the heads on the LDS feature tile (smallconv_l2s_mfma_kernel<bf16, 32>'s loop)
-    f32x16 acc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int toff = (tap / 3) * C1H_HROWB + (tap % 3) * C1H_PF;
-#pragma unroll
-      for (int ks = 0; ks < C1H_CL / 16; ++ks) {
-        const int koff = ks * 32 + half * 16;
-        const short8 fb = *reinterpret_cast<const short8*>(ldsW + boff + tap * C1H_CL * 2 + koff);
-        const short8 fl = *reinterpret_cast<const short8*>(ldsW + 8 * C1H_PW + boff + tap * C1H_CL * 2 + koff);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const short8 fa = *reinterpret_cast<const short8*>(ldsF + aoff[j] + toff + koff);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fa), as_bf16x8(fb), acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fa), as_bf16x8(fl), acc[j], 0, 0, 0);
-        }
-      }
-    }
-    if (l31 < a.CS) {
-      const float bv = a.bias ? a.bias[l31] : 0.f;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int m = (q & 3) + 8 * (q >> 2) + 4 * half;
-          ldsO[l31 * 256 + (4 * wave + 2 * j) * TS + m] = acc[j][q] + bv;
-        }
-    }
-    __syncthreads();                                    // results staged; every wave is done with the feature and input tiles
-    for (int i = tid; i < a.CS * 256; i += 256) {
-      const int sidx = i >> 8, px = i & 255;
-      const int yy = y0 + px / TS, xx = x0 + px % TS;
-      if (yy < a.H && xx < a.W) a.out[(((size_t)b * a.CS + sidx) * a.H + yy) * a.W + xx] = ldsO[i];
-    }
-  }
-}
-
 // data-gradient of the heads: g [B][CS][H][W] fp32, w [CS][9][CL] fp32 (forward layout, used flipped) -> dF [B][H][W][CL] T
 template <typename T, int CL>
 __global__ __launch_bounds__(256) void smallconv_s2l_dgrad_mfma_kernel(S2LArgs a) {
@@ -1197,26 +1039,6 @@ extern "C" int im2im_smallconv_l2s_fwd(const void* in, const float* w, const flo
     hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(ntiles, 256 * per_cu)), dim3(256), smem, stream, a);
     return check_launch("smallconv_l2s_mfma_kernel");
   });
-}
-
-extern "C" int im2im_conv1x1_heads_fwd(const void* x, const void* w1, const float* b1, const float* w, const float* bias, float* out,
-                                       int32_t B, int32_t H, int32_t W, int32_t C1, int32_t CL, int32_t CS, int32_t dtype,
-                                       im2im_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  IM2IM_REQUIRE(x && w1 && w && out && B > 0 && H > 0 && W > 0 && CS >= 1 && CS <= CS_MAX);
-  if (dtype != IM2IM_BF16 || C1 != C1H_CI || CL != C1H_CL) {
-    set_error("im2im_conv1x1_heads_fwd: bf16, 64 -> 32 -> CS only (got dtype %d, %d -> %d)", dtype, C1, CL);
-    return IM2IM_ERR_UNSUPPORTED;
-  }
-  C1HArgs a{(const bf16_t*)x, (const bf16_t*)w1, b1, w, bias, out, B, H, W, CS, (int)cdiv(H, TS), (int)cdiv(W, TS)};
-  constexpr size_t smem = c1h_smem();
-  static_assert(smem <= 160 * 1024, "fits one CU's LDS");
-  static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_heads_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
-  const int64_t ntiles = (int64_t)B * a.tilesY * a.tilesX;
-  const int per_cu = (int)std::max<size_t>(1, (160 * 1024) / smem);
-  hipLaunchKernelGGL(conv1x1_heads_kernel, dim3((unsigned)std::min<int64_t>(ntiles, 256 * per_cu)), dim3(256), smem, stream, a);
-  return check_launch("conv1x1_heads_kernel");
 }
 
 extern "C" int64_t im2im_smallconv_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t CS, int32_t CL) {

@@ -161,7 +161,7 @@ def invalidate_packed(*weights) -> None:
     if not weights:
         _pack_cache.clear()
         _EVAL_CACHE.clear()
-        _TAIL_CACHE.clear()
+        _HEADS_CACHE.clear()
         return
     ids = {id(w) for w in weights}
     for k in [k for k in _pack_cache if k[0] in ids]:
@@ -321,6 +321,9 @@ def conv_fwd_fp8(x, wq, wscale, bias=None, scale_shift=None, relu=False, want_st
         ev.record(torch.cuda.current_stream(x.device))
     return (y, stats) if want_stats else y
 
+
+if os.environ.get("IM2IM_CONV_SPLITK") is not None:       # A/B of the split-K target (see im2im_set_option): 0 = off
+    check(lib.im2im_set_option(b"conv_splitk", int(os.environ["IM2IM_CONV_SPLITK"])), "im2im_set_option")
 
 BF16_CENTERING = False    # opt-in: bf16 train mode stores z - running_mean (im2im_conv_fwd `center`); measured gain on the
                           # train-forward rounding error is modest (5.8 % -> 4.8 %), so the default keeps the plain storage
@@ -1030,47 +1033,6 @@ def conv_bn_relu_eval(x, weight, bias, gamma, beta, running_mean, running_var, e
 
 
 _HEAD_ACT = {"relu": 0, "abs": 1}
-# opt-in: measured on MI355X (fastMRI calibration, 3,474 images, profiles/r03_ab_experiments.txt) the fused tail is bit-identical
-# but SLOWER end to end -- 6,510-6,520 vs 6,790-6,800 calib img/s: its 100 KB of LDS allow one workgroup per CU, so the staging,
-# the 1x1 MFMAs, the heads and the output copy of a tile run one after the other, where the two separate kernels each overlap
-# several workgroups per CU; the 1.2 GB of feature-map traffic it saves per 78 images is worth less than that
-FUSE_EVAL_TAIL = os.environ.get("IM2IM_FUSE_EVAL_TAIL", "0") == "1"
-_TAIL_CACHE = weakref.WeakKeyDictionary()      # OutConv's conv module -> (key, packed operands)
-
-
-def conv1x1_heads_eval(x, out_conv, head_convs, act=None):
-    """eval-mode tail in ONE kernel (csrc/smallconv.hip conv1x1_heads_kernel): heads3x3(OutConv1x1(x)) -> [B,K,C,H,W] fp32,
-    bit-identical to Conv1x1 followed by the heads kernel; the 32-channel feature map never reaches HBM.  x: the trunk's
-    64-channel activation, logical [B,64,H,W], channels-last bf16.  Returns None when the shape / dtype is not the fused
-    kernel's (the caller then runs the two modules)."""
-    w1, b1 = out_conv.weight, out_conv.bias
-    k, c_out = len(head_convs), head_convs[0].weight.shape[0]
-    if (not FUSE_EVAL_TAIL or not x.is_cuda or x.dtype != BF16 or w1.shape[0] != 32 or w1.shape[1] != 64 or k * c_out > 8
-            or not x.permute(0, 2, 3, 1).is_contiguous() or getattr(x, LAZY_ATTR, None) is not None):
-        return None
-    tensors = [w1, b1] + [t for cv in head_convs for t in (cv.weight, cv.bias)]
-    key = tuple(v for t in tensors for v in (t.data_ptr(), t._version))
-    hit = _TAIL_CACHE.get(out_conv)
-    if hit is not None and hit[0] == key:
-        wf1, b1f, wh, bh = hit[1]
-    else:
-        wf1 = pack_weight(w1, BF16, want_wd=False)[0]                                # [32][1][64] bf16
-        b1f = b1.detach().to(F32).contiguous()
-        wh = pack_weight(torch.cat([cv.weight.detach() for cv in head_convs], dim=0), F32, want_wd=False)[0]   # [K*C][9][32] fp32
-        bh = torch.cat([cv.bias.detach() for cv in head_convs], dim=0).to(F32).contiguous()
-        _TAIL_CACHE[out_conv] = (key, (wf1, b1f, wh, bh))
-    xin = nhwc(x.detach())
-    b, h, w_, _ = xin.shape
-    out = torch.empty((b, k * c_out, h, w_), dtype=F32, device=x.device)
-    check(lib.im2im_conv1x1_heads_fwd(dptr(xin), dptr(wf1), dptr(b1f), dptr(wh), dptr(bh), dptr(out), b, h, w_, 64, 32, k * c_out,
-                                      _DT[BF16], stream_ptr(x.device)), "im2im_conv1x1_heads_fwd")
-    out = out.view(b, k, c_out, h, w_)
-    if act is not None:
-        p = c_out * h * w_
-        pre = torch.empty((b, p), dtype=F32, device=out.device)
-        check(lib.im2im_head_activation_fwd(dptr(out), dptr(pre), b, p, k * p, p, _HEAD_ACT[act], stream_ptr(out.device)),
-              "im2im_head_activation_fwd")
-    return out
 
 
 # ----------------------------------------------------------------------------------------- GroupNorm (north-star extra)
@@ -1398,7 +1360,7 @@ class Conv1x1(torch.autograd.Function):
     def forward(ctx, x, weight, bias, cdt):
         ss = lazy_ss(x)
         xin = nhwc(x.detach(), cdt)
-        wf, wd = pack_weight(weight, cdt)
+        wf, wd = packed_pair(weight, cdt)                     # with the 3x3 weights' per-step batch (one launch for the model)
         y = conv_fwd(xin, wf, bias.detach(), in_ss=ss)
         ctx.has_ss = ss is not None
         ctx.link = getattr(x, LINK_ATTR, None)
@@ -1422,6 +1384,27 @@ class Conv1x1(torch.autograd.Function):
         return dx, dw, colsum(dy), None
 
 
+_HEADS_CACHE = WeakTensorKeyDictionary()     # first head weight -> (key, packed weights, concatenated biases): inference only
+
+
+def _packed_heads(ws, bs):
+    """([K*C][9][Cmid] fp32 packed head weights, [K*C] fp32 biases) of K 3x3 heads.  Under torch.no_grad() (calibration and
+    validation run hundreds of forwards over the same weights) the pair is kept while none of the tensors changed -- the two
+    concatenations and the packing were three launches per forward."""
+    key = None
+    if not torch.is_grad_enabled():
+        key = tuple(v for t in (*ws, *bs) for v in (t.data_ptr(), t._version))
+        hit = _HEADS_CACHE.get(ws[0])
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2]
+    w_all = torch.cat([w.detach() for w in ws], dim=0)
+    b_all = torch.cat([b.detach() for b in bs], dim=0).to(F32).contiguous()
+    wf, _ = pack_weight(w_all, F32, want_wd=False)
+    if key is not None:
+        _HEADS_CACHE[ws[0]] = (key, wf, b_all)
+    return wf, b_all
+
+
 class QuantileHeads(torch.autograd.Function):
     """Three 3x3 heads (lower, prediction, upper) in one kernel, output written directly as [B,3,C,H,W] fp32
     (finallayers/quantile_layer.py:15-17,19-21)."""
@@ -1430,9 +1413,7 @@ class QuantileHeads(torch.autograd.Function):
     def forward(ctx, feat, w_lo, b_lo, w_mid, b_mid, w_hi, b_hi, cdt):
         x = nhwc(feat.detach(), cdt)
         c_out = w_lo.shape[0]
-        w_all = torch.cat([w_lo.detach(), w_mid.detach(), w_hi.detach()], dim=0)
-        b_all = torch.cat([b_lo.detach(), b_mid.detach(), b_hi.detach()], dim=0).to(F32).contiguous()
-        wf, _ = pack_weight(w_all, F32, want_wd=False)              # [3C][9][Cmid] fp32
+        wf, b_all = _packed_heads((w_lo, w_mid, w_hi), (b_lo, b_mid, b_hi))     # [3C][9][Cmid] fp32
         b, h, w_, _ = x.shape
         out = smallconv_l2s(x, wf, b_all, 3 * c_out)                # [B,3C,H,W]
         ctx.save_for_backward(x, wf)
@@ -1465,9 +1446,7 @@ class Heads(torch.autograd.Function):
         k = len(wb) // 2
         ws, bs = wb[0::2], wb[1::2]
         c_out = ws[0].shape[0]
-        w_all = torch.cat([w.detach() for w in ws], dim=0)
-        b_all = torch.cat([b.detach() for b in bs], dim=0).to(F32).contiguous()
-        wf, _ = pack_weight(w_all, F32, want_wd=False)              # [K*C][9][Cmid] fp32
+        wf, b_all = _packed_heads(ws, bs)                            # [K*C][9][Cmid] fp32
         b, h, w_, _ = x.shape
         out = smallconv_l2s(x, wf, b_all, k * c_out).view(b, k, c_out, h, w_)
         pre = torch.empty(0)

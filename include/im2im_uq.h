@@ -126,7 +126,7 @@ int im2im_rcps_scan(const float* table, int64_t N, int32_t L, int64_t row_stride
 
 /* Run-time switch for within-process A/B measurements of kernel variants (tools/, bench.py); no reference counterpart.
  * "wgrad_co128" / "wgrad_tile16": 0 switches the 128-output-channel / 256-pixel-tile forms of the weight gradient off;
- * "conv_splitk": 0 = im2im_conv_fwd_split_ws never splits. */
+ * "conv_splitk": 0 = im2im_conv_fwd_split_ws never splits, n = it aims at n * 256 workgroups (default 3). */
 int im2im_set_option(const char* key, int32_t value);
 
 /* ---------------------------------------------------------------------------------------------
@@ -420,15 +420,6 @@ int im2im_smallconv_l2s_fwd(const void* in, const float* w, const float* bias, f
                             int32_t H, int32_t W, int32_t CL, int32_t CS, int32_t dtype,
                             im2im_stream_t stream);
 
-/* Eval-mode fusion of OutConv with the heads (SURVEY 8(b) `conv1x1_heads_fwd`; unet_parts.py:87-94 followed by
- * finallayers/quantile_layer.py:15-20): out [B][CS][H][W] fp32 = heads3x3(conv1x1(x) + b1) without the 32-channel feature
- * map ever reaching HBM; bit-identical to im2im_conv_fwd(taps = 1) + im2im_smallconv_l2s_fwd.
- *   x [B][H][W][C1] (dtype), w1 [CL][C1] = im2im_pack_conv_weight's wf of the 1x1 weights, b1 [CL]|NULL,
- *   w [CS][9][CL] fp32, bias [CS]|NULL.  Supported: dtype IM2IM_BF16, C1 = 64, CL = 32 (the reference trunk's tail);
- *   anything else returns IM2IM_ERR_UNSUPPORTED and the caller runs the two kernels. */
-int im2im_conv1x1_heads_fwd(const void* x, const void* w1, const float* b1, const float* w, const float* bias, float* out,
-                            int32_t B, int32_t H, int32_t W, int32_t C1, int32_t CL, int32_t CS, int32_t dtype,
-                            im2im_stream_t stream);
 int64_t im2im_smallconv_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t CS, int32_t CL);
 int im2im_smallconv_wgrad(const float* S, const void* L, float* dw, float* dbias, int32_t B, int32_t H,
                           int32_t W, int32_t CS, int32_t CL, int32_t l_major, int32_t dtype, void* ws,

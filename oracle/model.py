@@ -339,6 +339,40 @@ def det_state(n_in: int = 1, n_out: int = 1, utype: str = "quantiles", depth: in
     return {k: det_fill(k, shp) for k, shp in state_spec(n_in, n_out, utype=utype, depth=depth, base=base, norm=norm)}
 
 
+def default_init_state(n_in: int = 1, n_out: int = 1, seed: int = 0, utype: str = "quantiles", depth: int = 4,
+                       base: int = 64) -> Dict[str, torch.Tensor]:
+    """The initialisation the reference's modules get from torch when router.py builds them (core/models/trunks/unet_parts.py:
+    nn.Conv2d / nn.BatchNorm2d defaults; finallayers/quantile_layer.py:11-13): conv weights kaiming_uniform_(a=sqrt(5)), i.e.
+    U(-1/sqrt(fan_in), 1/sqrt(fan_in)); conv biases U(-1/sqrt(fan_in), 1/sqrt(fan_in)); BatchNorm gamma 1, beta 0, running
+    mean 0, running variance 1, no batches tracked.  Drawn from a seeded generator key by key: the same distribution as a
+    freshly constructed reference model (not its bits -- those depend on torch's construction order)."""
+    g = torch.Generator().manual_seed(seed)
+    st = {}
+    spec = state_spec(n_in, n_out, utype=utype, depth=depth, base=base)
+    fan = {}
+    for k, shp in spec:
+        if len(shp) == 4:
+            fan[k[:-len("weight")]] = shp[1] * shp[2] * shp[3]
+    for k, shp in spec:
+        if k.endswith("num_batches_tracked"):
+            st[k] = torch.zeros((), dtype=torch.int64)
+        elif k.endswith("running_mean"):
+            st[k] = torch.zeros(shp)
+        elif k.endswith("running_var"):
+            st[k] = torch.ones(shp)
+        elif len(shp) == 4:
+            b = 1.0 / math.sqrt(shp[1] * shp[2] * shp[3])
+            st[k] = (torch.rand(shp, generator=g) * 2 - 1) * b
+        elif k[:-len("bias")] in fan and k.endswith("bias"):             # a convolution's bias
+            b = 1.0 / math.sqrt(fan[k[:-len("bias")]])
+            st[k] = (torch.rand(shp, generator=g) * 2 - 1) * b
+        elif k.endswith("weight"):                                         # BatchNorm gamma
+            st[k] = torch.ones(shp)
+        else:                                                              # BatchNorm beta
+            st[k] = torch.zeros(shp)
+    return st
+
+
 def det_images(n: int, c: int, h: int, w: int, salt: int = 0):
     """deterministic (input, target) pair: target in [0,1], input = target + structured noise."""
     idx = torch.arange(n * c * h * w, dtype=torch.float64).reshape(n, c, h, w)

@@ -59,6 +59,13 @@ def test_bench_gpus_2_spawns_its_own_ranks():
     assert d["distributed"]["allreduce_bytes_per_step"] == 17269123 * 4
     assert d["config"]["global_batch"] == 10 and d["scaling"] == "weak"
     assert d["strong"]["global_batch"] == 5 and d["strong"]["per_gpu_batch_rank0"] == 3 and d["strong"]["value"] > 0
+    # [r4] the line says which device every rank ran on, times one standalone all-reduce of the gradient buffer and the part of
+    # the exchange a step does not hide (here: two ranks on ONE device over gloo -- distinct_devices says so)
+    ds = d["distributed"]
+    assert [r["rank"] for r in ds["ranks"]] == [0, 1] and ds["ranks"][0]["pid"] != ds["ranks"][1]["pid"]
+    assert ds["distinct_devices"] == 1 and all(r["local_device_index"] == 0 for r in ds["ranks"])
+    assert ds["allreduce_ms"] > 0 and ds["allreduce_busbw_gbs"] > 0
+    assert ds["step_ms_with_grad_exchange"] > 0 and ds["step_ms_without_grad_exchange"] > 0 and "grad_exchange_exposed_ms" in ds
 
 
 def test_bench_gpus_2_over_rccl_needs_two_gpus():

@@ -150,53 +150,6 @@ def test_calibrate_model_runs_the_c_abi_scan(case, monkeypatch):
     assert np.array_equal(table.numpy(), g["table"]) and np.float32(float(ident.lhat)) == np.float32(g["lhat"])
 
 
-@pytest.mark.parametrize("utype", ["quantiles", "gaussian", "residual_magnitude"])
-@pytest.mark.parametrize("shape", [(3, 48, 80), (2, 70, 50), (1, 16, 16)])
-def test_fused_eval_tail_is_bit_identical_to_outconv_plus_heads(utype, shape):
-    """im2im_conv1x1_heads_fwd (OutConv unet_parts.py:87-94 + the heads quantile_layer.py:15-20 in one kernel, the feature map
-    only in LDS) against the two-kernel path: same bits, for full and overhanging 16x16 tiles, three and two heads (with the
-    ReLU / abs on the second plane)."""
-    from im2im_uq_amd import nn_ops
-    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
-    from im2im_uq_amd.core.models.trunks.unet import UNet
-    params = dict(uncertainty_type=utype, q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1)
-    nn_ops.set_compute_dtype("bf16")
-    torch.manual_seed(1)
-    model = add_uncertainty(UNet(1, 1, depth=2), dict(params)).to(DEV)
-    with torch.no_grad():                                     # give the BatchNorm buffers non-trivial values
-        model.train()
-        model(torch.randn(2, 1, 32, 32, device=DEV))
-    model.eval()
-    b, h, w = shape
-    x = torch.randn(b, 1, h, w, device=DEV)
-    calls = []
-    real = nn_ops.conv1x1_heads_eval
-    nn_ops.conv1x1_heads_eval = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
-    was = nn_ops.FUSE_EVAL_TAIL
-    try:
-        with torch.no_grad():
-            nn_ops.FUSE_EVAL_TAIL = True                      # (opt-in: the fused kernel is correct but not faster, nn_ops.py)
-            fused = model(x)
-            nn_ops.FUSE_EVAL_TAIL = False
-            plain = model(x)
-    finally:
-        nn_ops.FUSE_EVAL_TAIL = was
-        nn_ops.conv1x1_heads_eval = real
-    assert len(calls) == 1 and fused.shape == plain.shape == (b, 3 if utype == "quantiles" else 2, 1, h, w)    # [r4] diverted only when opted in
-    assert torch.equal(fused, plain)
-    # train mode and autograd-enabled eval never take the fused path
-    model.train()
-    calls.clear()
-    nn_ops.conv1x1_heads_eval = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
-    nn_ops.FUSE_EVAL_TAIL = True
-    try:
-        model(x)
-    finally:
-        nn_ops.conv1x1_heads_eval = real
-        nn_ops.FUSE_EVAL_TAIL = was
-    assert not calls
-
-
 def test_graphed_train_step_is_bit_identical_to_the_eager_loop():
     """core/scripts/train.py GraphedStep (HIP graph of forward + loss + backward for launch-bound batch shapes, BASELINE
     configs[0]: 32x32, depth 2): the same batches through the eager loop (train.py:141-165 of the reference) and through the

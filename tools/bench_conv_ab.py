@@ -1,5 +1,5 @@
 """within-process A/B of conv kernel variants on the BASELINE layer shapes (batch 78, bf16): values of one im2im_set_option
-key (default "conv_splitk": 0 = off, 1 = auto), interleaved rounds, median of the per-round times.
+key (default "conv_splitk": 0 = off, n = aim at n * 256 workgroups), interleaved rounds, median of the per-round times.
     python tools/bench_conv_ab.py [batch] [rounds] [modes, e.g. 0,1] [option key]"""
 import os
 import statistics
@@ -13,7 +13,7 @@ from im2im_uq_amd import hip_ops, nn_ops
 dev = "cuda:0"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 78
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 7
-modes = [int(m) for m in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 1]
+modes = [int(m) for m in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 3]
 KEY = sys.argv[4] if len(sys.argv) > 4 else "conv_splitk"
 # (h, ci, co, split_in, kind)  kind: fwd = forward + statistics + lazy input; dgrad = plain store
 LAYERS = [(320, 64, 64, False, "fwd"), (320, 128, 64, True, "fwd"), (320, 64, 64, False, "dgrad"), (320, 64, 128, False, "dgrad_split"),
