@@ -513,15 +513,15 @@ def _on_side_stream(device, tensors, fn, after=None):
     12 GB working set, and a process starting while the driver was still releasing that memory ran 2x slower
     (profiles/r02_allocator_stall.txt)."""
     main = torch.cuda.current_stream(device)
+    idx = torch.device(device).index
+    _side_keep.setdefault(idx, []).extend(t for t in tensors if t is not None)
+    _queue_join(idx)
     side = side_stream(device)
     side.wait_stream(main)
     if after is not None:                                # an operand produced on a third stream (pipelined BatchNorm backward)
         side.wait_event(after)
     with torch.cuda.stream(side):
         fn()
-    idx = torch.device(device).index
-    _side_keep.setdefault(idx, []).extend(t for t in tensors if t is not None)
-    _queue_join(idx)
 
 
 def conv_wgrad(x, dz, taps, x_ss=None, x_hi=None, x_ss_hi=None, scratch_key="a", out=None):
@@ -826,11 +826,15 @@ class ConvStats(torch.autograd.Function):
             # ... or a tensor hook on the weight (wandb.watch, a user's register_hook) would read dW on THIS stream right away
             if (WGRAD_SIDE_STREAM and not torch.is_grad_enabled() and w_ref is not None and w_ref.grad is None
                     and not getattr(w_ref, "_backward_hooks", None)):
-                dw = torch.empty((dz.shape[3], ci, 9), dtype=F32, device=dz.device)     # owned by the current stream's pool
-                _on_side_stream(dz.device, (xin, dz, in_ss, xin_hi, in_ss_hi, dw),
-                                lambda: conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi, scratch_key="side", out=dw),
+                dw_buf = torch.empty((dz.shape[3], ci, 9), dtype=F32, device=dz.device)     # owned by the current stream's pool
+                # (the closure must not hold the tensor OBJECT handed to autograd: AccumulateGrad adopts an incoming gradient only
+                # while nobody else references it, otherwise it clones it on the spot -- before the side stream has computed it)
+                _on_side_stream(dz.device, (xin, dz, in_ss, xin_hi, in_ss_hi, dw_buf),
+                                lambda xin=xin, dz=dz, in_ss=in_ss, xin_hi=xin_hi, in_ss_hi=in_ss_hi, dw_buf=dw_buf:
+                                conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi, scratch_key="side", out=dw_buf),
                                 after=dz_ready)
-                dw = dw.view(dz.shape[3], ci, 3, 3)
+                dw = dw_buf.view(dz.shape[3], ci, 3, 3)
+                del dw_buf
             else:
                 if dz_ready is not None:
                     main.wait_event(dz_ready)

@@ -90,10 +90,18 @@ def _trained_state(state, n_in, h, w, steps=50):
 
 
 # name, mode, emulation flag, n_in, B, H, W, and per stage ("init" / "trained") the absolute ceilings
-#   (outputs vs fp32, loss rel, gradient median vs fp32, gradient worst tensor vs fp32): <= 1.3x measured (see the profile file)
+#   (outputs vs fp32, loss rel, gradient median vs fp32, gradient worst resolved tensor vs fp32): <= 1.3x what was measured on
+#   MI355X for the HIP path (profiles/r04_bf16_parity_default_init.txt; the CPU emulation measured the same to two digits):
+#     fastmri_320_bf16  init    outputs 0.0351  loss 3.0e-4  gradients median 0.204  worst 0.470
+#                       trained outputs 0.0015  loss 3.0e-4  gradients median 0.042  worst 0.116
+#     bsbcm_512x2_fp8   init    outputs 0.212   loss 1.6e-4  gradients median 0.770  worst resolved 0.814 (28 of 62 tensors unresolved)
+#                       trained outputs 0.0073  loss 7.8e-3  gradients median 0.198  worst resolved 0.431 (1 unresolved)
+#   i.e. at INITIALISATION (whichever: closed-form or torch's default) train-mode BatchNorm amplifies storage rounding to percents
+#   of the outputs and tens of percent of the gradients in any implementation; fifty optimiser steps later the same network is
+#   20x (outputs) / 5x (gradients) closer to fp32.
 CASES = [
-    ("fastmri_320_bf16", "bf16", True, 1, 4, 320, 320, {"init": (9, 9, 9, 9), "trained": (9, 9, 9, 9)}),
-    ("bsbcm_512x2_fp8", "fp8", "fp8", 2, 2, 512, 512, {"init": (9, 9, 9, 9), "trained": (9, 9, 9, 9)}),
+    ("fastmri_320_bf16", "bf16", True, 1, 4, 320, 320, {"init": (0.046, 1e-3, 0.265, 0.62), "trained": (0.0020, 1e-3, 0.055, 0.152)}),
+    ("bsbcm_512x2_fp8", "fp8", "fp8", 2, 2, 512, 512, {"init": (0.276, 1e-3, 1.0, 1.06), "trained": (0.0095, 1.1e-2, 0.26, 0.56)}),
 ]
 
 
@@ -120,15 +128,20 @@ def test_low_precision_step_on_default_init_and_trained_weights(case):
             rows.append((pname, rel_l2(gv, ref_g[pname]), rel_l2(emu_g[pname], ref_g[pname]), rel_l2(gv, emu_g[pname])))
         hip, emu, pair = sorted(r[1] for r in rows), sorted(r[2] for r in rows), sorted(r[3] for r in rows)
         med = lambda v: v[len(v) // 2]
-        worst = max(rows, key=lambda r: r[1])
+        # "worst tensor" is taken over the tensors this precision RESOLVES: where even the faithful CPU evaluation is >= 90 % away
+        # from the fp32 gradient (a trained quantile head's bias: the mean of (q - 1[y < pred]) over the pixels, ~0 once the head
+        # is calibrated) the gradient is rounding noise in any implementation and its relative error says nothing
+        resolved = [r for r in rows if r[2] < 0.9] or rows
+        worst = max(resolved, key=lambda r: r[1])
+        hip_w, emu_w = worst[1], max(r[2] for r in resolved)
         print(f"[{name}/{stage}] outputs vs fp32: hip {e_hip:.4f} emu {e_emu:.4f} | hip vs emu {e_pair:.4f} | loss rel: hip {l_hip:.2e} emu {l_emu:.2e}")
-        print(f"[{name}/{stage}] gradient rel-L2 vs fp32: median hip {med(hip):.4f} emu {med(emu):.4f} | worst hip {hip[-1]:.4f} ({worst[0]}) "
-              f"emu {emu[-1]:.4f} | hip vs emu median {med(pair):.4f} worst {pair[-1]:.4f}")
+        print(f"[{name}/{stage}] gradient rel-L2 vs fp32: median hip {med(hip):.4f} emu {med(emu):.4f} | worst resolved tensor hip {hip_w:.4f} "
+              f"({worst[0]}) emu {emu_w:.4f} | {len(rows) - len(resolved)} of {len(rows)} tensors unresolved | hip vs emu median {med(pair):.4f}")
         # as close to fp32 as a faithful evaluation at this precision is
         assert e_hip <= 1.3 * e_emu + 2e-3, (stage, e_hip, e_emu)
         assert l_hip <= 1.5 * l_emu + 2e-3, (stage, l_hip, l_emu)
         assert med(hip) <= 1.3 * med(emu) + 2e-3, (stage, med(hip), med(emu))
-        assert hip[-1] <= 1.5 * emu[-1] + 5e-3, (stage, worst, emu[-1])
+        assert hip_w <= 1.5 * emu_w + 5e-3, (stage, worst, emu_w)
         # absolute: what the mode costs on a network someone would train
         c_out, c_loss, c_med, c_worst = ceilings[stage]
-        assert e_hip < c_out and l_hip < c_loss and med(hip) < c_med and hip[-1] < c_worst, (stage, e_hip, l_hip, med(hip), hip[-1])
+        assert e_hip < c_out and l_hip < c_loss and med(hip) < c_med and hip_w < c_worst, (stage, e_hip, l_hip, med(hip), hip_w)
