@@ -460,6 +460,248 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
       }
 }
 
+// ------------------------------------------------------------------------------------------------
+// [r4] fp8 weight gradient (BASELINE configs[4] "fp8 MFMA conv path": the last third of the conv FLOPs that was still bf16):
+//   dW[co][tap][ci] = sum over pixels of dz[p][co] * a[p + tap][ci]
+// on v_mfma_scale_f32_32x32x64_f8f6f4 with K = 64 PIXELS per instruction: dz as OCP e5m2 under the tensor's delayed
+// power-of-two scale (the same amax slot its fp8 data-gradient reads, conv_fp8.hip), the layer input a as e4m3 times 2^4 -- exactly
+// the operand the fp8 FORWARD staged (lazy BatchNorm+ReLU with the coefficients pre-scaled, clamp, v_cvt_pk_fp8_f32) -- fp32
+// accumulation; both scales are undone for free by the instruction's E8M0 block scales, so the partial sums and the split-K
+// reduction are the bf16 kernel's.  Same workgroup shape as conv_wgrad_pipe_kernel (12 waves = 2 x 2 (co, ci) quadrants x 3
+// kernel rows, 8 x 16-pixel tiles double-buffered in LDS, next tile prefetched into registers under the MFMAs), but the tiles
+// are held as BYTES: [pixel][channel] fp8, and the K(= pixel)-contiguous fragments come from ds_read_b64_tr_b8 (8 x 16-byte
+// block per 16 lanes: lane q supplies row q>>1, half q&1, receives column l&15 of the 8 rows -- tools/hwprobe/tr8probe.hip,
+// profiles/r04_tr8probe.txt).  A lane's 32 fragment bytes = 32 consecutive pixels of ONE channel = two tile rows = 4 reads.
+// Half the LDS bytes and half the MFMA cycles of the bf16 kernel per tile; the HBM side (bf16 operands) is unchanged, so the
+// gain is on the layers whose operands are shared through L2 (>= 128 channels), not on the full-resolution ones.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) i32x2 lds_i32x2;
+constexpr float FP8W_XSCALE = 16.f;          // activation pre-scale 2^4 (conv_fp8.hip XSCALE), undone by scale_b = 127 - 4
+constexpr float FP8W_E4M3_MAX = 448.f, FP8W_E5M2_MAX = 57344.f;
+
+struct Fp8WgradArgs {
+  WgradArgs w;             // x = layer input (bf16), dz (bf16), partial, geometry, lazy coefficients, split input
+  const float* amax_in;    // max |dz| of the previous step (device scalar): the staging scale 2^(14 - e), amax = f * 2^e
+};
+
+template <int COT>
+__global__ __launch_bounds__(768) void conv_wgrad_fp8_kernel(Fp8WgradArgs fa_) {
+  using T = bf16_t;
+  const WgradArgs& a = fa_.w;
+  constexpr int NT = 768;
+  constexpr int TH = 8, TW = 16, HH = TH + 2, HWD = TW + 2, HPX = HH * HWD, M = TH * TW;
+  constexpr int CT = 64, CJ = COT / 64;
+  // byte pitches: the 8 rows of a transposing read (and the two channel sub-blocks of a half-wave) land on 16 distinct
+  // 16-byte bank groups of the 256-byte LDS row with a pad of 32
+  constexpr int PA = COT + 32, PB = CT + 32;
+  constexpr int PPRA = COT / 8, PPR = CT / 8;          // 16-byte bf16 source pieces (8 channels) per pixel
+  constexpr int A_BYTES = M * PA, B_BYTES = HPX * PB, BUF_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_ROUNDS = (M * PPRA + NT - 1) / NT, B_ROUNDS = (HPX * PPR + NT - 1) / NT;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tg = wave >> 2;                          // kernel row kh
+  const int wco = (wave >> 1) & 1, wci = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ci_tiles = a.Ci / CT;
+  int cb = blockIdx.x, split = blockIdx.y;
+#if IM2IM_WGRAD_XCD
+  if ((gridDim.y & 7) == 0) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, j = lin >> 3;
+    split = (j / (int)gridDim.x) * 8 + xcd;
+    cb = j % (int)gridDim.x;
+  }
+#endif
+  const int co0 = (cb / ci_tiles) * COT, ci0 = (cb % ci_tiles) * CT;
+  const WgradSrc<T> xs(a, ci0);
+  const T* __restrict__ xg = xs.x;
+  const T* __restrict__ dzg = reinterpret_cast<const T*>(a.dz);
+
+  f32x16 acc[CJ][3];
+#pragma unroll
+  for (int j = 0; j < CJ; ++j)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
+
+  // delayed scaling of dz: s = 2^(14 - e); the MFMA multiplies the A operand by 2^(scale_a - 127) = 1 / s
+  float dzs = 1.f;
+  int scale_a = 127;
+  {
+    const float amax = *fa_.amax_in;
+    if (amax > 0.f && amax < 3.0e38f) {
+      int e;
+      frexpf(amax, &e);
+      dzs = ldexpf(1.f, 14 - e);
+      scale_a = 127 - (14 - e);
+      if (scale_a < 1) { scale_a = 127; dzs = 1.f; }
+    }
+  }
+  constexpr int scale_b = 127 - 4;
+
+  int a_px[A_ROUNDS], a_part[A_ROUNDS], b_px[B_ROUNDS], b_part[B_ROUNDS];
+#pragma unroll
+  for (int i = 0; i < A_ROUNDS; ++i) { const int p = i * NT + tid; a_px[i] = (p < M * PPRA) ? p / PPRA : -1; a_part[i] = p % PPRA; }
+#pragma unroll
+  for (int i = 0; i < B_ROUNDS; ++i) { const int p = i * NT + tid; b_px[i] = (p < HPX * PPR) ? p / PPR : -1; b_part[i] = p % PPR; }
+  struct Stage { uint4 a[A_ROUNDS], b[B_ROUNDS]; unsigned valid; };
+  // lazy coefficients of the 64 input channels times 2^4, in LDS behind the tile buffers (16 * max(z*s + h, 0) == max(z*16s + 16h, 0))
+  float* ldsSS = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);
+  const bool lazy_x = xs.sc != nullptr;
+  if (lazy_x) {
+    if (tid < CT) { ldsSS[tid] = xs.sc[tid] * FP8W_XSCALE; ldsSS[CT + tid] = xs.sh[tid] * FP8W_XSCALE; }
+    __syncthreads();
+  }
+
+  auto gload = [&](int t, Stage& R) __attribute__((always_inline)) {
+    int tt = t;
+    const int tx_id = tt % a.tilesX; tt /= a.tilesX;
+    const int ty_id = tt % a.tilesY;
+    const int b = tt / a.tilesY;
+    const int y0 = ty_id * TH, x0 = tx_id * TW;
+    const T* xb = xg + (size_t)b * a.H * a.W * xs.stride;
+    const T* dzb = dzg + (size_t)b * a.H * a.W * a.Co + co0;
+#pragma unroll
+    for (int i = 0; i < A_ROUNDS; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (a_px[i] >= 0) {
+        const int yy = y0 + a_px[i] / TW, xx = x0 + a_px[i] % TW;
+        if (yy < a.H && xx < a.W) v = *reinterpret_cast<const uint4*>(dzb + ((size_t)yy * a.W + xx) * a.Co + a_part[i] * 8);
+      }
+      R.a[i] = v;
+    }
+    R.valid = 0;
+#pragma unroll
+    for (int i = 0; i < B_ROUNDS; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (b_px[i] >= 0) {
+        const int yy = y0 + b_px[i] / HWD - 1, xx = x0 + b_px[i] % HWD - 1;
+        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+          v = *reinterpret_cast<const uint4*>(xb + ((size_t)yy * a.W + xx) * xs.stride + b_part[i] * 8);
+          R.valid |= 1u << i;
+        }
+      }
+      R.b[i] = v;
+    }
+  };
+  auto to8 = [&](const float (&v)[8], bool e5m2) __attribute__((always_inline)) -> uint2 {
+    float c[8];
+    const float lim = e5m2 ? FP8W_E5M2_MAX : FP8W_E4M3_MAX;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c[k] = __builtin_amdgcn_fmed3f(v[k], -lim, lim);
+    int lo, hi;
+    if (e5m2) {
+      lo = __builtin_amdgcn_cvt_pk_bf8_f32(c[0], c[1], 0, false); lo = __builtin_amdgcn_cvt_pk_bf8_f32(c[2], c[3], lo, true);
+      hi = __builtin_amdgcn_cvt_pk_bf8_f32(c[4], c[5], 0, false); hi = __builtin_amdgcn_cvt_pk_bf8_f32(c[6], c[7], hi, true);
+    } else {
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], 0, false); hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], hi, true);
+    }
+    return make_uint2((unsigned)lo, (unsigned)hi);
+  };
+  auto swrite = [&](int buf, const Stage& R) __attribute__((always_inline)) {
+    char* la = smem + buf * BUF_BYTES;
+    char* lb = la + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_ROUNDS; ++i)
+      if (a_px[i] >= 0) {
+        float v[8];
+        Vec16<T>::load(reinterpret_cast<const T*>(&R.a[i]), v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= dzs;
+        *reinterpret_cast<uint2*>(la + a_px[i] * PA + a_part[i] * 8) = to8(v, true);
+      }
+#pragma unroll
+    for (int i = 0; i < B_ROUNDS; ++i) {
+      if (b_px[i] >= 0) {
+        uint2 q = make_uint2(0u, 0u);
+        if ((R.valid >> i) & 1) {                         // zero padding stays exactly zero
+          float v[8];
+          Vec16<T>::load(reinterpret_cast<const T*>(&R.b[i]), v);
+          if (lazy_x) {
+            const int c0 = (tid % PPR) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] * ldsSS[c0 + k] + ldsSS[CT + c0 + k], 0.f);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] *= FP8W_XSCALE;
+          }
+          q = to8(v, false);
+        }
+        *reinterpret_cast<uint2*>(lb + b_px[i] * PB + b_part[i] * 8) = q;
+      }
+    }
+  };
+  // fragment addressing: 16-lane group g = lane >> 4 reads channel sub-block (g & 1) * 16 of the wave's 32, pixels (g >> 1) * 32 ...
+  // of the k-step (= MFMA lane half); lane q of the group supplies pixel row q >> 1 and the 8-byte half q & 1 of the block
+  const int g = lane >> 4, q = lane & 15;
+  auto tr8 = [&](const char* p) __attribute__((always_inline)) -> i32x2 {
+    return __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_i32x2*)(lds_char*)p);
+  };
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    const char* la = smem + buf * BUF_BYTES;
+    const char* lb = la + A_BYTES + tg * HWD * PB;
+    const char* pa = la + ((g >> 1) * 32 + (q >> 1)) * PA + wco * (COT / 2) + (g & 1) * 16 + (q & 1) * 8;
+    const char* pb = lb + ((g >> 1) * 2 * HWD + (q >> 1)) * PB + wci * 32 + (g & 1) * 16 + (q & 1) * 8;
+#pragma unroll 1                                          // (unrolled, the scheduler hoists both k-steps' 40 fragment reads: 94 spilled registers)
+    for (int ks = 0; ks < M / 64; ++ks) {
+      i32x8 fa[CJ];
+#pragma unroll
+      for (int j = 0; j < CJ; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const i32x2 v = tr8(pa + j * 32 + (ks * 64 + 8 * i) * PA);
+          fa[j][2 * i] = v[0]; fa[j][2 * i + 1] = v[1];
+        }
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        i32x8 fb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const i32x2 v = tr8(pb + ((ks * 4 + (i >> 1)) * HWD + (i & 1) * 8 + kw) * PB);
+          fb[2 * i] = v[0]; fb[2 * i + 1] = v[1];
+        }
+#pragma unroll
+        for (int j = 0; j < CJ; ++j)
+          acc[j][kw] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[j], fb, acc[j][kw], 1, 0, 0, scale_a, 0, scale_b);
+      }
+    }
+  };
+
+  const int t_begin = split * a.tiles_per_split;
+  const int t_end = min(t_begin + a.tiles_per_split, a.ntiles);
+  if (t_begin < t_end) {
+    Stage R;
+    gload(t_begin, R);
+    swrite(0, R);
+    __syncthreads();
+    int cur = 0;
+    for (int t = t_begin; t < t_end; ++t) {
+      const bool more = t + 1 < t_end;
+      if (more) gload(t + 1, R);
+      compute(cur);
+      if (more) swrite(cur ^ 1, R);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  float* out = a.partial + (size_t)split * a.Co * 9 * a.Ci;
+#pragma unroll
+  for (int j = 0; j < CJ; ++j)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wco * (COT / 2) + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int ci = ci0 + wci * 32 + l31;
+        if (co < a.Co) out[((size_t)co * 9 + tg * 3 + kw) * a.Ci + ci] = acc[j][kw][r];
+      }
+}
+
 // sum partial[nsplit][Co][TAPS][Ci] over splits and write torch layout dw[Co][Ci][TAPS].  Block = 64 outputs x 4 split
 // lanes (lane s adds splits s, s+4, ... in order, the four partial sums are combined in a fixed order): deterministic,
 // and the many-split / few-output case (the 1x1 OutConv) does not serialise on one thread per output.
@@ -804,4 +1046,50 @@ extern "C" int im2im_pack_conv_weights_multi(int32_t n_tensors, const float* con
     }
   }
   return IM2IM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ fp8 weight gradient (ABI)
+extern "C" int im2im_conv_wgrad_fp8(const void* x, const float* x_scale_shift, const void* x_hi, const float* x_scale_shift_hi,
+                                    int32_t Ci_lo, const void* dz, const float* amax_prev, float* dw, void* workspace,
+                                    int64_t workspace_bytes, int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                                    im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(x && dz && dw && workspace && amax_prev);
+  if (x_hi) {
+    IM2IM_REQUIRE(Ci_lo > 0 && Ci_lo % 64 == 0 && Ci == 2 * Ci_lo);
+  } else {
+    IM2IM_REQUIRE(x_scale_shift_hi == nullptr);
+    Ci_lo = Ci;
+  }
+  IM2IM_REQUIRE(B > 0 && H > 0 && W > 0);
+  IM2IM_REQUIRE(Ci > 0 && Ci % 64 == 0 && Co > 0 && Co % 64 == 0);
+  constexpr int TH = 8, TW = 16;
+  WgradArgs a{x, dz, reinterpret_cast<float*>(workspace), B, H, W, Ci, Co, (int)cdiv(H, TH), (int)cdiv(W, TW), 0, 0, x_scale_shift,
+              x_hi, x_scale_shift_hi, Ci_lo};
+  a.ntiles = B * a.tilesY * a.tilesX;
+  const bool wide = Co % 128 == 0;
+  const int cot = wide ? 128 : 64;
+  const int cblocks = (Co / cot) * (Ci / 64);
+  const size_t wsz = (size_t)Co * 9 * Ci * sizeof(float);
+  const int64_t max_split = workspace_bytes / (int64_t)wsz;
+  if (max_split < 1) return fail_invalid("wgrad_fp8: workspace smaller than one weight-sized slab");
+  int64_t nsplit = cdiv(256, cblocks);
+  if (nsplit > a.ntiles) nsplit = a.ntiles;
+  if (nsplit > max_split) nsplit = max_split;
+  if (nsplit < 1) nsplit = 1;
+  a.tiles_per_split = (int)cdiv(a.ntiles, nsplit);
+  nsplit = cdiv(a.ntiles, a.tiles_per_split);
+  Fp8WgradArgs fa{a, amax_prev};
+  if (wide) {
+    constexpr size_t smem = 2 * ((size_t)TH * TW * (128 + 32) + (size_t)(TH + 2) * (TW + 2) * 96) + 512;
+    hipLaunchKernelGGL(conv_wgrad_fp8_kernel<128>, dim3((unsigned)cblocks, (unsigned)nsplit), dim3(768), smem, stream, fa);
+  } else {
+    constexpr size_t smem = 2 * ((size_t)TH * TW * (64 + 32) + (size_t)(TH + 2) * (TW + 2) * 96) + 512;
+    hipLaunchKernelGGL(conv_wgrad_fp8_kernel<64>, dim3((unsigned)cblocks, (unsigned)nsplit), dim3(768), smem, stream, fa);
+  }
+  if (int rc = check_launch("conv_wgrad_fp8_kernel")) return rc;
+  const size_t total = (size_t)Co * 9 * Ci;
+  int blocks = (int)std::min<size_t>(cdiv(total / 4, 64), 8192);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<float*>(workspace), (int)nsplit, Co, Ci, 9, dw);
+  return check_launch("wgrad_reduce_kernel");
 }

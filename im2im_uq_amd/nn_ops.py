@@ -250,6 +250,7 @@ def pack_weight_fp8_dgrad(w: torch.Tensor):
 
 
 FP8_DGRAD = os.environ.get("IM2IM_FP8_DGRAD", "1") != "0"     # fp8 mode: data-gradients on the fp8 kernel too (e5m2 operand)
+FP8_WGRAD = os.environ.get("IM2IM_FP8_WGRAD", "1") != "0"     # [r4] ... and the weight gradients of those layers (e5m2 dz x e4m3 input)
 
 
 _fp8_grad_scales = WeakTensorKeyDictionary()        # conv weight -> Fp8GradScale; NOT an attribute of the Parameter: Parameter.__reduce_ex__
@@ -276,8 +277,29 @@ class Fp8GradScale:
         return base + 4 * prev, base + 4 * now, base + 4 * nxt
 
 
-def conv_dgrad_fp8(dz, wq_d, wscale_d, state: Fp8GradScale, split_out=0):
-    """dx (bf16) = data-gradient of a 3x3 pad-1 conv with e5m2 dz / e4m3 weights (csrc/conv_fp8.hip, GRAD form)."""
+def conv_wgrad_fp8(x, dz, amax_prev, x_ss=None, x_hi=None, x_ss_hi=None, scratch_key="a", out=None):
+    """dw [Co,Ci,9] fp32 of a 3x3 conv with e5m2 dz (scaled from the device scalar at `amax_prev`, an address) and e4m3 input
+    (csrc/conv_wgrad.hip conv_wgrad_fp8_kernel); arguments as conv_wgrad."""
+    b, h, w_, ci = x.shape
+    ci_lo = ci
+    if x_hi is not None:
+        ci = 2 * ci
+    co = dz.shape[3]
+    nbytes = lib.im2im_conv_wgrad_workspace_bytes(b, h, w_, ci, co, 9)
+    ws = _Scratch.get(nbytes, x.device, scratch_key)
+    dw = torch.empty((co, ci, 9), dtype=F32, device=x.device) if out is None else out
+    ev = TIMER.wrap(f"conv_wgrad_fp8_kernel<{128 if co % 128 == 0 else 64}>", 2.0 * b * h * w_ * co * ci * 9, x.device) if TIMER else None
+    check(lib.im2im_conv_wgrad_fp8(dptr(x), dptr(x_ss), dptr(x_hi), dptr(x_ss_hi), ci_lo, dptr(dz), amax_prev, dptr(dw), dptr(ws), ws.numel(),
+                                   b, h, w_, ci, co, stream_ptr(x.device)), "im2im_conv_wgrad_fp8")
+    if ev is not None:
+        ev.record(torch.cuda.current_stream(x.device))
+    return dw
+
+
+def conv_dgrad_fp8(dz, wq_d, wscale_d, state: Fp8GradScale, split_out=0, slots=None):
+    """dx (bf16) = data-gradient of a 3x3 pad-1 conv with e5m2 dz / e4m3 weights (csrc/conv_fp8.hip, GRAD form).
+    slots: this step's (previous, now, next) amax addresses when the caller already took them (the fp8 weight gradient of the same
+    layer reads `previous` too)."""
     b, h, w_, cz = dz.shape
     cx = wq_d.shape[0]
     if split_out:
@@ -285,7 +307,7 @@ def conv_dgrad_fp8(dz, wq_d, wscale_d, state: Fp8GradScale, split_out=0):
         dx_hi = torch.empty((b, h, w_, cx - split_out), dtype=BF16, device=dz.device)
     else:
         dx, dx_hi = torch.empty((b, h, w_, cx), dtype=BF16, device=dz.device), None
-    prev, now, nxt = state.slots(dz)
+    prev, now, nxt = slots if slots is not None else state.slots(dz)
     small = h < 64 or w_ < 64
     name = f"conv_fp8_kernel<{'2x8x8' if small else '1x16x16'},{128 if cx % 128 == 0 else 64},dgrad>"
     ev = TIMER.wrap(name, 2.0 * b * h * w_ * cz * cx * 9, dz.device) if TIMER else None
@@ -823,15 +845,22 @@ class ConvStats(torch.autograd.Function):
             # the weight gradient goes to the second stream (see _on_side_stream) unless autograd is about to ACCUMULATE it into
             # an existing .grad on this stream the moment we return (gradient accumulation over several backward passes)
             w_ref = ctx.weight_ref() if ctx.weight_ref is not None else None
+            # fp8 mode: this layer's dz scale slots, taken ONCE per step (the weight gradient reads `previous`, the data-gradient
+            # below reads it too and maintains the other two)
+            fp8_slots = ctx.fp8_gs.slots(dz) if ctx.fp8_dgrad else None
+            fp8_w = ctx.fp8_dgrad and FP8_WGRAD and dz.dtype == BF16 and dz.shape[3] % 64 == 0 and ci % 64 == 0
+
+            def wgrad(out, key):
+                if fp8_w:
+                    return conv_wgrad_fp8(xin, dz, fp8_slots[0], x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi, scratch_key=key, out=out)
+                return conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi, scratch_key=key, out=out)
             # ... or a tensor hook on the weight (wandb.watch, a user's register_hook) would read dW on THIS stream right away
             if (WGRAD_SIDE_STREAM and not torch.is_grad_enabled() and w_ref is not None and w_ref.grad is None
                     and not getattr(w_ref, "_backward_hooks", None)):
                 dw_buf = torch.empty((dz.shape[3], ci, 9), dtype=F32, device=dz.device)     # owned by the current stream's pool
                 # (the closure must not hold the tensor OBJECT handed to autograd: AccumulateGrad adopts an incoming gradient only
                 # while nobody else references it, otherwise it clones it on the spot -- before the side stream has computed it)
-                _on_side_stream(dz.device, (xin, dz, in_ss, xin_hi, in_ss_hi, dw_buf),
-                                lambda xin=xin, dz=dz, in_ss=in_ss, xin_hi=xin_hi, in_ss_hi=in_ss_hi, dw_buf=dw_buf:
-                                conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi, scratch_key="side", out=dw_buf),
+                _on_side_stream(dz.device, (xin, dz, in_ss, xin_hi, in_ss_hi, dw_buf), lambda dw_buf=dw_buf: wgrad(dw_buf, "side"),
                                 after=dz_ready)
                 dw = dw_buf.view(dz.shape[3], ci, 3, 3)
                 del dw_buf
@@ -839,7 +868,7 @@ class ConvStats(torch.autograd.Function):
                 if dz_ready is not None:
                     main.wait_event(dz_ready)
                     halves = dz_ready = None
-                dw = conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi).view(dz.shape[3], ci, 3, 3)
+                dw = wgrad(None, "a").view(dz.shape[3], ci, 3, 3)
             link = ctx.link
             fuse = (FUSE_BN_REDUCE and xin_hi is None and link is not None and link.consumers == 1 and link.z.dtype == dz.dtype
                     and not ctx.fp8_dgrad)
@@ -873,10 +902,10 @@ class ConvStats(torch.autograd.Function):
                 if ctx.fp8_dgrad and (xin_hi is not None or ctx.needs_input_grad[0]):
                     # fp8 mode: e5m2 dz x e4m3 weights on the block-scaled MFMA (conv_fp8.hip, GRAD form)
                     if xin_hi is not None:
-                        dx, dx_hi = conv_dgrad_fp8(dz, wq_d, wscale_d, ctx.fp8_gs, split_out=xin.shape[3])
+                        dx, dx_hi = conv_dgrad_fp8(dz, wq_d, wscale_d, ctx.fp8_gs, split_out=xin.shape[3], slots=fp8_slots)
                         dx, dx_hi = nchw(dx), nchw(dx_hi)
                     else:
-                        dx = nchw(conv_dgrad_fp8(dz, wq_d, wscale_d, ctx.fp8_gs))
+                        dx = nchw(conv_dgrad_fp8(dz, wq_d, wscale_d, ctx.fp8_gs, slots=fp8_slots))
                 elif xin_hi is not None:
                     # the data-gradient lands directly in d(skip) and d(up): no concatenated gradient tensor
                     dx, dx_hi = conv_fwd(dz, wd, split_out=xin.shape[3])

@@ -264,6 +264,17 @@ int im2im_conv_wgrad_split(const void* x, const float* x_scale_shift, const void
                            int64_t workspace_bytes, int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co,
                            int32_t taps, int32_t dtype, im2im_stream_t stream);
 
+/* [r4] fp8 weight gradient (BASELINE configs[4] "fp8 MFMA conv path"; the dW half of autograd's backward of nn.Conv2d 3x3,
+ * unet_parts.py:16,19 under loss.backward(), train.py:159): dz as OCP e5m2 under the tensor's delayed power-of-two scale
+ * (amax_prev: max |dz| of the previous step, the slot im2im_conv_dgrad_fp8 maintains), the layer input as e4m3 x 2^4 -- the
+ * operand the fp8 forward staged, lazy BatchNorm+ReLU included -- on v_mfma_scale_f32_32x32x64_f8f6f4 with K = 64 pixels,
+ * fp32 accumulation, deterministic split-K reduction into dw [Co][Ci][3][3] fp32.  x, dz bf16; Ci % 64 == 0, Co % 64 == 0;
+ * workspace as for im2im_conv_wgrad (im2im_conv_wgrad_workspace_bytes with taps = 9). */
+int im2im_conv_wgrad_fp8(const void* x, const float* x_scale_shift, const void* x_hi, const float* x_scale_shift_hi,
+                         int32_t Ci_lo, const void* dz, const float* amax_prev, float* dw, void* workspace,
+                         int64_t workspace_bytes, int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                         im2im_stream_t stream);
+
 
 /* Shared scratch for the deterministic two-stage "sum over pixels" reductions: bytes needed to reduce
  * K columns (used by bn_finalize; other entry points have their own *_workspace_bytes). */

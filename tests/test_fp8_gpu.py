@@ -338,3 +338,100 @@ def test_fp8_mode_train_step_uses_the_fp8_data_gradient():
         nn_ops.TIMER = None
     errs = sorted(rel_l2(grads[True][n].cpu(), grads[False][n].cpu()) for n in grads[True] if float(grads[False][n].abs().max()) > 0)
     assert errs[len(errs) // 2] < 0.15 and errs[-1] < 0.6, (errs[len(errs) // 2], errs[-1])
+
+
+# [r4] fp8 weight gradient: e5m2 dz (the tensor's delayed scale) x e4m3 layer input (x 2^4, lazy BatchNorm+ReLU applied while
+# staging) on the K = 64-pixel block-scaled MFMA -- csrc/conv_wgrad.hip conv_wgrad_fp8_kernel (ds_read_b64_tr_b8 fragments)
+def _wgrad_emulation(x_nhwc, dz_nhwc, amax, ss=None, x_hi=None, ss_hi=None):
+    """the kernel's arithmetic on the CPU: dz -> bf16 -> x s -> clamp -> e5m2 (/ s); input -> bf16 -> max(z*(16 sc) + 16 sh, 0) or
+    x 16 -> clamp -> e4m3 (/ 16); the correlation in float64."""
+    xs = _grad_scale(amax)
+    dq = (dz_nhwc.to(BF16).to(F32) * xs).clamp(-57344.0, 57344.0).to(torch.float8_e5m2).to(F32) / xs
+
+    def q(x, ss):
+        v = x.to(BF16).to(F32)
+        if ss is not None:
+            v = torch.clamp_min(v * (ss[0] * 16.0) + ss[1] * 16.0, 0.0)       # mul then add, as the kernel (no contraction)
+        else:
+            v = v * 16.0
+        return v.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(F32) / 16.0
+    xq = q(x_nhwc, ss)
+    if x_hi is not None:
+        xq = torch.cat([xq, q(x_hi, ss_hi)], dim=-1)
+    co, ci = dq.shape[-1], xq.shape[-1]
+    dw = torch.nn.grad.conv2d_weight(xq.permute(0, 3, 1, 2).double(), (co, ci, 3, 3), dq.permute(0, 3, 1, 2).double(), padding=1)
+    return dw.float()
+
+
+WGRAD8_CASES = [
+    # B, H, W, Ci, Co, lazy input, split input
+    (2, 40, 48, 128, 128, True, False),      # 128 output channels per workgroup, full tiles
+    (3, 20, 24, 256, 64, True, False),       # 64-channel form, overhanging tiles (20 = 2.5 x 8), several splits
+    (1, 33, 17, 64, 128, False, False),      # plain (non-lazy) input, ragged extent
+    (2, 32, 32, 256, 128, True, True),       # split input: the Up block's [skip, upsampled]
+    (1, 80, 80, 128, 256, True, False),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD8_CASES)
+def test_conv_wgrad_fp8_vs_cpu_on_identically_quantised_operands(case):
+    from im2im_uq_amd import nn_ops
+    b, h, w, ci, co, lazy, split = case
+    cin = ci // 2 if split else ci
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(b, h, w, cin, generator=g)
+    xh = torch.randn(b, h, w, cin, generator=g) if split else None
+    ss = torch.stack([torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.4]) if lazy else None
+    ssh = torch.stack([torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.4]) if (lazy and split) else None
+    dz = torch.randn(b, h, w, co, generator=g) * 3e-5             # gradient-sized: far below e5m2's normals unscaled
+    dz[0, 0, 0, 0] = 2.5e-4
+    amax_v = float(dz.to(BF16).to(F32).abs().max())
+    ref = _wgrad_emulation(x, dz, amax_v, ss, xh, ssh)
+    amax = torch.tensor([amax_v], dtype=F32, device=DEV)
+    xd, dzd = x.to(DEV, BF16), dz.to(DEV, BF16)
+    got = nn_ops.conv_wgrad_fp8(xd, dzd, amax.data_ptr(), x_ss=ss.to(DEV) if lazy else None, x_hi=xh.to(DEV, BF16) if split else None,
+                                x_ss_hi=ssh.to(DEV) if ssh is not None else None)
+    got2 = nn_ops.conv_wgrad_fp8(xd, dzd, amax.data_ptr(), x_ss=ss.to(DEV) if lazy else None, x_hi=xh.to(DEV, BF16) if split else None,
+                                 x_ss_hi=ssh.to(DEV) if ssh is not None else None)
+    assert torch.equal(got, got2)                                 # deterministic
+    got = got.view(co, ci, 3, 3).cpu()
+    assert rel_l2(got, ref) < 2e-5, rel_l2(got, ref)             # same operands, fp32 accumulation in another order
+    # against the bf16 weight gradient: what e5m2 x e4m3 costs on a contraction over B*H*W pixels
+    bf = nn_ops.conv_wgrad(xd, dzd, 9, x_ss=ss.to(DEV) if lazy else None, x_hi=xh.to(DEV, BF16) if split else None,
+                           x_ss_hi=ssh.to(DEV) if ssh is not None else None).view(co, ci, 3, 3).cpu()
+    assert rel_l2(got, bf) < 0.08, rel_l2(got, bf)
+
+
+def test_fp8_mode_train_step_uses_the_fp8_weight_gradient():
+    """fp8 mode: the layers whose data-gradient is fp8 take the fp8 weight gradient too (IM2IM_FP8_WGRAD, default on); the step
+    is finite and its gradients stay within fp8-sized distance of the step with bf16 weight gradients."""
+    from im2im_uq_amd import nn_ops
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from im2im_uq_amd.core.models.trunks.unet import UNet
+    nn_ops.set_compute_dtype("fp8")
+    torch.manual_seed(0)
+    model = add_uncertainty(UNet(1, 1), dict(PARAMS)).to(DEV).train()
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.randn(3, 1, 64, 64, generator=g).to(DEV), torch.rand(3, 1, 64, 64, generator=g).to(DEV)
+    grads = {}
+    was = nn_ops.FP8_WGRAD
+    try:
+        for flag in (False, True):
+            nn_ops.FP8_WGRAD = flag
+            for rep in range(2):                                  # second pass: the scales come from the first (delayed scaling)
+                nn_ops.TIMER = nn_ops.KernelTimer()
+                for p in model.parameters():
+                    p.grad = None
+                loss = model.loss_fn(model(x), y)
+                loss.backward()
+                nn_ops.join_side_streams()
+                rows = nn_ops.TIMER.collect()
+                nn_ops.TIMER = None
+            assert any("wgrad_fp8" in k for k in rows) == flag
+            grads[flag] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+            assert all(bool(torch.isfinite(v).all()) for v in grads[flag].values())
+    finally:
+        nn_ops.FP8_WGRAD = was
+        nn_ops.TIMER = None
+    errs = sorted(rel_l2(grads[True][n].cpu(), grads[False][n].cpu()) for n in grads[True] if float(grads[False][n].abs().max()) > 0)
+    assert errs[len(errs) // 2] < 0.05 and errs[-1] < 0.3, (errs[len(errs) // 2], errs[-1])
