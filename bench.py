@@ -106,7 +106,8 @@ CONFIGS = {
                       size=32, n_in=1, depth=2, batch=32, calib_total=64, num_lambdas=50, lam=(0.0, 6.0), dtype="bf16"),
     "temca1024": dict(label="TEMCA2-shaped 1024x1024 tiles, 5-level (deeper) UNet (BASELINE configs[3])",
                       size=1024, n_in=1, depth=5, batch=4, calib_total=256, num_lambdas=100, lam=(7.0, 10.0), dtype="bf16"),
-    "bsbcm512": dict(label="BSBCM-shaped 512x512, 2 input channels, 4-level UNet (BASELINE configs[4])",
+    "bsbcm512": dict(label="BSBCM-shaped 512x512, 2 input channels, 4-level UNet (BASELINE configs[4]; dtype fp8 = e4m3 / e5m2 operands in the forward, "
+                           "data-gradient and weight-gradient 3x3 convs of the layers with >= 128 input channels, everything else bf16)",
                      size=512, n_in=2, depth=4, batch=16, calib_total=256, num_lambdas=2000, lam=(0.0, 6.0), dtype="fp8"),
 }
 
@@ -387,7 +388,8 @@ def roofline_leg(wl, config_name, full=True):
     rows = wl.kernel_rows(overlapped=False)
     per_kernel = {k: {"launches": n, "avg_ms": t / n, "tflops": f / t / 1e9} for k, (n, f, t) in sorted(rows.items())}
     ig = [v for k, v in rows.items() if k.startswith("conv_igemm") or k.startswith("conv_ws")]
-    wg = [v for k, v in rows.items() if k.startswith("conv_wgrad")]
+    wg = [v for k, v in rows.items() if k.startswith("conv_wgrad") and not k.startswith("conv_wgrad_fp8")]
+    wg8 = [v for k, v in rows.items() if k.startswith("conv_wgrad_fp8")]
     f8 = [v for k, v in rows.items() if k.startswith("conv_fp8")]
     roof = dict(_agg(ig, peak), kernel="conv_igemm_kernel + conv_ws_kernel (forward + data-gradient launches, all tile variants)")
     roof_dgrad = None
@@ -396,6 +398,8 @@ def roofline_leg(wl, config_name, full=True):
         roof_dgrad = dict(roof, kernel="conv_igemm_kernel (bf16: the launches the fp8 kernels do not cover)")
         roof = roof_fp8
     roof_w = dict(_agg(wg, peak), kernel="conv_wgrad_kernel (+ its split-K reduce)") if wg else None
+    if wg8 and roof_w is not None:      # fp8 mode: the eligible layers' weight gradients run on the block-scaled MFMA -> priced against ITS peak
+        roof_w["fp8_launches"] = dict(_agg(wg8, PEAK_FP8_TFLOPS), kernel="conv_wgrad_fp8_kernel (e5m2 dz x e4m3 input, + its split-K reduce)")
     if not full:
         return roof, roof_w, per_kernel, roof_dgrad
     # second reading: the same kernels inside the step that `value` times (weight gradients on their own stream)
@@ -568,7 +572,7 @@ def sub_record(job, name, steps=4, warmup=2, dtype=None, batch=None, calib=True)
            "hip_graph": bool(wl.graphed),      # the train loop's rule: forward + loss + backward replayed as one HIP graph for launch-bound shapes
            "train_tflops": tr["imgs_per_s"] * wl.train_flop / 1e12,
            "roofline": {k: roof[k] for k in ("achieved", "peak", "frac", "unit", "kernel")},
-           "roofline_wgrad": {k: roof_w[k] for k in ("achieved", "peak", "frac", "unit")} if roof_w else None}
+           "roofline_wgrad": {k: roof_w[k] for k in ("achieved", "peak", "frac", "unit", "fp8_launches") if k in roof_w} if roof_w else None}
     if roof_dgrad:
         rec["roofline_bf16_igemm"] = {k: roof_dgrad[k] for k in ("achieved", "peak", "frac", "unit")}
     if calib:
