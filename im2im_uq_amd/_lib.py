@@ -50,6 +50,7 @@ SIGNATURES = {
     # x, in_ss, x_hi, in_ss_hi, Ci_lo, wf, bias, center, scale, shift, y, y_hi, Co_lo, stats, B, H, W, Ci, Co, taps, relu, dtype, stream
     "im2im_conv_fwd_split": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr,
                                     _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
+    "im2im_conv_fwd_eval_pool": (_i32, [_ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_conv_wgrad_fp8": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_conv_splitk_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "im2im_conv_fwd_split_ws": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr,

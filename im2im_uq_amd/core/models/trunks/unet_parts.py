@@ -75,7 +75,7 @@ class DoubleConv(nn.Module):
             else:
                 needs_graph = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad or bn.weight.requires_grad)
                 x = nn_ops.conv_bn_relu_eval(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
-                                             bn.running_var, bn.eps, cdt, owner=conv, x_hi=x_hi)
+                                             bn.running_var, bn.eps, cdt, owner=conv, x_hi=x_hi, pool=(pool and ci == 3 and not needs_graph))
                 if needs_graph:
                     # the fused eval kernel has no backward: the forward works as in the reference, but the result is tied
                     # to its inputs by a node that raises if anyone back-propagates through it (instead of silently

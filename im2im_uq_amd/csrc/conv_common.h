@@ -39,6 +39,8 @@ struct ConvArgs {
   int ksplit, kchunks;
   float* kpartial;
   int64_t kws_bytes;    // size of the caller's workspace behind kpartial
+  // EPI 2 (eval): null, or [B][H/2][W/2][Co] T: MaxPool2d(2) of the stored result, taken from the epilogue's LDS tile (H, W even)
+  void* pool_y;
 };
 
 // Packed bf16 3x3 weights are FRAGMENT-MAJOR: the 32 rows x 16 reduction channels one lane-set of v_mfma_f32_32x32x16_bf16

@@ -523,6 +523,25 @@ __global__ __launch_bounds__(256, (igemm_wgs_per_cu<T, TB * TH * TW / (32 * WM) 
       const size_t off = (((size_t)bb * a.H + yy) * a.W + xx) * ystride + piece * EPP;
       // streamed: the tile is not read again by this kernel and is far larger than L2 (+2 % over the 13 BASELINE layers)
       __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(yg + off));
+      if constexpr (EPI == 2) {
+        // [r4] eval mode, a block whose output also feeds MaxPool2d(2) (unet_parts.py:33-36): the 2x2 maximum comes from this wave's
+        // LDS tile (the window's other three pixels are rows +1, +TW, +TW+1 of the same tile: tiles start on even pixels and a
+        // wave owns an even number of whole tile rows), so the separate pooling pass never re-reads the activation from HBM
+        if (a.pool_y) {
+          const int yi = (m % MI) / TW, xi = m % TW;
+          if (!((yi | xi) & 1) && yy + 1 < a.H && xx + 1 < a.W) {
+            float p00[EPP], p01[EPP], p10[EPP], p11[EPP];
+            Vec16<T>::load(reinterpret_cast<const T*>(&v), p00);
+            Vec16<T>::load(reinterpret_cast<const T*>(wbuf + (row + 1) * WP + piece * 16), p01);
+            Vec16<T>::load(reinterpret_cast<const T*>(wbuf + (row + TW) * WP + piece * 16), p10);
+            Vec16<T>::load(reinterpret_cast<const T*>(wbuf + (row + TW + 1) * WP + piece * 16), p11);
+#pragma unroll
+            for (int k = 0; k < EPP; ++k) p00[k] = fmaxf(fmaxf(p00[k], p01[k]), fmaxf(p10[k], p11[k]));      // maxpool2_fwd_kernel's order
+            T* py = reinterpret_cast<T*>(a.pool_y) + ((((size_t)bb * (a.H >> 1) + (yy >> 1)) * (a.W >> 1) + (xx >> 1)) * a.Co) + ncol + piece * EPP;
+            Vec16<T>::store_nt(py, p00);
+          }
+        }
+      }
       if constexpr (EPI == 3) {
         float g[EPP], zz[EPP];
         Vec16<T>::load(reinterpret_cast<const T*>(&v), g);
@@ -771,7 +790,7 @@ int conv_fwd_impl(const void* x, const float* in_scale_shift, int in_ss_img, boo
                   const float* in_scale_shift_hi, int32_t Ci_lo, const void* w, const float* bias, const float* center,
                   const float* scale, const float* shift, void* y, void* y_hi, int32_t Co_lo, float* stats, int32_t B, int32_t H,
                   int32_t W, int32_t Ci, int32_t Co, int32_t taps, int32_t relu, int32_t dtype, im2im_stream_t stream_,
-                  void* ws = nullptr, int64_t ws_bytes = 0);
+                  void* ws = nullptr, int64_t ws_bytes = 0, void* pool_y = nullptr);
 }
 
 extern "C" int im2im_conv_fwd_per_image(const void* x, const float* in_scale_shift_per_image, const void* w, const float* bias,
@@ -804,6 +823,14 @@ extern "C" int im2im_conv_fwd_split_ws(const void* x, const float* in_scale_shif
                        stats, B, H, W, Ci, Co, taps, relu, dtype, stream_, workspace, workspace_bytes);
 }
 
+extern "C" int im2im_conv_fwd_eval_pool(const void* x, const void* x_hi, int32_t Ci_lo, const void* w, const float* scale,
+                                        const float* shift, void* y, void* pool_y, int32_t B, int32_t H, int32_t W, int32_t Ci,
+                                        int32_t Co, int32_t dtype, im2im_stream_t stream_) {
+  IM2IM_REQUIRE(pool_y != nullptr);
+  return conv_fwd_impl(x, nullptr, 0, false, x_hi, nullptr, Ci_lo, w, nullptr, nullptr, scale, shift, y, nullptr, Co, nullptr, B, H, W,
+                       Ci, Co, 9, 1, dtype, stream_, nullptr, 0, pool_y);
+}
+
 namespace im2im { void set_conv_splitk(int v) { g_conv_splitk = v; } }
 
 namespace {
@@ -811,7 +838,7 @@ int conv_fwd_impl(const void* x, const float* in_scale_shift, int in_ss_img, boo
                   const float* in_scale_shift_hi, int32_t Ci_lo, const void* w, const float* bias, const float* center,
                   const float* scale, const float* shift, void* y, void* y_hi, int32_t Co_lo, float* stats, int32_t B, int32_t H,
                   int32_t W, int32_t Ci, int32_t Co, int32_t taps, int32_t relu, int32_t dtype, im2im_stream_t stream_,
-                  void* ws, int64_t ws_bytes) {
+                  void* ws, int64_t ws_bytes, void* pool_y) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(x && w && y);
   if (x_hi) {
@@ -837,7 +864,8 @@ int conv_fwd_impl(const void* x, const float* in_scale_shift, int in_ss_img, boo
   IM2IM_REQUIRE(in_ss_img == 0 || (per_image && x_hi == nullptr));   // per-image coefficients need one image per tile
   ConvArgs a{x, w, bias, scale, shift, y, stats, B, H, W, Ci, Co, 0, 0, relu, center, in_scale_shift,
              x_hi, in_scale_shift_hi, Ci_lo, y_hi, Co_lo, nullptr, nullptr, nullptr, nullptr, in_ss_img,
-             1, 0, reinterpret_cast<float*>(ws), ws ? ws_bytes : 0};
+             1, 0, reinterpret_cast<float*>(ws), ws ? ws_bytes : 0, pool_y};
+  if (pool_y) IM2IM_REQUIRE(scale && relu && y_hi == nullptr && H % 2 == 0 && W % 2 == 0 && !per_image);
   if (dtype == IM2IM_BF16) return taps == 9 ? dispatch_conv<bf16_t, 9>(a, stream, per_image) : dispatch_conv<bf16_t, 1>(a, stream, per_image);
   return taps == 9 ? dispatch_conv<float, 9>(a, stream, per_image) : dispatch_conv<float, 1>(a, stream, per_image);
 }
@@ -854,7 +882,7 @@ extern "C" int im2im_conv_dgrad_bn(const void* dz, const void* wd, void* dx, con
   IM2IM_REQUIRE(taps == 9 || taps == 1);
   IM2IM_REQUIRE(dtype == IM2IM_F32 || dtype == IM2IM_BF16);
   ConvArgs a{dz, wd, nullptr, nullptr, nullptr, dx, nullptr, B, H, W, Ci, Co, 0, 0, 0, nullptr, nullptr,
-             nullptr, nullptr, Ci, nullptr, Co, bn_z, bn_scale_shift, bn_mean_invstd, bn_partial, 0, 1, 0, nullptr, 0};
+             nullptr, nullptr, Ci, nullptr, Co, bn_z, bn_scale_shift, bn_mean_invstd, bn_partial, 0, 1, 0, nullptr, 0, nullptr};
   if (dtype == IM2IM_BF16) return taps == 9 ? dispatch_conv<bf16_t, 9>(a, stream) : dispatch_conv<bf16_t, 1>(a, stream);
   return taps == 9 ? dispatch_conv<float, 9>(a, stream) : dispatch_conv<float, 1>(a, stream);
 }

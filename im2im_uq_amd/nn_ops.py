@@ -1031,8 +1031,10 @@ def conv_bn_relu_train(x, weight, bias, gamma, beta, running_mean, running_var, 
 _EVAL_CACHE = weakref.WeakKeyDictionary()      # conv module -> (key, packed operands): see conv_bn_relu_eval
 
 
-def conv_bn_relu_eval(x, weight, bias, gamma, beta, running_mean, running_var, eps, cdt, owner=None, x_hi=None):
+def conv_bn_relu_eval(x, weight, bias, gamma, beta, running_mean, running_var, eps, cdt, owner=None, x_hi=None, pool=False):
     """eval mode: BatchNorm folded into the conv epilogue (one kernel, no intermediate).
+    pool=True [r4]: also return MaxPool2d(2) of the result -> (a, pooled), taken from the epilogue's LDS tile when the extent is
+    even and the conv runs on the bf16 / fp32 MFMA kernel (otherwise the caller pools separately: a plain tensor is returned).
 
     owner (the conv module): the folded coefficients and the packed weight are kept for it and reused while none of the
     six tensors changed (storage and version counter) -- calibration and validation run hundreds of forwards over the
@@ -1062,6 +1064,16 @@ def conv_bn_relu_eval(x, weight, bias, gamma, beta, running_mean, running_var, e
     xin_hi = nhwc(x_hi.detach(), cdt) if x_hi is not None else None
     if fp8:
         return nchw(conv_fwd_fp8(xin, packed[0], packed[1], None, fold, relu=True, x_hi=xin_hi))
+    b, h, w_, cin = xin.shape
+    if pool and not torch.is_grad_enabled() and h % 2 == 0 and w_ % 2 == 0 and h >= 2 and w_ >= 2:
+        y = torch.empty((b, h, w_, co), dtype=cdt, device=xin.device)
+        pooled = torch.empty((b, h // 2, w_ // 2, co), dtype=cdt, device=xin.device)
+        ev = TIMER.wrap(_tile_name("igemm", h, w_, co, 9, cdt), 2.0 * b * h * w_ * co * ci * 9, xin.device) if TIMER else None
+        check(lib.im2im_conv_fwd_eval_pool(dptr(xin), dptr(xin_hi), cin, dptr(packed), dptr(fold[0]), dptr(fold[1]), dptr(y), dptr(pooled),
+                                           b, h, w_, ci, co, _DT[cdt], stream_ptr(xin.device)), "im2im_conv_fwd_eval_pool")
+        if ev is not None:
+            ev.record(torch.cuda.current_stream(xin.device))
+        return nchw(y), nchw(pooled)
     return nchw(conv_fwd(xin, packed, None, fold, relu=True, x_hi=xin_hi))
 
 

@@ -204,6 +204,14 @@ int im2im_conv_fwd_split_ws(const void* x, const float* in_scale_shift, const vo
                             int32_t taps, int32_t relu, int32_t dtype, void* workspace, int64_t workspace_bytes,
                             im2im_stream_t stream);
 
+/* [r4] Eval-mode conv3x3 + folded BatchNorm + ReLU of a block whose output ALSO feeds MaxPool2d(2) (DoubleConv followed by
+ * Down.maxpool_conv[0], unet_parts.py:33-36, in model.eval()): y as im2im_conv_fwd_split with scale / shift / relu = 1, and
+ * pool_y [B][H/2][W/2][Co] = MaxPool2d(2)(y), taken from the epilogue's LDS tile -- same values as im2im_maxpool2_fwd on y, without
+ * re-reading y.  H and W even.  x_hi / Ci_lo as in im2im_conv_fwd_split (NULL / Ci for a single input). */
+int im2im_conv_fwd_eval_pool(const void* x, const void* x_hi, int32_t Ci_lo, const void* wf, const float* scale,
+                             const float* shift, void* y, void* pool_y, int32_t B, int32_t H, int32_t W, int32_t Ci,
+                             int32_t Co, int32_t dtype, im2im_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * fp8 forward convolution (BASELINE configs[4] "fp8 MFMA conv path"): 3x3 pad-1 conv whose operands are OCP e4m3 on
  * v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64, ~2x the bf16 MFMA rate), fp32 accumulate, bf16 in/out.  Same contract as

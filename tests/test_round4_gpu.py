@@ -171,3 +171,47 @@ def test_bn_reductions_many_launches_of_changing_shapes():
         assert torch.allclose(dg.double().cpu(), (gg * xhat).sum(0), rtol=1e-4, atol=1e-3), it
         want = sc.double() * (gg - gg.mean(0) - xhat * (gg * xhat).mean(0))
         assert rel_l2(dz.double().cpu().view(m, c), want) < 2e-5, it
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp32"])
+def test_eval_conv_with_fused_maxpool_equals_conv_then_maxpool(dt):
+    """[r4] im2im_conv_fwd_eval_pool: the eval-mode conv + folded BatchNorm + ReLU of a block that also feeds MaxPool2d(2)
+    (unet_parts.py:33-36) hands back the pooled tensor from its epilogue -- same bits as the separate max-pool pass, for every tile
+    family (32x16x64, 16x16x128, 8x8 patches of several images), overhanging tiles included; and a whole eval forward with and
+    without the fusion is bit-identical."""
+    from im2im_uq_amd import nn_ops
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from im2im_uq_amd.core.models.trunks.unet import UNet
+    nn_ops.set_compute_dtype(dt)
+    cdt = BF16 if dt == "bf16" else F32
+    try:
+        g = torch.Generator().manual_seed(8)
+        for (b, h, w_, ci, co) in [(2, 64, 96, 64, 64), (3, 80, 72, 64, 128), (5, 40, 24, 128, 256), (1, 20, 36, 256, 256), (2, 70, 66, 64, 32)]:
+            x = torch.randn(b, ci, h, w_, generator=g).to(DEV).to(cdt).contiguous(memory_format=torch.channels_last)
+            conv = torch.nn.Conv2d(ci, co, 3, padding=1).to(DEV)
+            bn = torch.nn.BatchNorm2d(co).to(DEV)
+            with torch.no_grad():
+                bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2.0); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
+                args = (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, cdt)
+                a, pooled = nn_ops.conv_bn_relu_eval(x, *args, pool=True)
+                a0 = nn_ops.conv_bn_relu_eval(x, *args)
+                assert torch.equal(a, a0)
+                assert torch.equal(pooled, nn_ops.MaxPool2.apply(a0)), (b, h, w_, ci, co)
+        torch.manual_seed(1)
+        params = dict(uncertainty_type="quantiles", q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1)
+        model = add_uncertainty(UNet(1, 1), dict(params)).to(DEV)
+        with torch.no_grad():
+            model.train()
+            model(torch.randn(2, 1, 64, 64, device=DEV))             # non-trivial BatchNorm buffers
+            model.eval()
+            xin = torch.randn(3, 1, 96, 80, device=DEV)
+            fused = model(xin)
+            real = nn_ops.conv_bn_relu_eval
+            nn_ops.conv_bn_relu_eval = lambda *a_, pool=False, **k: real(*a_, **k)
+            try:
+                plain = model(xin)
+            finally:
+                nn_ops.conv_bn_relu_eval = real
+        assert torch.equal(fused, plain)
+    finally:
+        nn_ops.set_compute_dtype("bf16")
