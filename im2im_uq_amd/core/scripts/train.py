@@ -455,6 +455,7 @@ class GraphedStep:
                 self.sync.deferred = False
         self.graph = graph
         self.grads = [p.grad for p in self.params]            # without a GradSync: the graph's own gradient tensors
+        self.stepped = [p for p in self.params if p.grad is not None]    # what the captured optimizer step updates
         self.addr = self._addresses()
         self.fresh = True                                      # the capture did the host bookkeeping of its first replay
         return True
@@ -500,7 +501,7 @@ class GraphedStep:
             self.sync.reduce_all()                            # the exchange itself: outside the graph (any backend)
         if self.in_graph_opt:
             if not self.fresh:
-                self.opt.advance(self.params)                 # host bookkeeping of the step the graph just took
+                self.opt.advance(self.stepped)                # host bookkeeping of the step the graph just took
             self.fresh = False
         else:
             self.opt.step()
