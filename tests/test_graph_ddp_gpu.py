@@ -102,6 +102,9 @@ def _worker_rccl(rank, world, port, tmpdir):
         lg, sg, opt = _run(rank, world, graph=True)         # all-reduce + FusedAdam inside the graph
         t = torch.ones(1 << 20, device=DEV)
         dist.all_reduce(t)
+        objs = [None]
+        dist.all_gather_object(objs, {"rank": rank, "device": torch.cuda.current_device()})      # bench.py's per-rank device record
+        assert objs[0]["rank"] == 0
         torch.cuda.synchronize()
         ver = ".".join(str(v) for v in torch.cuda.nccl.version())
         torch.save({"le": le, "ls": ls, "lg": lg, "se": se, "ss": ss, "sg": sg, "rccl": ver, "sum": float(t.sum()),
