@@ -242,3 +242,66 @@ def test_gradsync_launches_buckets_in_index_order_whatever_autograd_finishes_fir
     """RCCL pairs collectives by issue order, so the buckets must go out in one fixed order on every rank even
     when backward completes them in another (module use order != registration order) or not at all (unused parameters)."""
     mp.spawn(_gradsync_order_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
+def _deferred_worker(rank, world, port, tmpdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from im2im_uq_amd.core.scripts.train import GradSync
+        g = torch.Generator().manual_seed(11)
+        x, y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+        lo, hi = (0, 5) if rank == 0 else (5, 8)
+        results = {}
+        for mode in ("hooks", "deferred"):
+            torch.manual_seed(5)
+            net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
+            sync = GradSync(net.parameters(), bucket_bytes=256)
+            for step in range(3):                              # step 0 learns the buckets' parameter counts in both modes
+                sync.zero_grad()
+                sync.deferred = mode == "deferred"
+                loss = torch.nn.functional.mse_loss(net(x[lo:hi]), y[lo:hi])
+                (loss * ((hi - lo) / 8)).backward()
+                if mode == "deferred":
+                    assert all(h is None for h in sync.launched) and sync.next_bucket == 0      # the hooks launched nothing
+                    sync.pack_all()                            # (the part a HIP graph holds)
+                    sync.deferred = False
+                    sync.reduce_all()                          # (the part issued after the replay)
+                else:
+                    sync.finish()
+                for p in net.parameters():
+                    assert p.grad.data_ptr() >= sync.flat.data_ptr()
+            results[mode] = sync.flat.clone()
+            assert sync.own_hook_ids() and len(sync.own_hook_ids()) == len(sync.params)
+        assert torch.equal(results["hooks"], results["deferred"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradsync_deferred_pack_then_reduce_equals_hook_driven_exchange(tmp_path):
+    """[r4] GraphedStep under data parallelism captures forward + backward + GradSync.pack_all() (hooks only count) and issues
+    reduce_all() after the replay: the flat gradient buffer is bit-identical to the hook-driven bucketed exchange."""
+    mp.spawn(_deferred_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
+def test_graphed_step_policy_helpers_on_cpu():
+    """GraphedStep.wanted / has_foreign_hooks / static_module are host logic: auto = single process and <= 2^18 label pixels, never
+    fp8, several ranks only when asked for; hooks on a module or a parameter (wandb.watch) keep auto mode eager."""
+    from im2im_uq_amd.core.scripts.train import GraphedStep
+    assert GraphedStep.wanted({}, 1 << 18, 1, "bf16") and not GraphedStep.wanted({}, (1 << 18) + 1, 1, "bf16")
+    assert not GraphedStep.wanted({}, 1024, 2, "bf16") and GraphedStep.wanted({"hip_graph": True}, 1 << 30, 8, "fp32")
+    assert not GraphedStep.wanted({"hip_graph": True}, 1024, 1, "fp8") and not GraphedStep.wanted({"hip_graph": "false"}, 1024, 1, "bf16")
+    net = torch.nn.Sequential(torch.nn.Conv2d(1, 4, 3), torch.nn.ReLU())
+    assert GraphedStep.static_module(net, {}) and not GraphedStep.has_foreign_hooks(net)
+    h = net[0].register_forward_pre_hook(lambda m, a: None)
+    assert GraphedStep.has_foreign_hooks(net) and not GraphedStep.static_module(net, {}) and GraphedStep.static_module(net, {"hip_graph": True})
+    h.remove()
+    h = net[0].weight.register_post_accumulate_grad_hook(lambda p: None)
+    assert GraphedStep.has_foreign_hooks(net)
+    h.remove()
+
+    class Mine(torch.nn.Module):                              # a user's own module: may branch in Python on its data
+        def forward(self, x):
+            return x
+    assert not GraphedStep.static_module(torch.nn.Sequential(net, Mine()), {})
