@@ -51,6 +51,7 @@ SIGNATURES = {
     "im2im_conv_fwd_split": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr,
                                     _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_conv_fwd_eval_pool": (_i32, [_ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
+    "im2im_conv_fwd_eval_tail": (_i32, [_ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_conv_wgrad_fp8": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_conv_splitk_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "im2im_conv_fwd_split_ws": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr,

@@ -7,6 +7,7 @@ written for any depth and base width: level i has base * 2**i channels, the deep
 upsampling is bilinear, every Up halves again except the last.  The defaults (depth=4, base=64) give the reference's
 network, module for module and state_dict key for key; BASELINE configs[0] ("2-level") is depth=2 and configs[3]
 ("deeper UNet", 1024x1024 tiles) is depth=5."""
+import torch
 import torch.nn as nn
 
 from ... import _pkg  # noqa: F401
@@ -43,9 +44,13 @@ class UNet(nn.Module):
         self.out = OutConv(base, self.n_channels_middle)
 
     def forward(self, x):
+        if not self.training and not torch.is_grad_enabled():
+            # inference: the last block hands OutConv's 1x1 to its own conv epilogue when it can (nn_ops.conv_bn_relu_eval tail=)
+            h = self.features(x, tail=self.out.conv)
+            return h if getattr(h, "_im2im_tail_done", False) else self.out(h)
         return self.out(self.features(x))
 
-    def features(self, x):
+    def features(self, x, tail=None):
         """everything but the final 1x1 OutConv: the last Up block's activation."""
         # lazy=True: between these blocks activations stay "pre-BatchNorm + (scale, shift)"; every consumer below is one
         # of this package's kernels and applies BatchNorm+ReLU on the fly (see DoubleConv.forward).
@@ -60,5 +65,5 @@ class UNet(nn.Module):
             skips.append(feat)
         h = getattr(self, f"down{depth}")(pooled, lazy=True, pooled=True)
         for k in range(1, depth + 1):                                  # up1(x5, x4) ... up4(., x1)  (:40-43)
-            h = getattr(self, f"up{k}")(h, skips[depth - k], lazy=True)
+            h = getattr(self, f"up{k}")(h, skips[depth - k], lazy=True, tail=tail if k == depth else None)
         return h

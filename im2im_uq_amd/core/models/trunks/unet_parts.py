@@ -49,8 +49,10 @@ class DoubleConv(nn.Module):
         )
         self.compute_dtype = None
 
-    def forward(self, x, lazy=False, x_hi=None, pool=False):
-        """x_hi: second half of the input channels when the caller did not concatenate them (Up.forward).
+    def forward(self, x, lazy=False, x_hi=None, pool=False, tail=None):
+        """tail (eval mode only): the 1x1 nn.Conv2d that is the ONLY consumer of this block's result (UNet's OutConv); when the
+        fused kernel applies, the returned tensor already is that convolution's output (tagged `_im2im_tail_done`).
+        x_hi: second half of the input channels when the caller did not concatenate them (Up.forward).
         pool=True: return (result, MaxPool2d(2)(result)) -- for a skip-connection block whose output also feeds the next
         Down block; in training the pooling's backward is then folded into this block's BatchNorm backward.
         lazy=True (used between this package's own blocks): in training the result is a *lazy activation* -- it
@@ -75,7 +77,8 @@ class DoubleConv(nn.Module):
             else:
                 needs_graph = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad or bn.weight.requires_grad)
                 x = nn_ops.conv_bn_relu_eval(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
-                                             bn.running_var, bn.eps, cdt, owner=conv, x_hi=x_hi, pool=(pool and ci == 3 and not needs_graph))
+                                             bn.running_var, bn.eps, cdt, owner=conv, x_hi=x_hi, pool=(pool and ci == 3 and not needs_graph),
+                                             tail=(tail if (ci == 3 and not needs_graph and not pool) else None))
                 if needs_graph:
                     # the fused eval kernel has no backward: the forward works as in the reference, but the result is tied
                     # to its inputs by a node that raises if anyone back-propagates through it (instead of silently
@@ -130,7 +133,7 @@ class Up(nn.Module):
             self.conv = DoubleConv(in_channels, out_channels, norm=norm)
         self.compute_dtype = None
 
-    def forward(self, x1, x2, lazy=False):
+    def forward(self, x1, x2, lazy=False, tail=None):
         # x1: deep feature map, x2: skip connection.  cat([x2, pad(up(x1))]) is not materialised: the first conv reads the
         # skip half in place and the upsampled half from its own tensor (odd widths fall back to one fused
         # upsample + pad + concat kernel).
@@ -141,13 +144,13 @@ class Up(nn.Module):
             if dy or dx:
                 x1 = torch.nn.functional.pad(x1, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
             if nn_ops.SPLIT_CONCAT and x1.shape[1] == x2.shape[1] and x2.shape[1] % 64 == 0:
-                return self.conv(x2, lazy=lazy, x_hi=x1)
-            return self.conv(torch.cat([nn_ops.materialize(x2), x1], dim=1), lazy=lazy)
+                return self.conv(x2, lazy=lazy, x_hi=x1, tail=tail)
+            return self.conv(torch.cat([nn_ops.materialize(x2), x1], dim=1), lazy=lazy, tail=tail)
         if nn_ops.can_split_concat(x1, x2):
             up = nn_ops.Upsample2x.apply(x1, x2.shape[2], x2.shape[3])
-            return self.conv(x2, lazy=lazy, x_hi=up)
+            return self.conv(x2, lazy=lazy, x_hi=up, tail=tail)
         x = nn_ops.UpsampleConcat.apply(x1, x2)
-        return self.conv(x, lazy=lazy)
+        return self.conv(x, lazy=lazy, tail=tail)
 
 
 class OutConv(nn.Module):

@@ -41,6 +41,11 @@ struct ConvArgs {
   int64_t kws_bytes;    // size of the caller's workspace behind kpartial
   // EPI 2 (eval): null, or [B][H/2][W/2][Co] T: MaxPool2d(2) of the stored result, taken from the epilogue's LDS tile (H, W even)
   void* pool_y;
+  // EPI 5 (eval, Co == 64): the block's result is consumed ONLY by a 1x1 conv (OutConv, unet_parts.py:87-94): fuse_w [C1][64] T
+  // (im2im_pack_conv_weight's wf for taps = 1), fuse_bias [C1] fp32 | null, fuse_y [B][H][W][C1] T; y itself is not written
+  const void* fuse_w;
+  const float* fuse_bias;
+  void* fuse_y;
 };
 
 // Packed bf16 3x3 weights are FRAGMENT-MAJOR: the 32 rows x 16 reduction channels one lane-set of v_mfma_f32_32x32x16_bf16

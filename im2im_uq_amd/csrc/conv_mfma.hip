@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, (igemm_wgs_per_cu<T, TB * TH * TW / (32 * WM) 
       const int n = n0 + nl;
       const float bias_v = (a.bias ? a.bias[n] : 0.f) - (a.center ? a.center[n] : 0.f);
       float sc = 1.f, sh = 0.f;
-      if constexpr (EPI == 2) { sc = a.scale[n]; sh = a.shift[n]; }
+      if constexpr (EPI == 2 || EPI == 5) { sc = a.scale[n]; sh = a.shift[n]; }
       float s = 0.f, sq = 0.f;
       const float K = to_float(from_float<T>(acc[0][nt][0] + bias_v));
 #pragma unroll
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256, (igemm_wgs_per_cu<T, TB * TH * TW / (32 * WM) 
         for (int r = 0; r < 16; ++r) {
           const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
           float v = acc[mt][nt][r] + bias_v;
-          if constexpr (EPI == 2) {
+          if constexpr (EPI == 2 || EPI == 5) {
             v = v * sc + sh;
             if (a.relu) v = fmaxf(v, 0.f);
           }
@@ -501,6 +501,55 @@ __global__ __launch_bounds__(256, (igemm_wgs_per_cu<T, TB * TH * TW / (32 * WM) 
     }
   };
   if (want_stats && tile_full) convert_tile(std::true_type{}); else convert_tile(std::false_type{});
+  if constexpr (EPI == 5) {
+    // [r4] eval mode, last block of the trunk: its 64-channel result is consumed by OutConv's 1x1 convolution only
+    // (unet.py:45-46).  The wave holds all 64 channels of its pixels in its LDS tile (rounded to the storage type, as the
+    // separate kernel would read them back): the 1x1 conv is 4 k-steps of MFMAs per 32 pixels from that tile, in the order
+    // conv_igemm<taps = 1> takes them (two 32-channel chunks), + bias, one rounding -- same bits -- and only the C1-channel
+    // feature map reaches HBM: the 64-channel tensor is neither written nor read back, and the 1x1 launch disappears.
+    static_assert(EPI != 5 || (NT == 2 && WN == 1), "the wave owns all 64 output channels");
+    constexpr int C1 = 32;
+    const char* w1 = reinterpret_cast<const char*>(a.fuse_w) + (size_t)l31 * 64 * sizeof(T);
+    f32x16 acc2[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int ks = 0; ks < Frag<T>::KSTEPS; ++ks) {
+        const typename Frag<T>::AB fb = Frag<T>::load(w1 + c * 32 * (int)sizeof(T), ks, half);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const typename Frag<T>::AB fa = Frag<T>::load(wbuf + (mt * 32 + l31) * WP + c * 32 * (int)sizeof(T), ks, half);
+          acc2[mt] = Frag<T>::mfma(fa, fb, acc2[mt]);
+        }
+      }
+    // every fragment read above has returned before the MFMA that used it; LDS operations of one wave complete in issue order, so
+    // the same region can take the C1-channel tile now: [pixel][C1], pitch + 16 B
+    constexpr int WP2 = C1 * (int)sizeof(T) + 16;
+    const float b1 = a.fuse_bias ? a.fuse_bias[l31] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        *reinterpret_cast<T*>(wbuf + row * WP2 + l31 * (int)sizeof(T)) = from_float<T>(acc2[mt][r] + b1);
+      }
+    constexpr int EPR2 = C1 / EPP, RPP2 = 64 / EPR2;
+    T* __restrict__ fy = reinterpret_cast<T*>(a.fuse_y);
+#pragma unroll
+    for (int pass = 0; pass < WROWS / RPP2; ++pass) {
+      const int row = pass * RPP2 + lane / EPR2, piece = lane % EPR2;
+      const uint4 v = *reinterpret_cast<const uint4*>(wbuf + row * WP2 + piece * 16);
+      const int m = wm * WROWS + row;
+      const int bb = b0 + m / MI, yy = y0 + (m % MI) / TW, xx = x0 + m % TW;
+      if (bb < a.B && yy < a.H && xx < a.W)
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(fy + (((size_t)bb * a.H + yy) * a.W + xx) * C1 + piece * EPP));
+    }
+    return;
+  }
   // wave-private region: LDS operations of one wave complete in issue order, no barrier needed
   float bsc[EPP], bsh[EPP], bmu[EPP], bis[EPP], bs1[EPP], bs2[EPP];      // EPI 3: this lane's EPP channels (fixed over the passes)
   if constexpr (EPI == 3) {
@@ -734,6 +783,10 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
   if constexpr (TAPS == 9 && TB >= 2 && BN >= 64) {
     if (a.ksplit > 1) return launch_conv_epi<T, TB, TH, TW, BN, WM, WN, TAPS, 4>(a, stream);
   }
+  if constexpr (TAPS == 9 && BN == 64 && WN == 1) {
+    if (a.fuse_y) return launch_conv_epi<T, TB, TH, TW, BN, WM, WN, TAPS, 5>(a, stream);
+  }
+  if (a.fuse_y) return fail_invalid("fused 1x1 tail: 64 output channels only");
   if (a.bn_partial) return launch_conv_epi<T, TB, TH, TW, BN, WM, WN, TAPS, 3>(a, stream);
   if (a.stats) return launch_conv_epi<T, TB, TH, TW, BN, WM, WN, TAPS, 1>(a, stream);
   if (a.scale) return launch_conv_epi<T, TB, TH, TW, BN, WM, WN, TAPS, 2>(a, stream);
@@ -790,7 +843,8 @@ int conv_fwd_impl(const void* x, const float* in_scale_shift, int in_ss_img, boo
                   const float* in_scale_shift_hi, int32_t Ci_lo, const void* w, const float* bias, const float* center,
                   const float* scale, const float* shift, void* y, void* y_hi, int32_t Co_lo, float* stats, int32_t B, int32_t H,
                   int32_t W, int32_t Ci, int32_t Co, int32_t taps, int32_t relu, int32_t dtype, im2im_stream_t stream_,
-                  void* ws = nullptr, int64_t ws_bytes = 0, void* pool_y = nullptr);
+                  void* ws = nullptr, int64_t ws_bytes = 0, void* pool_y = nullptr, const void* fuse_w = nullptr,
+                  const float* fuse_bias = nullptr, void* fuse_y = nullptr);
 }
 
 extern "C" int im2im_conv_fwd_per_image(const void* x, const float* in_scale_shift_per_image, const void* w, const float* bias,
@@ -831,6 +885,14 @@ extern "C" int im2im_conv_fwd_eval_pool(const void* x, const void* x_hi, int32_t
                        Ci, Co, 9, 1, dtype, stream_, nullptr, 0, pool_y);
 }
 
+extern "C" int im2im_conv_fwd_eval_tail(const void* x, const void* x_hi, int32_t Ci_lo, const void* w, const float* scale,
+                                        const float* shift, const void* w1, const float* b1, void* f_out, int32_t B, int32_t H,
+                                        int32_t W, int32_t Ci, int32_t C1, int32_t dtype, im2im_stream_t stream_) {
+  IM2IM_REQUIRE(w1 && f_out && C1 == 32);
+  return conv_fwd_impl(x, nullptr, 0, false, x_hi, nullptr, Ci_lo, w, nullptr, nullptr, scale, shift, nullptr, nullptr, 64, nullptr, B, H, W,
+                       Ci, 64, 9, 1, dtype, stream_, nullptr, 0, nullptr, w1, b1, f_out);
+}
+
 namespace im2im { void set_conv_splitk(int v) { g_conv_splitk = v; } }
 
 namespace {
@@ -838,9 +900,9 @@ int conv_fwd_impl(const void* x, const float* in_scale_shift, int in_ss_img, boo
                   const float* in_scale_shift_hi, int32_t Ci_lo, const void* w, const float* bias, const float* center,
                   const float* scale, const float* shift, void* y, void* y_hi, int32_t Co_lo, float* stats, int32_t B, int32_t H,
                   int32_t W, int32_t Ci, int32_t Co, int32_t taps, int32_t relu, int32_t dtype, im2im_stream_t stream_,
-                  void* ws, int64_t ws_bytes, void* pool_y) {
+                  void* ws, int64_t ws_bytes, void* pool_y, const void* fuse_w, const float* fuse_bias, void* fuse_y) {
   hipStream_t stream = (hipStream_t)stream_;
-  IM2IM_REQUIRE(x && w && y);
+  IM2IM_REQUIRE(x && w && (y || fuse_y));
   if (x_hi) {
     IM2IM_REQUIRE(Ci_lo > 0 && Ci_lo % 32 == 0 && Ci == 2 * Ci_lo);   // both sources share one pixel stride
   } else {
@@ -864,7 +926,8 @@ int conv_fwd_impl(const void* x, const float* in_scale_shift, int in_ss_img, boo
   IM2IM_REQUIRE(in_ss_img == 0 || (per_image && x_hi == nullptr));   // per-image coefficients need one image per tile
   ConvArgs a{x, w, bias, scale, shift, y, stats, B, H, W, Ci, Co, 0, 0, relu, center, in_scale_shift,
              x_hi, in_scale_shift_hi, Ci_lo, y_hi, Co_lo, nullptr, nullptr, nullptr, nullptr, in_ss_img,
-             1, 0, reinterpret_cast<float*>(ws), ws ? ws_bytes : 0, pool_y};
+             1, 0, reinterpret_cast<float*>(ws), ws ? ws_bytes : 0, pool_y, fuse_w, fuse_bias, fuse_y};
+  if (fuse_y) IM2IM_REQUIRE(fuse_w && scale && relu && Co == 64 && taps == 9 && y_hi == nullptr && !per_image && pool_y == nullptr);
   if (pool_y) IM2IM_REQUIRE(scale && relu && y_hi == nullptr && H % 2 == 0 && W % 2 == 0 && !per_image);
   if (dtype == IM2IM_BF16) return taps == 9 ? dispatch_conv<bf16_t, 9>(a, stream, per_image) : dispatch_conv<bf16_t, 1>(a, stream, per_image);
   return taps == 9 ? dispatch_conv<float, 9>(a, stream, per_image) : dispatch_conv<float, 1>(a, stream, per_image);
@@ -882,7 +945,7 @@ extern "C" int im2im_conv_dgrad_bn(const void* dz, const void* wd, void* dx, con
   IM2IM_REQUIRE(taps == 9 || taps == 1);
   IM2IM_REQUIRE(dtype == IM2IM_F32 || dtype == IM2IM_BF16);
   ConvArgs a{dz, wd, nullptr, nullptr, nullptr, dx, nullptr, B, H, W, Ci, Co, 0, 0, 0, nullptr, nullptr,
-             nullptr, nullptr, Ci, nullptr, Co, bn_z, bn_scale_shift, bn_mean_invstd, bn_partial, 0, 1, 0, nullptr, 0, nullptr};
+             nullptr, nullptr, Ci, nullptr, Co, bn_z, bn_scale_shift, bn_mean_invstd, bn_partial, 0, 1, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
   if (dtype == IM2IM_BF16) return taps == 9 ? dispatch_conv<bf16_t, 9>(a, stream) : dispatch_conv<bf16_t, 1>(a, stream);
   return taps == 9 ? dispatch_conv<float, 9>(a, stream) : dispatch_conv<float, 1>(a, stream);
 }

@@ -1031,10 +1031,16 @@ def conv_bn_relu_train(x, weight, bias, gamma, beta, running_mean, running_var, 
 _EVAL_CACHE = weakref.WeakKeyDictionary()      # conv module -> (key, packed operands): see conv_bn_relu_eval
 
 
-def conv_bn_relu_eval(x, weight, bias, gamma, beta, running_mean, running_var, eps, cdt, owner=None, x_hi=None, pool=False):
+FUSE_EVAL_OUTCONV = os.environ.get("IM2IM_FUSE_EVAL_OUTCONV", "1") != "0"    # [r4] eval: OutConv's 1x1 in the last block's conv epilogue
+
+
+def conv_bn_relu_eval(x, weight, bias, gamma, beta, running_mean, running_var, eps, cdt, owner=None, x_hi=None, pool=False, tail=None):
     """eval mode: BatchNorm folded into the conv epilogue (one kernel, no intermediate).
     pool=True [r4]: also return MaxPool2d(2) of the result -> (a, pooled), taken from the epilogue's LDS tile when the extent is
     even and the conv runs on the bf16 / fp32 MFMA kernel (otherwise the caller pools separately: a plain tensor is returned).
+    tail=<OutConv's nn.Conv2d> [r4]: the block's result is consumed only by that 1x1 convolution (64 -> 32): return
+    conv1x1(result) computed on the epilogue's LDS tile (same bits as Conv1x1 on the stored result; the 64-channel tensor never
+    reaches HBM), tagged `_im2im_tail_done`; when the shapes are not the fused kernel's the plain result comes back untagged.
 
     owner (the conv module): the folded coefficients and the packed weight are kept for it and reused while none of the
     six tensors changed (storage and version counter) -- calibration and validation run hundreds of forwards over the
@@ -1065,6 +1071,25 @@ def conv_bn_relu_eval(x, weight, bias, gamma, beta, running_mean, running_var, e
     if fp8:
         return nchw(conv_fwd_fp8(xin, packed[0], packed[1], None, fold, relu=True, x_hi=xin_hi))
     b, h, w_, cin = xin.shape
+    if (tail is not None and FUSE_EVAL_OUTCONV and not torch.is_grad_enabled() and co == 64 and tuple(tail.weight.shape) == (32, 64, 1, 1)
+            and tail.weight.is_cuda):
+        tkey = (cdt,) + tuple(v for t in (tail.weight, tail.bias) for v in (t.data_ptr(), t._version))
+        thit = _EVAL_CACHE.get(tail)
+        if thit is not None and thit[0] == tkey:
+            w1, b1 = thit[1]
+        else:
+            w1 = pack_weight(tail.weight, cdt, want_wd=False)[0]              # [32][1][64]
+            b1 = tail.bias.detach().to(F32).contiguous()
+            _EVAL_CACHE[tail] = (tkey, (w1, b1))
+        f = torch.empty((b, h, w_, 32), dtype=cdt, device=xin.device)
+        ev = TIMER.wrap(_tile_name("igemm", h, w_, co, 9, cdt), 2.0 * b * h * w_ * co * ci * 9, xin.device) if TIMER else None
+        check(lib.im2im_conv_fwd_eval_tail(dptr(xin), dptr(xin_hi), cin, dptr(packed), dptr(fold[0]), dptr(fold[1]), dptr(w1), dptr(b1), dptr(f),
+                                           b, h, w_, ci, 32, _DT[cdt], stream_ptr(xin.device)), "im2im_conv_fwd_eval_tail")
+        if ev is not None:
+            ev.record(torch.cuda.current_stream(xin.device))
+        out = nchw(f)
+        out._im2im_tail_done = True
+        return out
     if pool and not torch.is_grad_enabled() and h % 2 == 0 and w_ % 2 == 0 and h >= 2 and w_ >= 2:
         y = torch.empty((b, h, w_, co), dtype=cdt, device=xin.device)
         pooled = torch.empty((b, h // 2, w_ // 2, co), dtype=cdt, device=xin.device)

@@ -212,6 +212,15 @@ int im2im_conv_fwd_eval_pool(const void* x, const void* x_hi, int32_t Ci_lo, con
                              const float* shift, void* y, void* pool_y, int32_t B, int32_t H, int32_t W, int32_t Ci,
                              int32_t Co, int32_t dtype, im2im_stream_t stream);
 
+/* [r4] Eval-mode LAST block of the trunk: conv3x3 (Ci -> 64) + folded BatchNorm + ReLU whose result is consumed only by OutConv's
+ * 1x1 convolution (unet.py:45-46, unet_parts.py:87-94) -- f_out [B][H][W][C1] = conv1x1(relu(affine(conv3x3(x))), w1) + b1, the
+ * 1x1 evaluated on the epilogue's LDS tile in the order im2im_conv_fwd(taps = 1) takes it (same bits as the two kernels); the
+ * 64-channel tensor is neither written nor read back.  w1 [C1][64] = im2im_pack_conv_weight's wf of the 1x1 weights, b1 [C1]|NULL,
+ * C1 == 32 (the reference trunk's n_channels_middle); x_hi / Ci_lo as in im2im_conv_fwd_split. */
+int im2im_conv_fwd_eval_tail(const void* x, const void* x_hi, int32_t Ci_lo, const void* wf, const float* scale,
+                             const float* shift, const void* w1, const float* b1, void* f_out, int32_t B, int32_t H,
+                             int32_t W, int32_t Ci, int32_t C1, int32_t dtype, im2im_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * fp8 forward convolution (BASELINE configs[4] "fp8 MFMA conv path"): 3x3 pad-1 conv whose operands are OCP e4m3 on
  * v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64, ~2x the bf16 MFMA rate), fp32 accumulate, bf16 in/out.  Same contract as

@@ -215,3 +215,42 @@ def test_eval_conv_with_fused_maxpool_equals_conv_then_maxpool(dt):
         assert torch.equal(fused, plain)
     finally:
         nn_ops.set_compute_dtype("bf16")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp32"])
+def test_eval_last_block_with_fused_outconv_equals_the_two_kernels(dt):
+    """[r4] im2im_conv_fwd_eval_tail: in inference the trunk's last conv (-> 64 channels) evaluates OutConv's 1x1 (unet_parts.py:87-94)
+    on its epilogue tile; the model output is bit-identical to the path with the separate 1x1 kernel, for the 32x16, 16x16 and
+    8x8-patch tile families, depth 2 and 4."""
+    from im2im_uq_amd import nn_ops
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from im2im_uq_amd.core.models.trunks.unet import UNet
+    nn_ops.set_compute_dtype(dt)
+    params = dict(uncertainty_type="quantiles", q_lo=0.05, q_hi=0.95, q_lo_weight=1, q_hi_weight=1, mse_weight=1)
+    was = nn_ops.FUSE_EVAL_OUTCONV
+    try:
+        for depth, shape in ((4, (3, 1, 96, 80)), (2, (2, 1, 64, 128)), (2, (5, 1, 40, 24)), (4, (1, 2, 160, 176))):
+            torch.manual_seed(depth)
+            model = add_uncertainty(UNet(shape[1], 1, depth=depth), dict(params)).to(DEV)
+            with torch.no_grad():
+                model.train()
+                model(torch.randn(2, shape[1], 64, 64, device=DEV))
+                model.eval()
+                x = torch.randn(*shape, device=DEV)
+                calls = []
+                real = nn_ops.Conv1x1.apply
+                nn_ops.FUSE_EVAL_OUTCONV = True
+                fused = model(x)
+                feat = model.baseModel(x)
+                assert getattr(feat, "_im2im_tail_done", False), shape         # the fused kernel took it
+                nn_ops.FUSE_EVAL_OUTCONV = False
+                plain = model(x)
+                assert not getattr(model.baseModel(x), "_im2im_tail_done", False)
+            assert torch.equal(fused, plain), shape
+            # grad-enabled eval and train mode never take the fused path
+            model.train()
+            nn_ops.FUSE_EVAL_OUTCONV = True
+            assert not getattr(model.baseModel(x), "_im2im_tail_done", False)
+    finally:
+        nn_ops.FUSE_EVAL_OUTCONV = was
+        nn_ops.set_compute_dtype("bf16")
