@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void smallconv_s2l_kernel(S2LArgs a) {
       T* o = outb + ((size_t)yy * a.W + xx) * CL;
       constexpr int N = Vec16<T>::N;
 #pragma unroll
-      for (int k = 0; k < 8; k += N) Vec16<T>::store(o + k, acc + k);
+      for (int k = 0; k < 8; k += N) Vec16<T>::store_nt(o + k, acc + k);      // streamed: 1 GB per 78 images, not read again by this kernel
       // statistics relative to this thread's first valid value (no cancellation when forming M2 below)
       if (cnt == 0.f) {
 #pragma unroll
