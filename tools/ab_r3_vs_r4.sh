@@ -1,6 +1,8 @@
 #!/bin/bash
 # same-box comparison of the round-3 tree (_r3_tree/, git archive of 88a67d2 built in place) and this tree: default train leg and
 # the batch-10 leg, interleaved.   tools/ab_r3_vs_r4.sh <tag>  ->  gpurun_out/<tag>_r3_vs_r4.txt
+# prepare first:  mkdir _r3_tree && git archive 88a67d2 | tar -x -C _r3_tree && (cd _r3_tree && python -m im2im_uq_amd.build)
+# (the directory is scratch: delete it afterwards, it is not part of the tree)
 tag=${1:-ab}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/${tag}_r3_vs_r4.txt
