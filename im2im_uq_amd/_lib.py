@@ -60,6 +60,7 @@ SIGNATURES = {
     "im2im_pack_conv_weight_fp8": (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr, _ptr]),
     # x, in_ss, x_hi, in_ss_hi, Ci_lo, wq, wscale, bias, scale, shift, y, stats, B, H, W, Ci, Co, relu, stream
     "im2im_pack_conv_weight_fp8_dgrad": (_i32, [_ptr, _i32, _i32, _i32, _ptr, _ptr, _ptr]),
+    "im2im_pack_conv_weights_fp8_multi": (_i32, [_i32, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr]),
     # dz, wq_d, wscale_d, dx, dx_hi, Cx_lo, amax_prev, amax_now, amax_next, B, H, W, Cz, Cx, stream
     "im2im_conv_dgrad_fp8": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_conv_fwd_fp8": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32,

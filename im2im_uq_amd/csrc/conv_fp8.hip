@@ -25,7 +25,9 @@
 // output (= the layer's input) channel; both scales are undone in the epilogue.  The weight gradient stays bf16.
 #include "common.h"
 #include "dtypes.h"
+#include <algorithm>
 #include <type_traits>
+#include <vector>
 
 namespace {
 using namespace im2im;
@@ -502,11 +504,10 @@ __global__ __launch_bounds__(256, 2) void conv_fp8_kernel(Fp8ConvArgs a) {
   }
 }
 
-// w [Co][Ci][9] fp32 -> wq [Co][9][Ci] e4m3 with one power-of-two scale per output channel: max |w| -> (128, 256]
-__global__ __launch_bounds__(256) void pack_weight_fp8_kernel(const float* __restrict__ w, int Ci, int taps,
-                                                               unsigned char* __restrict__ wq, float* __restrict__ wscale) {
-  __shared__ float s_max[256];
-  const int co = blockIdx.x;
+// w [Co][Ci][9] fp32 -> wq [Co][9][Ci] e4m3 with one power-of-two scale per output channel: max |w| -> (128, 256].  One block per
+// output channel `co` of a [Co][Ci][taps] tensor.
+__device__ __forceinline__ void pack_fp8_channel(const float* __restrict__ w, int Co, int Ci, int taps, int co,
+                                                 unsigned char* __restrict__ wq, float* __restrict__ wscale, float* s_max) {
   const int per = Ci * taps;
   const float* wc = w + (size_t)co * per;
   float m = 0.f;
@@ -527,17 +528,20 @@ __global__ __launch_bounds__(256) void pack_weight_fp8_kernel(const float* __res
     const int ci = i / taps, tp = i % taps;                  // source index (ci, tap)
     const float v = fminf(fmaxf(wc[i] * inv, -FP8_MAX), FP8_MAX);
     const int q = __builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false);
-    if (taps == 9 && Ci % 64 == 0 && gridDim.x % 32 == 0) wq[wfrag8_index(co, tp, ci, Ci)] = (unsigned char)(q & 0xff);   // fragment-major
+    if (taps == 9 && Ci % 64 == 0 && Co % 32 == 0) wq[wfrag8_index(co, tp, ci, Ci)] = (unsigned char)(q & 0xff);   // fragment-major
     else wq[((size_t)co * taps + tp) * Ci + ci] = (unsigned char)(q & 0xff);
   }
+}
+__global__ __launch_bounds__(256) void pack_weight_fp8_kernel(const float* __restrict__ w, int Ci, int taps,
+                                                               unsigned char* __restrict__ wq, float* __restrict__ wscale) {
+  __shared__ float s_max[256];
+  pack_fp8_channel(w, (int)gridDim.x, Ci, taps, blockIdx.x, wq, wscale, s_max);
 }
 
 // data-gradient operand: w [Co][Ci][9] fp32 -> wq [Ci][9 taps, reversed][Co] e4m3 with one power-of-two scale per INPUT channel
 // (the data-gradient's output channel): block = one ci
-__global__ __launch_bounds__(256) void pack_weight_fp8_dgrad_kernel(const float* __restrict__ w, int Co, int Ci, int taps,
-                                                                     unsigned char* __restrict__ wq, float* __restrict__ wscale) {
-  __shared__ float s_max[256];
-  const int ci = blockIdx.x;
+__device__ __forceinline__ void pack_fp8_dgrad_channel(const float* __restrict__ w, int Co, int Ci, int taps, int ci,
+                                                       unsigned char* __restrict__ wq, float* __restrict__ wscale, float* s_max) {
   const int per = Co * taps;
   float m = 0.f;
   for (int i = threadIdx.x; i < per; i += 256) { const int co = i / taps, tp = i % taps; m = fmaxf(m, fabsf(w[((size_t)co * Ci + ci) * taps + tp])); }
@@ -559,6 +563,138 @@ __global__ __launch_bounds__(256) void pack_weight_fp8_dgrad_kernel(const float*
     const int q = __builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false);
     if (taps == 9 && Co % 64 == 0 && Ci % 32 == 0) wq[wfrag8_index(ci, taps - 1 - tp, co, Co)] = (unsigned char)(q & 0xff);
     else wq[((size_t)ci * taps + (taps - 1 - tp)) * Co + co] = (unsigned char)(q & 0xff);
+  }
+}
+__global__ __launch_bounds__(256) void pack_weight_fp8_dgrad_kernel(const float* __restrict__ w, int Co, int Ci, int taps,
+                                                                     unsigned char* __restrict__ wq, float* __restrict__ wscale) {
+  __shared__ float s_max[256];
+  pack_fp8_dgrad_channel(w, Co, Ci, taps, blockIdx.x, wq, wscale, s_max);
+}
+
+// [r4] every fp8 operand of a model in ONE launch per kind (forward / data-gradient): the 17 + 14 per-layer pack launches of an
+// fp8-mode training step were 0.46 ms of a 20 ms step.  Block = one channel of one tensor, found through the prefix table.
+constexpr int FP8_PACK_MAX = 32;
+struct Fp8PackMultiArgs {
+  const float* w[FP8_PACK_MAX]; unsigned char* wq[FP8_PACK_MAX]; float* ws[FP8_PACK_MAX];
+  int Co[FP8_PACK_MAX], Ci[FP8_PACK_MAX];
+  int start[FP8_PACK_MAX + 1];       // prefix sums of the tensors' channel counts (Co forward, Ci data-gradient)
+  int n;
+};
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void pack_weight_fp8_multi_kernel(Fp8PackMultiArgs a) {
+  __shared__ float s_max[256];
+  int t = 0;
+  while (t + 1 < a.n && (int)blockIdx.x >= a.start[t + 1]) ++t;
+  const int c = blockIdx.x - a.start[t];
+  if constexpr (DGRAD) pack_fp8_dgrad_channel(a.w[t], a.Co[t], a.Ci[t], 9, c, a.wq[t], a.ws[t], s_max);
+  else pack_fp8_channel(a.w[t], a.Co[t], a.Ci[t], 9, c, a.wq[t], a.ws[t], s_max);
+}
+
+// Tiled form for the fragment-major operands (N % 32 == 0, K % 64 == 0: every fp8 layer of the UNet), two launches per kind.
+// PHASE 1, block = 8 (forward) / 16 (data-gradient) rows of one tensor: streams them once with coalesced float4 loads -> their scales.
+// PHASE 2, block = (32-row block, 64-k chunk): re-reads (L2 / Infinity Cache) a [32 rows][64 k][9 taps] tile through LDS and writes
+// every fragment part as 16-byte pieces of a contiguous 1 KiB run; `start` counts tiles (N / 32 * K / 64 per tensor).  The per-channel kernels above store single scattered bytes (and the data-gradient one gathers 36-byte runs): 0.18 +
+// 0.28 ms per fp8-mode step on 31 M weights; same arithmetic per element, so the bytes and scales are identical.
+//   element (n, tap, k) of the operand = w[n * sn + k * sk + tap]: forward n = co, k = ci (sn = 9 Ci, sk = 9), data-gradient
+//   n = ci, k = co (sn = 9, sk = 9 Ci), taps reversed on output.
+template <bool DGRAD, int PHASE>
+__global__ __launch_bounds__(DGRAD ? 576 : 512) void pack_weight_fp8_tiled_kernel(Fp8PackMultiArgs a) {
+  constexpr int NT = DGRAD ? 576 : 512;
+  constexpr int PITCH = DGRAD ? 289 : 577;            // odd pitches: the gathers below are bank-conflict free
+  extern __shared__ float tile[];                      // forward [32 n][577], data-gradient [64 k][289]
+  __shared__ __attribute__((aligned(16))) float s_amax[PHASE == 1 && DGRAD ? 16 * 144 : 4];
+  __shared__ float s_inv[32];
+  int t = 0;
+  while (t + 1 < a.n && (int)blockIdx.x >= a.start[t + 1]) ++t;
+  const int Co = a.Co[t], Ci = a.Ci[t];
+  const int K = DGRAD ? Co : Ci;
+  const int rb = PHASE == 1 ? blockIdx.x - a.start[t] : (blockIdx.x - a.start[t]) / (K >> 6);
+  const float* __restrict__ w = a.w[t];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = rb * 32;
+  // ---- phase 1: |w| maxima of the 32 rows -> scales
+  if constexpr (PHASE == 1) {
+    // block = P1_ROWS rows of one tensor (`start` counts those): forward 8 rows, one wave per (contiguous) row; data-gradient 16 rows
+    // (input channels): per co their 144 values are contiguous -> thread = (float4 of the run, co mod 16)
+    if constexpr (!DGRAD) {
+      const int per4 = Ci * 9 / 4;
+      const float4* row = reinterpret_cast<const float4*>(w + (size_t)(rb * 8 + wave) * Ci * 9);
+      float m = 0.f;
+#pragma unroll 4
+      for (int i = lane; i < per4; i += 64) {
+        const float4 v = row[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+      if (lane == 0) {
+        int e = 0;
+        if (m > 0.f) { frexpf(m, &e); }
+        a.ws[t][rb * 8 + wave] = m > 0.f ? ldexpf(1.f, e - 8) : 1.f;
+      }
+    } else {
+      float4* s_part = reinterpret_cast<float4*>(s_amax);      // [16 co groups][36 float4]
+      const int pos = tid % 36, grp = tid / 36;
+      const float4* base = reinterpret_cast<const float4*>(w + (size_t)rb * 16 * 9) + pos;
+      const size_t stride4 = (size_t)Ci * 9 / 4;
+      float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+      for (int co = grp; co < Co; co += 16) {
+        const float4 v = base[(size_t)co * stride4];
+        m.x = fmaxf(m.x, fabsf(v.x)); m.y = fmaxf(m.y, fabsf(v.y)); m.z = fmaxf(m.z, fabsf(v.z)); m.w = fmaxf(m.w, fabsf(v.w));
+      }
+      s_part[grp * 36 + pos] = m;
+      __syncthreads();
+      if (tid < 16) {
+        float r = 0.f;
+        for (int g = 0; g < 16; ++g)
+          for (int j = 0; j < 9; ++j) r = fmaxf(r, s_amax[g * 144 + tid * 9 + j]);
+        int e = 0;
+        if (r > 0.f) { frexpf(r, &e); }
+        a.ws[t][rb * 16 + tid] = r > 0.f ? ldexpf(1.f, e - 8) : 1.f;
+      }
+    }
+  } else {
+    // ---- phase 2: one 64-k tile through LDS -> fragment parts
+    if (tid < 32) s_inv[tid] = 1.f / a.ws[t][n0 + tid];
+    unsigned char* out = a.wq[t] + (size_t)rb * 9 * (K >> 6) * 2048;
+    const int chunk = (blockIdx.x - a.start[t]) % (K >> 6);
+    const int k0 = chunk * 64;
+    for (int i = tid; i < 4608; i += NT) {             // 4608 float4 = 32 x 64 x 9 floats
+      if constexpr (!DGRAD) {
+        const int r = i / 144, c = (i % 144) * 4;      // row r: 576 contiguous floats (64 ci x 9 taps)
+        const float4 v = *reinterpret_cast<const float4*>(w + ((size_t)(n0 + r) * Ci + k0) * 9 + c);
+        float* d = tile + r * PITCH + c;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      } else {
+        const int kk = i / 72, c = (i % 72) * 4;       // co = k0 + kk: 288 contiguous floats (32 ci x 9 taps)
+        const float4 v = *reinterpret_cast<const float4*>(w + ((size_t)(k0 + kk) * Ci + n0) * 9 + c);
+        float* d = tile + kk * PITCH + c;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    }
+    __syncthreads();
+    for (int piece = tid; piece < 9 * 128; piece += NT) {
+      const int tap = piece >> 7, part = (piece >> 6) & 1, l = piece & 63;
+      const int r = l & 31, kb = (l >> 5) * 32 + part * 16;        // 16 consecutive k of row r
+      const float inv = s_inv[r];
+      unsigned q[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int kk = kb + j * 4 + u;
+          const float x = DGRAD ? tile[kk * PITCH + r * 9 + tap] : tile[r * PITCH + kk * 9 + tap];
+          v[u] = fminf(fmaxf(x * inv, -FP8_MAX), FP8_MAX);
+        }
+        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+        q[j] = (unsigned)pk;
+      }
+      const int tap_out = DGRAD ? 8 - tap : tap;
+      *reinterpret_cast<uint4*>(out + ((size_t)(tap_out * (K >> 6) + chunk) * 2 + part) * 1024 + l * 16) = make_uint4(q[0], q[1], q[2], q[3]);
+    }
   }
 }
 
@@ -619,6 +755,64 @@ extern "C" int im2im_pack_conv_weight_fp8(const float* w, int32_t Co, int32_t Ci
   IM2IM_REQUIRE(w && wq && wscale && Co > 0 && Ci > 0 && taps > 0);
   hipLaunchKernelGGL(pack_weight_fp8_kernel, dim3((unsigned)Co), dim3(256), 0, stream, w, (int)Ci, (int)taps, (unsigned char*)wq, wscale);
   return im2im::check_launch("pack_weight_fp8_kernel");
+}
+
+extern "C" int im2im_pack_conv_weights_fp8_multi(int32_t n_tensors, const float* const* w, const int32_t* Co, const int32_t* Ci,
+                                                 void* const* wq, float* const* wscale, int32_t dgrad, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || (w && Co && Ci && wq && wscale)));
+  // fragment-major tensors (every fp8 layer of the UNet) -> tiled kernel, heaviest row blocks first; the rest -> block per channel
+  std::vector<int> tiled, plain;
+  for (int i = 0; i < n_tensors; ++i) {
+    IM2IM_REQUIRE(w[i] && wq[i] && wscale[i] && Co[i] > 0 && Ci[i] > 0);
+    const int N = dgrad ? Ci[i] : Co[i], K = dgrad ? Co[i] : Ci[i];
+    (N % 32 == 0 && K % 64 == 0 ? tiled : plain).push_back(i);
+  }
+  std::stable_sort(tiled.begin(), tiled.end(), [&](int x, int y) { return (dgrad ? Co[x] : Ci[x]) > (dgrad ? Co[y] : Ci[y]); });
+  for (int pass = 0; pass < 2; ++pass) {
+    const std::vector<int>& idx = pass == 0 ? tiled : plain;
+    for (size_t base = 0; base < idx.size(); base += FP8_PACK_MAX) {
+      Fp8PackMultiArgs a, a2;
+      a.n = (int)std::min<size_t>(FP8_PACK_MAX, idx.size() - base);
+      int blocks = 0, tiles = 0;
+      for (int i = 0; i < a.n; ++i) {
+        const int s = idx[base + i];
+        a.w[i] = w[s]; a.wq[i] = (unsigned char*)wq[s]; a.ws[i] = wscale[s];
+        a.Co[i] = Co[s]; a.Ci[i] = Ci[s];
+        a.start[i] = blocks;
+        const int N = dgrad ? Ci[s] : Co[s], K = dgrad ? Co[s] : Ci[s];
+        blocks += pass == 0 ? N / (dgrad ? 16 : 8) : N;      // phase 1: 16 (data-gradient) / 8 rows per block; plain: one per block
+        tiles += (N / 32) * (K / 64);
+      }
+      a.start[a.n] = blocks;
+      if (pass == 0) {
+        a2 = a;
+        for (int i = 0, at = 0; i <= a.n; ++i) {
+          a2.start[i] = at;
+          if (i < a.n) at += ((dgrad ? a.Ci[i] : a.Co[i]) / 32) * ((dgrad ? a.Co[i] : a.Ci[i]) / 64);
+        }
+        static bool attr_set = false;
+        if (!attr_set) {
+          hipFuncSetAttribute(reinterpret_cast<const void*>(pack_weight_fp8_tiled_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 577 * 4);
+          hipFuncSetAttribute(reinterpret_cast<const void*>(pack_weight_fp8_tiled_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 289 * 4);
+          attr_set = true;
+        }
+        if (dgrad) {
+          hipLaunchKernelGGL((pack_weight_fp8_tiled_kernel<true, 1>), dim3((unsigned)blocks), dim3(576), 0, stream, a);
+          hipLaunchKernelGGL((pack_weight_fp8_tiled_kernel<true, 2>), dim3((unsigned)tiles), dim3(576), 64 * 289 * 4, stream, a2);
+        } else {
+          hipLaunchKernelGGL((pack_weight_fp8_tiled_kernel<false, 1>), dim3((unsigned)blocks), dim3(512), 0, stream, a);
+          hipLaunchKernelGGL((pack_weight_fp8_tiled_kernel<false, 2>), dim3((unsigned)tiles), dim3(512), 32 * 577 * 4, stream, a2);
+        }
+        if (int rc = im2im::check_launch("pack_weight_fp8_tiled_kernel")) return rc;
+      } else {
+        if (dgrad) hipLaunchKernelGGL(pack_weight_fp8_multi_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(pack_weight_fp8_multi_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        if (int rc = im2im::check_launch("pack_weight_fp8_multi_kernel")) return rc;
+      }
+    }
+  }
+  return IM2IM_OK;
 }
 
 extern "C" int im2im_conv_fwd_fp8(const void* x, const float* in_scale_shift, const void* x_hi, const float* in_scale_shift_hi,

@@ -253,6 +253,11 @@ int im2im_conv_fwd_fp8(const void* x, const float* in_scale_shift, const void* x
  * Cz % 64 == 0, Cx % 64 == 0.  The weight gradient stays bf16 (im2im_conv_wgrad). */
 int im2im_pack_conv_weight_fp8_dgrad(const float* w, int32_t Co, int32_t Ci, int32_t taps, void* wq_d, float* wscale_d,
                                      im2im_stream_t stream);
+/* [r4] The fp8 operands of many 3x3 conv weights in one launch (per kind): n_tensors host arrays of device pointers / sizes as for
+ * im2im_pack_conv_weights_multi; dgrad == 0: wq [Co][9][Ci] + wscale [Co] of im2im_pack_conv_weight_fp8, dgrad != 0: wq_d
+ * [Ci][9 reversed][Co] + wscale_d [Ci] of im2im_pack_conv_weight_fp8_dgrad (same bits as the single-tensor entries). */
+int im2im_pack_conv_weights_fp8_multi(int32_t n_tensors, const float* const* w, const int32_t* Co, const int32_t* Ci,
+                                      void* const* wq, float* const* wscale, int32_t dgrad, im2im_stream_t stream);
 int im2im_conv_dgrad_fp8(const void* dz, const void* wq_d, const float* wscale_d, void* dx, void* dx_hi, int32_t Cx_lo,
                          const float* amax_prev, float* amax_now, float* amax_next, int32_t B, int32_t H, int32_t W,
                          int32_t Cz, int32_t Cx, im2im_stream_t stream);

@@ -435,3 +435,40 @@ def test_fp8_mode_train_step_uses_the_fp8_weight_gradient():
         nn_ops.TIMER = None
     errs = sorted(rel_l2(grads[True][n].cpu(), grads[False][n].cpu()) for n in grads[True] if float(grads[False][n].abs().max()) > 0)
     assert errs[len(errs) // 2] < 0.05 and errs[-1] < 0.3, (errs[len(errs) // 2], errs[-1])
+
+
+def test_batched_fp8_weight_pack_is_bit_equal_to_the_single_tensor_packs_and_follows_updates():
+    """[r4] packed_fp8: one launch per kind for every registered 3x3 weight == im2im_pack_conv_weight_fp8 / _fp8_dgrad per
+    tensor, bit for bit; an optimizer-style in-place update repacks, an untouched weight is served from the cache."""
+    from im2im_uq_amd import nn_ops
+    torch.manual_seed(11)
+    shapes = [(64, 64), (128, 64), (128, 128), (256, 128), (512, 256), (64, 128), (96, 40), (32, 3)]
+    ws = [torch.nn.Parameter(torch.randn(co, ci, 3, 3, device=DEV) * (0.02 + 0.1 * i)) for i, (co, ci) in enumerate(shapes)]
+    with torch.no_grad():
+        ws[2][5].zero_()                                           # an all-zero output channel: scale must not divide by zero
+    want = [ci % 128 == 0 for _, ci in shapes]
+
+    def check_all():
+        for w, dg in zip(ws, want):
+            (wq, sc), d = nn_ops.packed_fp8(w, dg)
+            wq1, sc1 = nn_ops.pack_weight_fp8(w.detach())
+            assert torch.equal(wq.view(torch.uint8), wq1.view(torch.uint8)) and torch.equal(sc, sc1), tuple(w.shape)
+            assert (d is not None) == dg
+            if dg:
+                wd1, sd1 = nn_ops.pack_weight_fp8_dgrad(w.detach())
+                assert torch.equal(d[0].view(torch.uint8), wd1.view(torch.uint8)) and torch.equal(d[1], sd1), tuple(w.shape)
+
+    for w, dg in zip(ws, want):                                    # register all, then verify: the first stale request packs everyone
+        nn_ops.packed_fp8(w, dg)
+    check_all()
+    first = nn_ops.packed_fp8(ws[0], want[0])[0][0]
+    assert nn_ops.packed_fp8(ws[0], want[0])[0][0] is first        # cached
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(1.7).add_(0.01)
+    assert nn_ops.packed_fp8(ws[0], want[0])[0][0] is not first
+    check_all()
+    # a later request for the data-gradient operand of a weight registered without one
+    (_, _), d = nn_ops.packed_fp8(ws[1], True)
+    wd1, sd1 = nn_ops.pack_weight_fp8_dgrad(ws[1].detach())
+    assert d is not None and torch.equal(d[0].view(torch.uint8), wd1.view(torch.uint8)) and torch.equal(d[1], sd1)
