@@ -110,5 +110,6 @@ inline TileChoice pick_tile(int B, int H, int W, int Co, bool per_image = false)
 
 // conv_mfma.hip: A/B switch of the split-K path (im2im_set_option "conv_splitk", conv_wgrad.hip)
 void set_conv_splitk(int v);
+void set_bn_fused_small(int v);          // elementwise.hip: one-launch BatchNorm sums for few partial rows
 
 }  // namespace im2im

@@ -1009,6 +1009,7 @@ extern "C" int im2im_set_option(const char* key, int32_t value) {
   if (std::string(key) == "conv_splitk") { im2im::set_conv_splitk(value); return IM2IM_OK; }
   if (std::string(key) == "wgrad_co128") { g_wgrad_co128 = value; return IM2IM_OK; }
   if (std::string(key) == "wgrad_tile16") { g_wgrad_tile16 = value; return IM2IM_OK; }
+  if (std::string(key) == "bn_fused_small") { im2im::set_bn_fused_small(value); return IM2IM_OK; }
   return im2im::fail_invalid("unknown option");
 }
 

@@ -65,8 +65,30 @@ __global__ __launch_bounds__(1024) void bn_stats_stage1_kernel(const float* __re
   }
 }
 
-// stage 2: tmp[S][3][C] -> mean_invstd[2][C], scale_shift[2][C] (scale = gamma*invstd, shift = beta - mean*scale),
+// one channel's batch moments -> mean_invstd[2][C], scale_shift[2][C] (scale = gamma*invstd, shift = beta - mean*scale),
 //   running stats (unbiased variance, as torch).
+__device__ __forceinline__ void bn_finalize_channel(const Moments& m, int c, int C, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                    float* __restrict__ running_var, float momentum, float eps, int centered,
+                                                    float* __restrict__ mean_invstd, float* __restrict__ scale_shift) {
+  const double mean = m.mean;
+  const double var = m.n > 0.0 ? m.m2 / m.n : 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  mean_invstd[c] = (float)mean;
+  mean_invstd[C + c] = invstd;
+  const float sc = gamma[c] * invstd;
+  scale_shift[c] = sc;
+  scale_shift[C + c] = beta[c] - (float)mean * sc;
+  if (running_mean) {
+    const double unbiased = m.n > 1.0 ? m.m2 / (m.n - 1.0) : var;
+    // centered: the statistics describe z - running_mean(old); the true batch mean adds it back
+    const float true_mean = (float)mean + (centered ? running_mean[c] : 0.f);
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * true_mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// stage 2: tmp[S][3][C] -> one wave per channel merges the splits, lane 0 finishes (bn_finalize_channel).
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ tmp, int S, int C, double count,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
@@ -88,20 +110,52 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   }
   if (lane != 0) return;
   (void)count;                                             // == m.n (kept in the ABI for the caller's bookkeeping)
-  const double mean = m.mean;
-  const double var = m.n > 0.0 ? m.m2 / m.n : 0.0;
-  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  mean_invstd[c] = (float)mean;
-  mean_invstd[C + c] = invstd;
-  const float sc = gamma[c] * invstd;
-  scale_shift[c] = sc;
-  scale_shift[C + c] = beta[c] - (float)mean * sc;
-  if (running_mean) {
-    const double unbiased = m.n > 1.0 ? m.m2 / (m.n - 1.0) : var;
-    // centered: the statistics describe z - running_mean(old); the true batch mean adds it back
-    const float true_mean = (float)mean + (centered ? running_mean[c] : 0.f);
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * true_mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  bn_finalize_channel(m, c, C, gamma, beta, running_mean, running_var, momentum, eps, centered, mean_invstd, scale_shift);
+}
+
+// [r4] few partial rows (R <= BN_FUSED_MAX_ROWS = 256: every layer of the 32x32 config, the deep levels of a small batch): stage 1 over
+// ALL rows and stage 2 in one launch, block = 16 channels x 64 row lanes -- one ~5 us launch less per BatchNorm layer where the
+// step is a chain of such launches.
+constexpr int BN_FUSED_MAX_ROWS = 256;
+__global__ __launch_bounds__(1024) void bn_stats_fused_kernel(const float* __restrict__ partial, int64_t R, int C,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                               float momentum, float eps, int centered,
+                                                               float* __restrict__ mean_invstd, float* __restrict__ scale_shift,
+                                                               long long* __restrict__ num_batches_tracked) {
+  __shared__ double sh[2][64][16];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const bool on = c < C;
+  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+  double n = 0.0, a = 0.0;
+  if (on)
+    for (int64_t r = rl; r < R; r += 64) {
+      const float* row = partial + r * 3 * C;
+      const double nt = (double)row[2 * C + c];
+      n += nt; a += nt * (double)row[c];
+    }
+  sh[0][rl][cl] = n; sh[1][rl][cl] = a;
+  __syncthreads();
+  double N = 0.0, A = 0.0;
+#pragma unroll 8
+  for (int i = 0; i < 64; ++i) { N += sh[0][i][cl]; A += sh[1][i][cl]; }
+  const double mean = N > 0.0 ? A / N : 0.0;
+  double q = 0.0;
+  if (on)
+    for (int64_t r = rl; r < R; r += 64) {
+      const float* row = partial + r * 3 * C;
+      const double d = (double)row[c] - mean;
+      q += (double)row[C + c] + (double)row[2 * C + c] * d * d;
+    }
+  __syncthreads();
+  sh[0][rl][cl] = q;
+  __syncthreads();
+  if (rl == 0 && on) {
+    double Q = 0.0;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) Q += sh[0][i][cl];
+    bn_finalize_channel(Moments{N, mean, Q}, c, C, gamma, beta, running_mean, running_var, momentum, eps, centered, mean_invstd, scale_shift);
   }
 }
 
@@ -235,6 +289,28 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
   double s2 = (lane < S) ? tmp[((size_t)lane * 2 + 1) * C + c] : 0.0;
   for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
   if (lane != 0) return;
+  dbeta[c] = (float)s1;
+  dgamma[c] = (float)s2;
+  coef[c] = (float)(s1 / count);
+  coef[C + c] = (float)(s2 / count);
+}
+
+// [r4] the same for few partial rows (R <= BN_FUSED_MAX_ROWS): both stages in one launch, block = 16 channels x 64 row lanes
+__global__ __launch_bounds__(1024) void bn_bwd_sums_fused_kernel(const float* __restrict__ partial, int64_t R, int C, double count,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  float* __restrict__ coef) {
+  __shared__ double sh[2][64][16];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double a1 = 0.0, a2 = 0.0;
+  if (c < C)
+    for (int64_t r = rl; r < R; r += 64) { a1 += (double)partial[r * 2 * C + c]; a2 += (double)partial[r * 2 * C + C + c]; }
+  sh[0][rl][cl] = a1; sh[1][rl][cl] = a2;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
+  for (int i = 0; i < 64; ++i) { s1 += sh[0][i][cl]; s2 += sh[1][i][cl]; }
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
   coef[c] = (float)(s1 / count);
@@ -1527,7 +1603,23 @@ inline dim3 row_grid(int rowvecs, int64_t rows) {
 }
 inline int ew_blocks(int64_t n) { int64_t b = cdiv(n, 256); if (b > 256 * 32) b = 256 * 32; if (b < 1) b = 1; return (int)b; }
 
+// BatchNorm-backward sums: partial[R][2][C] -> dgamma, dbeta, coef; one launch for few rows, two stages otherwise
+int g_bn_fused_small = 1;                                    // im2im_set_option("bn_fused_small", 0 / 1): A/B switch
+inline int launch_bn_bwd_sums(const float* partial, int64_t R, int C, double count, double* tmp, float* dgamma, float* dbeta,
+                              float* coef, hipStream_t stream) {
+  if (R <= BN_FUSED_MAX_ROWS && g_bn_fused_small) {
+    hipLaunchKernelGGL(bn_bwd_sums_fused_kernel, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, stream, partial, R, C, count, dgamma, dbeta, coef);
+    return check_launch("bn_bwd_sums_fused_kernel");
+  }
+  int rc;
+  const int S = launch_reduce_stage1(partial, R, 2 * (int64_t)C, tmp, stream, &rc);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, stream, (const double*)tmp, S, C, count, dgamma, dbeta, coef);
+  return check_launch("bn_bwd_finalize_kernel");
+}
+
 }  // namespace
+namespace im2im { void set_bn_fused_small(int v) { g_bn_fused_small = v; } }
 
 // ================================================================================================
 extern "C" int64_t im2im_reduce_workspace_bytes(int64_t K) { return im2im::reduce_tmp_bytes(K); }
@@ -1540,6 +1632,11 @@ extern "C" int im2im_bn_finalize(const float* partial, int64_t R, int32_t C, int
   IM2IM_REQUIRE(partial && gamma && beta && mean_invstd && scale_shift && ws && R > 0 && C > 0 && count > 0);
   IM2IM_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
   IM2IM_REQUIRE(!centered || running_mean);
+  if (R <= BN_FUSED_MAX_ROWS && g_bn_fused_small) {
+    hipLaunchKernelGGL(bn_stats_fused_kernel, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, stream, partial, R, (int)C, gamma, beta,
+                       running_mean, running_var, momentum, eps, (int)centered, mean_invstd, scale_shift, (long long*)num_batches_tracked);
+    return check_launch("bn_stats_fused_kernel");
+  }
   const int S = reduce_splits(R);
   hipLaunchKernelGGL(bn_stats_stage1_kernel, dim3((unsigned)cdiv(C, 64), (unsigned)S), dim3(1024), 0, stream, partial, R, (int)C,
                      cdiv(R, S), (double*)ws);
@@ -1593,12 +1690,7 @@ extern "C" int im2im_bn_relu_bwd(const void* da, const void* z, const float* sca
     hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<T>, dim3((unsigned)cdiv(M, rpb)), dim3(256), 0, stream,
                        (const T*)da, (const T*)z, scale_shift, mean_invstd, M, (int)C, rpb, partial);
     if (int rc = check_launch("bn_relu_bwd_reduce_kernel")) return rc;
-    int rc;
-    const int S = launch_reduce_stage1(partial, cdiv(M, rpb), 2 * (int64_t)C, tmp, stream, &rc);
-    if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, stream, (const double*)tmp, S, (int)C,
-                       (double)M, dgamma, dbeta, coef);
-    if (int rc2 = check_launch("bn_bwd_finalize_kernel")) return rc2;
+    if (int rc = launch_bn_bwd_sums(partial, cdiv(M, rpb), (int)C, (double)M, tmp, dgamma, dbeta, coef, stream)) return rc;
     const int64_t nvec = M * C / Vec16<T>::N;
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, stream, (const T*)da, (const T*)z,
                        scale_shift, mean_invstd, coef, (T*)dz, nvec, (int)C);
@@ -1643,12 +1735,7 @@ extern "C" int im2im_bn_relu_bwd_phase(const void* da, const void* z, const floa
       return check_launch("bn_relu_bwd_reduce_kernel");
     }
     if (phase == 2) {
-      int rc;
-      const int S = launch_reduce_stage1(partial, cdiv(M, rpb), 2 * (int64_t)C, tmp, stream, &rc);
-      if (rc) return rc;
-      hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, stream, (const double*)tmp, S, (int)C,
-                         (double)M, dgamma, dbeta, coef);
-      return check_launch("bn_bwd_finalize_kernel");
+      return launch_bn_bwd_sums(partial, cdiv(M, rpb), (int)C, (double)M, tmp, dgamma, dbeta, coef, stream);
     }
     const int64_t nvec = (row1 - row0) * C / Vec16<T>::N;
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, stream, (const T*)da + row0 * C,
@@ -1696,12 +1783,7 @@ extern "C" int im2im_bn_relu_pool_bwd(const void* da, const void* dpool, const v
     hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<T, false>), grid, dim3(256), 0, stream, (const T*)da, (const T*)dpool, (const T*)z,
                        scale_shift, mean_invstd, (const float*)nullptr, (T*)nullptr, partial, B, H, W, (int)C, rv);
     if (int rc = check_launch("bn_relu_pool_bwd_kernel<reduce>")) return rc;
-    int rc;
-    const int S = launch_reduce_stage1(partial, nblk, 2 * (int64_t)C, tmp, stream, &rc);
-    if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, stream, (const double*)tmp, S, (int)C,
-                       count, dgamma, dbeta, coef);
-    if (int rc2 = check_launch("bn_bwd_finalize_kernel")) return rc2;
+    if (int rc = launch_bn_bwd_sums(partial, nblk, (int)C, count, tmp, dgamma, dbeta, coef, stream)) return rc;
     hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<T, true>), grid, dim3(256), 0, stream, (const T*)da, (const T*)dpool, (const T*)z,
                        scale_shift, mean_invstd, (const float*)coef, (T*)dz, (float*)nullptr, B, H, W, (int)C, rv);
     return check_launch("bn_relu_pool_bwd_kernel<apply>");
@@ -1719,12 +1801,7 @@ extern "C" int im2im_bn_relu_bwd_from_partial(const void* da, const void* z, con
   float* coef = (float*)((char*)tmp + reduce_tmp_bytes(2 * (int64_t)C));
   return for_dtype(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
-    int rc;
-    const int S = launch_reduce_stage1(partial, R, 2 * (int64_t)C, tmp, stream, &rc);
-    if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, stream, (const double*)tmp, S, (int)C,
-                       (double)M, dgamma, dbeta, coef);
-    if (int rc2 = check_launch("bn_bwd_finalize_kernel")) return rc2;
+    if (int rc = launch_bn_bwd_sums(partial, R, (int)C, (double)M, tmp, dgamma, dbeta, coef, stream)) return rc;
     const int64_t nvec = M * C / Vec16<T>::N;
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, stream, (const T*)da, (const T*)z,
                        scale_shift, mean_invstd, coef, (T*)dz, nvec, (int)C);

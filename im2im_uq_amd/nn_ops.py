@@ -398,6 +398,8 @@ def conv_fwd_fp8(x, wq, wscale, bias=None, scale_shift=None, relu=False, want_st
     return (y, stats) if want_stats else y
 
 
+if os.environ.get("IM2IM_BN_FUSED_SMALL") is not None:   # A/B: one-launch BatchNorm sums for <= 256 partial rows (default on)
+    check(lib.im2im_set_option(b"bn_fused_small", int(os.environ["IM2IM_BN_FUSED_SMALL"])), "im2im_set_option")
 if os.environ.get("IM2IM_CONV_SPLITK") is not None:       # A/B of the split-K target (see im2im_set_option): 0 = off
     check(lib.im2im_set_option(b"conv_splitk", int(os.environ["IM2IM_CONV_SPLITK"])), "im2im_set_option")
 

@@ -254,3 +254,58 @@ def test_eval_last_block_with_fused_outconv_equals_the_two_kernels(dt):
     finally:
         nn_ops.FUSE_EVAL_OUTCONV = was
         nn_ops.set_compute_dtype("bf16")
+
+
+@pytest.mark.parametrize("rows,c", [(1, 64), (45, 512), (250, 256), (256, 72), (257, 64)])
+def test_bn_sums_in_one_launch_for_few_partial_rows(rows, c):
+    """[r4] bn_stats_fused_kernel / bn_bwd_sums_fused_kernel (<= 256 partial rows; 257 stays two-stage): the statistics, the
+    running buffers and the backward coefficients equal the two-stage path's to fp64-summation-order noise and a float64
+    evaluation of the same merge."""
+    from im2im_uq_amd import hip_ops, nn_ops
+    g = torch.Generator().manual_seed(rows * 1000 + c)
+    n = torch.randint(1, 300, (rows, 1, c), generator=g).float()
+    mean = torch.randn(rows, 1, c, generator=g) * 0.3 + 1.5
+    m2 = torch.rand(rows, 1, c, generator=g) * n * 0.8
+    stats = torch.cat([mean, m2, n], dim=1).contiguous().to(DEV)                 # [R][3][C]: (mean, M2, n) per tile
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(DEV), torch.randn(c, generator=g).to(DEV)
+    count = int(n[:, 0, 0].sum())
+    out = {}
+    try:
+        for mode in (0, 1):
+            hip_ops.set_option("bn_fused_small", mode)
+            rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+            nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+            mi, ss = nn_ops.bn_finalize(stats, count, gamma, beta, rm, rv, 0.1, 1e-5, num_batches_tracked=nbt)
+            out[mode] = (mi.cpu(), ss.cpu(), rm.cpu(), rv.cpu(), int(nbt))
+    finally:
+        hip_ops.set_option("bn_fused_small", 1)
+    nd, md, qd = n.double()[:, 0], mean.double()[:, 0], m2.double()[:, 0]
+    N = nd.sum(0)
+    mu = (nd * md).sum(0) / N
+    var = (qd + nd * (md - mu) ** 2).sum(0) / N
+    assert out[0][4] == out[1][4] == 1
+    for mode in (0, 1):
+        mi, ss, rm, rv, _ = out[mode]
+        torch.testing.assert_close(mi[0].double(), mu, rtol=2e-7, atol=1e-7)
+        torch.testing.assert_close(mi[1].double(), 1.0 / torch.sqrt(var + 1e-5), rtol=3e-7, atol=0)
+        torch.testing.assert_close(rm.double(), 0.1 * mu, rtol=3e-7, atol=1e-8)
+        torch.testing.assert_close(rv.double(), 0.9 + 0.1 * var * N / (N - 1), rtol=3e-7, atol=0)
+    for a, b in zip(out[0][:4], out[1][:4]):
+        torch.testing.assert_close(a, b, rtol=2.4e-7, atol=1e-7)                 # one fp32 rounding of differently-ordered fp64 sums
+    # backward: m pixels chosen so that the reduce kernel writes `rows` partial rows (64 pixels per row)
+    m = rows * 64
+    da = torch.randn(m, c, generator=g).to(DEV).bfloat16()
+    z = torch.randn(m, c, generator=g).to(DEV).bfloat16()
+    mi, ss = out[1][0].to(DEV), out[1][1].to(DEV)
+    res = {}
+    try:
+        for mode in (0, 1):
+            hip_ops.set_option("bn_fused_small", mode)
+            res[mode] = [t.float().cpu() for t in nn_ops.bn_relu_bwd(da, z, ss, mi)]
+    finally:
+        hip_ops.set_option("bn_fused_small", 1)
+    for a, b in zip(res[0], res[1]):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
+    mask = (z.float() * ss[0] + ss[1] > 0).double()
+    gd = da.double() * mask
+    torch.testing.assert_close(res[1][2].double(), gd.sum(0).cpu(), rtol=1e-5, atol=1e-4)          # dbeta
