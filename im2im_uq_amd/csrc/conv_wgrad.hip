@@ -10,6 +10,12 @@
 #ifndef IM2IM_WGRAD_ABL      // measurement-only: bit 0 = no global loads after the first tile, bit 1 = no LDS writes, bit 2 = no MFMA phase, bit 3 = loads of the same (cache-hot) tile, bit 4 = the dz half of the staging only for the first tile
 #define IM2IM_WGRAD_ABL 0
 #endif
+#ifndef IM2IM_WGRAD_ROLL     // 1 = rolling operand prefetch in the MFMA phase + staging spread over it (conv_wgrad_pipe_kernel)
+#define IM2IM_WGRAD_ROLL 0
+#endif
+#ifndef IM2IM_WGRAD_MID      // 0 = tile t+1 staged after the MFMAs of tile t; n = after k-step n/8 of them (see conv_wgrad_pipe_kernel)
+#define IM2IM_WGRAD_MID 0
+#endif
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -49,6 +55,10 @@ template <typename T> struct WgradSrc {
     sh = ss ? ss + stride + c : nullptr;
   }
 };
+
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
 
 template <typename T> struct WFrag;
 template <> struct WFrag<bf16_t> {
@@ -326,55 +336,49 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
   }
 
   bool abl_first = true; (void)abl_first;
-  auto gload = [&](int t, Stage& R) __attribute__((always_inline)) {
+  // where tile t lies: first pixel, image base pointers
+  struct TilePos { int y0, x0; const T* xb; const T* dzb; };
+  auto tile_pos = [&](int t) __attribute__((always_inline)) -> TilePos {
     int tt = t;
     const int tx_id = tt % a.tilesX; tt /= a.tilesX;
     const int ty_id = tt % a.tilesY;
     const int b = tt / a.tilesY;
-    const int y0 = ty_id * TH, x0 = tx_id * TW;
-    const T* xb = xg + (size_t)b * a.H * a.W * xs.stride;
-    const T* dzb = dzg + (size_t)b * a.H * a.W * a.Co + co0;
-#if IM2IM_WGRAD_ABL & 16
-    if (abl_first)
-#endif
-#pragma unroll
-    for (int i = 0; i < A_ROUNDS; ++i) {
+    return TilePos{ty_id * TH, tx_id * TW, xg + (size_t)b * a.H * a.W * xs.stride, dzg + (size_t)b * a.H * a.W * a.Co + co0};
+  };
+  // staging piece p of a tile: p < A_ROUNDS = the thread's dz piece p, else its x (halo) piece p - A_ROUNDS
+  auto gload_piece = [&](const TilePos& tp, Stage& R, int p) __attribute__((always_inline)) {
+    if (p < A_ROUNDS) {
+      const int i = p;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (a_px[i] >= 0) {
-        const int yy = y0 + a_px[i] / TW, xx = x0 + a_px[i] % TW;
+        const int yy = tp.y0 + a_px[i] / TW, xx = tp.x0 + a_px[i] % TW;
         if (yy < a.H && xx < a.W && co0 + a_part[i] * EPP < a.Co)
-          v = *reinterpret_cast<const uint4*>(dzb + ((size_t)yy * a.W + xx) * a.Co + a_part[i] * EPP);
+          v = *reinterpret_cast<const uint4*>(tp.dzb + ((size_t)yy * a.W + xx) * a.Co + a_part[i] * EPP);
       }
       R.a[i] = v;
-    }
-    R.valid = 0;
-#pragma unroll
-    for (int i = 0; i < B_ROUNDS; ++i) {
+    } else {
+      const int i = p - A_ROUNDS;
       uint4 v = make_uint4(0, 0, 0, 0);
+      bool ok = false;
       if (b_px[i] >= 0) {
-        const int yy = y0 + b_px[i] / HWD - 1, xx = x0 + b_px[i] % HWD - 1;
+        const int yy = tp.y0 + b_px[i] / HWD - 1, xx = tp.x0 + b_px[i] % HWD - 1;
         if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
-          v = *reinterpret_cast<const uint4*>(xb + ((size_t)yy * a.W + xx) * xs.stride + b_part[i] * EPP);
-          R.valid |= 1u << i;
+          v = *reinterpret_cast<const uint4*>(tp.xb + ((size_t)yy * a.W + xx) * xs.stride + b_part[i] * EPP);
+          ok = true;
         }
       }
+      R.valid = (R.valid & ~(1u << i)) | ((ok ? 1u : 0u) << i);
       R.b[i] = v;
     }
   };
-  auto swrite = [&](int buf, const Stage& R) __attribute__((always_inline)) {
+  auto swrite_piece = [&](int buf, const Stage& R, int p) __attribute__((always_inline)) {
     char* la = smem + buf * BUF_BYTES;
     char* lb = la + A_BYTES;
-#if IM2IM_WGRAD_ABL & 16
-    if (abl_first)
-#endif
-#pragma unroll
-    for (int i = 0; i < A_ROUNDS; ++i)
+    if (p < A_ROUNDS) {
+      const int i = p;
       if (a_px[i] >= 0) *reinterpret_cast<uint4*>(la + a_px[i] * PA + (SWZ ? (a_part[i] ^ (((a_px[i] >> 1) & 1) << 2)) : a_part[i]) * 16) = R.a[i];
-#if IM2IM_WGRAD_ABL & 16
-    abl_first = false;
-#endif
-#pragma unroll
-    for (int i = 0; i < B_ROUNDS; ++i) {
+    } else {
+      const int i = p - A_ROUNDS;
       if (b_px[i] >= 0) {
         uint4 v = R.b[i];
         if (lazy_x && ((R.valid >> i) & 1)) {
@@ -394,7 +398,32 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
       }
     }
   };
-  auto compute = [&](int buf) __attribute__((always_inline)) {
+  constexpr int NPIECES = A_ROUNDS + B_ROUNDS;
+  auto gload = [&](int t, Stage& R) __attribute__((always_inline)) {
+    const TilePos tp = tile_pos(t);
+    R.valid = 0;
+#pragma unroll
+    for (int p = 0; p < NPIECES; ++p) {
+#if IM2IM_WGRAD_ABL & 16
+      if (p < A_ROUNDS && !abl_first) continue;
+#endif
+      gload_piece(tp, R, p);
+    }
+  };
+  auto swrite = [&](int buf, const Stage& R) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < NPIECES; ++p) {
+#if IM2IM_WGRAD_ABL & 16
+      if (p < A_ROUNDS && !abl_first) continue;
+#endif
+      swrite_piece(buf, R, p);
+    }
+#if IM2IM_WGRAD_ABL & 16
+    abl_first = false;
+#endif
+  };
+  auto compute = [&](int buf, auto ks_lo_tag, auto ks_hi_tag) __attribute__((always_inline)) {
+    constexpr int KS_LO = decltype(ks_lo_tag)::value, KS_HI = decltype(ks_hi_tag)::value;   // k-steps [KS_LO, KS_HI) of the tile
     const char* la = smem + buf * BUF_BYTES;
     const char* lb = la + A_BYTES + tg * HWD * PB;           // this wave's kernel row
     // k-step ks covers tile row ks (TW == 16): every address below is lane base + compile-time constant, so the fully
@@ -408,7 +437,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) xo[j] = SWZ ? (((wci ^ (((((j + 2 * tg) & 3) + tr_row) >> 1) & 1)) << 6) + tr_col_b) : 0;
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
+    for (int ks = KS_LO; ks < KS_HI; ++ks) {
       short8 fa[CJ];
 #pragma unroll
       for (int j = 0; j < CJ; ++j) fa[j] = WFrag<bf16_t>::load(pa + j * 64 + ks * 16 * PA, pa + j * 64 + (ks * 16 + 4) * PA);
@@ -422,12 +451,115 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
     }
   };
 
+#if IM2IM_WGRAD_ROLL
+  // MFMA phase with a ROLLING operand prefetch: the fragments of unit u+1 (unit = one (k-step, kw): CJ MFMAs on one x fragment) are
+  // requested before the MFMAs of unit u are issued, so a wave's LDS latency runs under its own MFMAs instead of only under the
+  // other two waves of its SIMD (the compiler's own order is read -> s_waitcnt lgkmcnt(0) -> two MFMAs).  hook(k-step) runs after a
+  // k-step's last MFMAs were issued (the staging of the next tile, spread over the phase).
+  auto compute_roll = [&](int buf, auto&& hook) __attribute__((always_inline)) {
+    const char* la = smem + buf * BUF_BYTES;
+    const char* lb = la + A_BYTES + tg * HWD * PB;
+    const char* pa = la + (half * 8 + tr_row) * PA + (SWZ ? ((wco ^ ((tr_row >> 1) & 1)) << 6) : wco * (COT / 2) * 2) + tr_col_b;
+    const char* pb = lb + (half * 8 + tr_row) * PB + (SWZ ? 0 : wci * 64 + tr_col_b);
+    int xo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xo[j] = SWZ ? (((wci ^ (((((j + 2 * tg) & 3) + tr_row) >> 1) & 1)) << 6) + tr_col_b) : 0;
+    short8 fa[2][CJ], fb[2];
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) fa[0][j] = WFrag<bf16_t>::load(pa + j * 64, pa + j * 64 + 4 * PA);
+    fb[0] = WFrag<bf16_t>::load(pb + xo[0], pb + xo[0] + 4 * PB);
+    static_for<0, KSTEPS * 3>([&](auto u_tag) __attribute__((always_inline)) {
+      constexpr int u = decltype(u_tag)::value, ks = u / 3, kw = u % 3, n = u + 1, nks = n / 3, nkw = n % 3;
+      if constexpr (n < KSTEPS * 3) {
+        if constexpr (nkw == 0) {
+#pragma unroll
+          for (int j = 0; j < CJ; ++j) fa[nks & 1][j] = WFrag<bf16_t>::load(pa + j * 64 + nks * 16 * PA, pa + j * 64 + (nks * 16 + 4) * PA);
+        }
+        const int xj = xo[(2 * nks + nkw) & 3];
+        fb[n & 1] = WFrag<bf16_t>::load(pb + xj + (nks * HWD + nkw) * PB, pb + xj + (nks * HWD + nkw + 4) * PB);
+        __builtin_amdgcn_sched_group_barrier(0x100, nkw == 0 ? 2 * CJ + 2 : 2, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < CJ; ++j) acc[j][kw] = WFrag<bf16_t>::mfma(fa[ks & 1][j], fb[u & 1], acc[j][kw]);
+      __builtin_amdgcn_sched_group_barrier(0x008, CJ, 0);
+      if constexpr (kw == 2) hook(std::integral_constant<int, ks>{});
+    });
+  };
+#endif
+
   const int t_begin = split * a.tiles_per_split;
   const int t_end = min(t_begin + a.tiles_per_split, a.ntiles);
   if (t_begin < t_end) {
     Stage R;
     gload(t_begin, R);
     swrite(0, R);
+#if IM2IM_WGRAD_ROLL
+    // rolling operand prefetch + staging spread over the MFMA phase (see IM2IM_WGRAD_MID == 9 below)
+    if (t_begin + 1 < t_end) gload(t_begin + 1, R);
+    __syncthreads();
+    int cur = 0;
+    for (int t = t_begin; t < t_end; ++t) {
+      const bool more1 = t + 1 < t_end, more2 = t + 2 < t_end;
+      const TilePos tp2 = tile_pos(more2 ? t + 2 : t);
+      compute_roll(cur, [&](auto ks_tag) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ks_tag)::value;
+        static_for<0, NPIECES>([&](auto p_tag) __attribute__((always_inline)) {
+          constexpr int p = decltype(p_tag)::value;
+          if constexpr ((2 * p + 1) * KSTEPS / (2 * NPIECES) == ks) {
+            if (more1) swrite_piece(cur ^ 1, R, p);
+            if (more2) gload_piece(tp2, R, p);
+          }
+        });
+      });
+      __syncthreads();
+      cur ^= 1;
+    }
+#elif IM2IM_WGRAD_MID == 9
+    // Staging SPREAD over a tile's MFMA phase: after k-step slot(p) of tile t, this thread's piece p of tile t+1 (requested at the same
+    // point of tile t-1: one whole tile period in flight) goes to the other LDS buffer and the request for its piece p of tile
+    // t+2 follows at once -- a handful of transform / ds_write / address instructions between two k-steps' MFMAs instead of a
+    // staging phase of all twelve waves in front of the barrier, which is followed by MFMA work at once.  Same registers (a piece's
+    // registers are live for one period either way), same LDS, same arithmetic.
+    if (t_begin + 1 < t_end) gload(t_begin + 1, R);
+    __syncthreads();
+    int cur = 0;
+    for (int t = t_begin; t < t_end; ++t) {
+      const bool more1 = t + 1 < t_end, more2 = t + 2 < t_end;
+      const TilePos tp2 = tile_pos(more2 ? t + 2 : t);
+      static_for<0, KSTEPS>([&](auto ks_tag) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ks_tag)::value;
+        compute(cur, std::integral_constant<int, ks>{}, std::integral_constant<int, ks + 1>{});
+        static_for<0, NPIECES>([&](auto p_tag) __attribute__((always_inline)) {
+          constexpr int p = decltype(p_tag)::value;
+          if constexpr ((2 * p + 1) * KSTEPS / (2 * NPIECES) == ks) {
+            if (more1) swrite_piece(cur ^ 1, R, p);
+            if (more2) gload_piece(tp2, R, p);
+          }
+        });
+      });
+      __syncthreads();
+      cur ^= 1;
+    }
+#elif IM2IM_WGRAD_MID
+    // Staging in the MIDDLE of a tile's MFMA phase: tile t+1 (requested one whole tile period earlier) goes to the other LDS buffer
+    // after k-step MIDK of tile t and the request for tile t+2 follows it, so the transform + ds_write instructions of one wave run
+    // beside the other waves' MFMAs instead of all twelve waves staging together in front of the barrier, and the barrier is
+    // followed by MFMA work at once.  Same registers, same LDS, same arithmetic.
+    constexpr int MIDK = KSTEPS * IM2IM_WGRAD_MID / 8;
+    if (t_begin + 1 < t_end) gload(t_begin + 1, R);
+    __syncthreads();
+    int cur = 0;
+    for (int t = t_begin; t < t_end; ++t) {
+      compute(cur, std::integral_constant<int, 0>{}, std::integral_constant<int, MIDK>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < t_end) swrite(cur ^ 1, R);
+      if (t + 2 < t_end) gload(t + 2, R);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur, std::integral_constant<int, MIDK>{}, std::integral_constant<int, KSTEPS>{});
+      __syncthreads();
+      cur ^= 1;
+    }
+#else
     __syncthreads();
     int cur = 0;
     for (int t = t_begin; t < t_end; ++t) {
@@ -438,7 +570,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
       if (more) gload(t + 1, R);                       // in flight during the MFMAs below
 #endif
 #if !(IM2IM_WGRAD_ABL & 4)
-      compute(cur);
+      compute(cur, std::integral_constant<int, 0>{}, std::integral_constant<int, KSTEPS>{});
 #endif
 #if !(IM2IM_WGRAD_ABL & 2)
       if (more) swrite(cur ^ 1, R);
@@ -446,6 +578,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
       __syncthreads();
       cur ^= 1;
     }
+#endif
   }
   float* out = a.partial + (size_t)split * a.Co * 9 * a.Ci;
 #pragma unroll
@@ -457,6 +590,310 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
         const int co = co0 + wco * (COT / 2) + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         const int ci = ci0 + wci * 32 + l31;
         if (co < a.Co) out[((size_t)co * 9 + tg * 3 + kw) * a.Ci + ci] = acc[j][kw][r];
+      }
+}
+
+// ------------------------------------------------------------------------------------------------
+// [r4b] conv_wgrad_pipe_kernel with the two phases of a tile dissolved into each other (needs Co % COT == 0 and 32-bit byte offsets
+// within an image: launch_wgrad sends everything else to conv_wgrad_pipe_kernel; PARTIAL = tiles may hang over the image).  Same workgroup (12 waves = 2 x 2 (co, ci) quadrants
+// x 3 kernel rows), same LDS images, same accumulation order -- bit-identical results -- but:
+//  * ROLLING OPERAND PREFETCH.  The compiler's order for the MFMA phase is  ds_read_b64_tr_b16 x2 -> s_waitcnt lgkmcnt(0) -> MFMA x2:
+//    a wave's LDS latency is hidden only by the two other waves of its SIMD.  Here the fragments of unit u+1 (unit = one
+//    (k-step, kw): CJ MFMAs on one x fragment) are requested BEFORE the MFMAs of unit u issue (sched_group_barrier pins "reads,
+//    then MFMAs"), so the latency also runs under the wave's own MFMAs.
+//  * STAGING SPREAD OVER THE MFMA PHASE.  After k-step slot(p) of tile t this thread's piece p of tile t+1 -- requested at the same
+//    point of tile t-1, one whole tile period in flight -- goes to the other LDS buffer and the request for piece p of tile t+2
+//    follows at once.  No staging phase of all twelve waves in front of the barrier; after the barrier MFMA work issues at once.
+//  * A VALU DIET.  With 48 MFMAs per wave and tile, ~7 VALU instructions per MFMA issue for free in the MFMA's shadow; the
+//    pipe kernel spends 216 per tile on addresses, bounds and the lazy transform (the first version of this kernel 285: no gain;
+//    without the lazy transform +7 %).  Here: buffer loads (uniform 64-bit tile base in the descriptor, one 32-bit per-thread
+//    offset per piece computed ONCE; a halo piece outside the image gets offset 0xffffffff = out of range = the hardware returns
+//    zeros: no clamps, no selects, no exec branches), LDS addresses computed once, a tile's edge test = one AND of a per-thread
+//    nibble mask with a uniform nibble, the lazy BatchNorm+ReLU on packed fp32 pairs (v_pk_mul_f32, v_pk_add_f32,
+//    v_cvt_pk_bf16_f32, ReLU as v_pk_max_i16 on the bf16 bit patterns -- same bits as max(x, 0) before the rounding).
+//  * BRANCH-FREE tile iteration = ONE basic block: s_waitcnt vmcnt counts exactly (with exec branches around the loads the
+//    compiler waits for vmcnt(0), i.e. also for the requests just issued).  Past the end of a split the last tile is requested
+//    again (L2 hits) and written to the buffer nobody reads.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <int TH, int TW, int COT, bool LAZY, bool PARTIAL>
+__global__ __launch_bounds__(768) void conv_wgrad_roll_kernel(WgradArgs a) {
+  using T = bf16_t;
+  constexpr int NT = 768;
+  constexpr int HH = TH + 2, HWD = TW + 2, HPX = HH * HWD;
+  constexpr int M = TH * TW;
+  constexpr bool SWZ = TH == 16;                       // unpadded XOR-swizzled 256-pixel tiles (see conv_wgrad_pipe_kernel)
+  static_assert(!SWZ || COT == 64, "swizzled 256-pixel tiles: 64 output channels");
+  static_assert(TW == 16, "k-step == one 16-pixel tile row");
+  constexpr int CT = 64, EPP = 8, PPR = 8, PB = SWZ ? 128 : 192;
+  constexpr int CJ = COT / 64;
+  constexpr int PA = SWZ ? COT * 2 : COT * 2 + 64;
+  constexpr int PPRA = COT / 8;
+  constexpr int A_BYTES = M * PA, B_BYTES = HPX * PB, BUF_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_PIECES = M * PPRA, B_PIECES = HPX * PPR;
+  constexpr int A_ROUNDS = (A_PIECES + NT - 1) / NT, B_ROUNDS = (B_PIECES + NT - 1) / NT, NPIECES = A_ROUNDS + B_ROUNDS;
+  static_assert(A_PIECES >= NT && B_PIECES >= NT, "a thread without a piece repeats its piece of the previous round");
+  static_assert(B_ROUNDS <= 8, "one nibble of edge bits per halo piece");
+  constexpr int A_PXR = NT / PPRA;                     // dz pixels per staging round: whole tile rows, an even number of pixel pairs
+  static_assert(A_PXR % TW == 0 && (A_PXR / 2) % 2 == 0, "a dz round = whole tile rows; the swizzle parity repeats per round");
+  constexpr int KSTEPS = M / 16;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tg = wave >> 2;                          // kernel row kh
+  const int wco = (wave >> 1) & 1, wci = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ci_tiles = a.Ci / CT;
+  int cb = blockIdx.x, split = blockIdx.y;
+#if IM2IM_WGRAD_XCD
+  if ((gridDim.y & 7) == 0) {                        // all channel blocks of one pixel split on ONE XCD (see conv_wgrad_pipe_kernel)
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, j = lin >> 3;
+    split = (j / (int)gridDim.x) * 8 + xcd;
+    cb = j % (int)gridDim.x;
+  }
+#endif
+  const int co0 = (cb / ci_tiles) * COT, ci0 = (cb % ci_tiles) * CT;
+  const WgradSrc<T> xs(a, ci0);
+  const T* __restrict__ xg = xs.x;
+  const T* __restrict__ dzg = reinterpret_cast<const T*>(a.dz) + co0;
+
+  f32x16 acc[CJ][3];
+#pragma unroll
+  for (int j = 0; j < CJ; ++j)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
+
+  const int q16 = lane & 15;
+  const int tr_col_b = (((lane >> 4) & 1) * 16 + (q16 & 3) * 4) * 2;
+  const int tr_row = q16 >> 2;
+
+  // ---- per-thread staging constants (computed once) ----
+  // dz: piece q = round * NT + tid -> pixel q / PPRA (a round = A_PXR / TW whole tile rows further down), 16-byte part q % PPRA.
+  // Rounds 0 .. A_ROUNDS-2 share ONE byte offset (the round's rows go into the instruction's scalar offset) and ONE LDS address
+  // (+ an immediate); a thread without a piece in the last round repeats its piece of the round before.
+  const int a_pix = tid / PPRA, a_part = tid % PPRA;
+  const int a_goff = ((a_pix / TW) * a.W + a_pix % TW) * a.Co * 2 + a_part * 16;               // bytes from the tile's first dz element
+  const int a_round_b = (A_PXR / TW) * a.W * a.Co * 2;                                         // bytes per round (uniform)
+  const int a_loff = a_pix * PA + (SWZ ? (a_part ^ (((a_pix >> 1) & 1) << 2)) : a_part) * 16;
+  constexpr bool A_WRAP = A_ROUNDS * NT > A_PIECES;
+  const int a_last = (A_WRAP && (A_ROUNDS - 1) * NT + tid >= A_PIECES) ? A_ROUNDS - 2 : A_ROUNDS - 1;   // round this thread stages last
+  const int a_goff_last = a_goff + a_last * a_round_b, a_loff_last = a_loff + a_last * A_PXR * PA;
+  // PARTIAL (H % TH or W % TW != 0: the 40x40 / 20x20 levels): tiles may hang over the image, so a piece's pixel (row << 16 | column,
+  // tile / halo coordinates) is compared with the tile's uniform limits on packed 16-bit halves instead of the edge nibbles
+  const int a_yx = ((a_pix / TW) << 16) | (a_pix % TW);
+  const int a_yx_last = a_yx + ((a_last * (A_PXR / TW)) << 16);
+  // x (halo): piece q -> halo pixel q / 8 (row q / 8 / 18, column q / 8 % 18), part q % 8; byte offset from the halo's first pixel
+  // (y0 - 1, x0 - 1), LDS address, and four edge bits (top row, bottom row, left column, right column of the halo)
+  int b_goff[B_ROUNDS], b_loff[B_ROUNDS], b_yx[PARTIAL ? B_ROUNDS : 1];
+  unsigned b_edge = 0;
+#pragma unroll
+  for (int i = 0; i < B_ROUNDS; ++i) {
+    int q = i * NT + tid;
+    if ((i + 1) * NT > B_PIECES && q >= B_PIECES) q -= NT;
+    const int pix = q / PPR, part = q % PPR, hy = pix / HWD, hx = pix % HWD;
+    b_goff[i] = ((hy * a.W + hx) * xs.stride + part * EPP) * 2;
+    b_loff[i] = A_BYTES + pix * PB + (SWZ ? (part ^ (((pix >> 1) & 1) << 2)) : part) * 16;
+    b_edge |= (unsigned)((hy == 0) | ((hy == HH - 1) << 1) | ((hx == 0) << 2) | ((hx == HWD - 1) << 3)) << (4 * i);
+    if constexpr (PARTIAL) b_yx[i] = (hy << 16) | hx;
+  }
+
+  // lazy BatchNorm coefficients of this thread's 8 channels as pairs: LDS behind the tile buffers (COT = 128: no registers
+  // left) or registers.  LAZY = some source of the launch has coefficients; with a split input this workgroup's 64 channels may
+  // come from the one that has none: scale 1, shift 0 and no ReLU then (wave-uniform mask, no branch)
+  constexpr bool SS_LDS = COT > 64;
+  f32x2 xsc[SS_LDS ? 1 : 4], xsh[SS_LDS ? 1 : 4];
+  float* ldsSS = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);
+  const bool lazy_x = LAZY && xs.sc != nullptr;
+  const int relu_keep = lazy_x ? 0 : (int)0x80008000;       // v_pk_max_i16(v, relu_floor): floor 0 = ReLU, floor -32768 = identity
+  if constexpr (LAZY) {
+    if constexpr (SS_LDS) {
+      if (tid < CT) { ldsSS[tid] = lazy_x ? xs.sc[tid] : 1.f; ldsSS[CT + tid] = lazy_x ? xs.sh[tid] : 0.f; }
+      __syncthreads();
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = (tid % PPR) * EPP + 2 * k;
+        xsc[k] = f32x2{lazy_x ? xs.sc[c] : 1.f, lazy_x ? xs.sc[c + 1] : 1.f};
+        xsh[k] = f32x2{lazy_x ? xs.sh[c] : 0.f, lazy_x ? xs.sh[c + 1] : 0.f};
+      }
+    }
+  }
+
+  // ---- tile walk (wave-uniform) ----
+  struct Pos { int tx, ty, b; };
+  auto pos_of = [&](int t) __attribute__((always_inline)) -> Pos { Pos p; p.tx = t % a.tilesX; t /= a.tilesX; p.ty = t % a.tilesY; p.b = t / a.tilesY; return p; };
+  auto advance = [&](Pos p, bool go) __attribute__((always_inline)) -> Pos {       // the next tile if go, else the same one; no branches
+    const int wx = (p.tx + 1 == a.tilesX), wy = wx & (p.ty + 1 == a.tilesY);
+    Pos n;
+    n.tx = wx ? 0 : p.tx + 1;
+    n.ty = wy ? 0 : p.ty + wx;
+    n.b = p.b + wy;
+    n.tx = go ? n.tx : p.tx; n.ty = go ? n.ty : p.ty; n.b = go ? n.b : p.b;
+    return n;
+  };
+  // PARTIAL: inside <=> lo <= yx < hi on both halves: (yx - hi) negative and (yx - lo) non-negative per half
+  auto outside = [&](int yx, int lo, int hi) __attribute__((always_inline)) -> bool {
+    const s16x2 d1 = __builtin_bit_cast(s16x2, yx) - __builtin_bit_cast(s16x2, hi), d2 = __builtin_bit_cast(s16x2, yx) - __builtin_bit_cast(s16x2, lo);
+    return ((__builtin_bit_cast(int, d1) & ~__builtin_bit_cast(int, d2)) & (int)0x80008000) != (int)0x80008000;
+  };
+  struct Src { __amdgpu_buffer_rsrc_t dz, x; unsigned bad; int a_hi, b_lo, b_hi; };   // descriptors based at the tile's first dz element / first halo pixel; bad: nibble i != 0 <=> halo piece i lies outside the image
+  auto src_of = [&](Pos p) __attribute__((always_inline)) -> Src {
+    const int y0 = p.ty * TH, x0 = p.tx * TW;
+    const T* dzb = dzg + (((size_t)p.b * a.H + y0) * a.W + x0) * a.Co;
+    const T* xb = xg + (((ptrdiff_t)p.b * a.H + y0 - 1) * a.W + x0 - 1) * (ptrdiff_t)xs.stride;     // may lie in front of the tensor: those pieces are "bad"
+    const unsigned em = (unsigned)((y0 == 0) | ((y0 + TH == a.H) << 1) | ((x0 == 0) << 2) | ((x0 + TW == a.W) << 3));
+    Src s;
+    s.dz = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dzb), 0, 0x7fffffff, 0x00020000);
+    s.x = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xb), 0, 0x7fffffff, 0x00020000);
+    s.bad = b_edge & (em * 0x11111111u);
+    s.a_hi = (min(a.H - y0, 0x7fff) << 16) | min(a.W - x0, 0x7fff);                  // dz pixel (row, column) limits of the tile
+    s.b_lo = ((y0 == 0) << 16) | (x0 == 0);                                          // halo pixel limits (halo coordinates = tile + 1)
+    s.b_hi = (min(a.H - y0 + 1, 0x7fff) << 16) | min(a.W - x0 + 1, 0x7fff);
+    return s;
+  };
+  struct Stage { i32x4 v[NPIECES]; };                  // one tile in flight
+  auto gload_piece = [&](const Src& s, Stage& R, auto p_tag) __attribute__((always_inline)) {
+    constexpr int p = decltype(p_tag)::value;
+    if constexpr (p < A_ROUNDS - 1) {
+      int off = a_goff;
+      if constexpr (PARTIAL) off = outside(a_yx + ((p * (A_PXR / TW)) << 16), 0, s.a_hi) ? -1 : off;
+      R.v[p] = __builtin_amdgcn_raw_buffer_load_b128(s.dz, off, p * a_round_b, 0);
+    } else if constexpr (p == A_ROUNDS - 1) {
+      int off = a_goff_last;
+      if constexpr (PARTIAL) off = outside(a_yx_last, 0, s.a_hi) ? -1 : off;
+      R.v[p] = __builtin_amdgcn_raw_buffer_load_b128(s.dz, off, 0, 0);
+    } else {
+      constexpr int i = p - A_ROUNDS;
+      bool bad;
+      if constexpr (PARTIAL) bad = outside(b_yx[i], s.b_lo, s.b_hi); else bad = (s.bad >> (4 * i)) & 15u;
+      const int off = bad ? -1 : b_goff[i];                              // 0xffffffff >= num_records: the load returns zeros
+      R.v[p] = __builtin_amdgcn_raw_buffer_load_b128(s.x, off, 0, 0);
+    }
+  };
+  struct Edge { unsigned bad; int b_lo, b_hi; };      // what swrite_piece needs of the tile it writes: which halo pieces are padding
+  auto swrite_piece = [&](int bufoff, const Edge& e, const Stage& R, auto p_tag) __attribute__((always_inline)) {
+    constexpr int p = decltype(p_tag)::value;
+    i32x4 v = R.v[p];
+    if constexpr (p < A_ROUNDS - 1) {
+      *reinterpret_cast<i32x4*>(smem + bufoff + a_loff + p * A_PXR * PA) = v;
+    } else if constexpr (p == A_ROUNDS - 1) {
+      *reinterpret_cast<i32x4*>(smem + bufoff + a_loff_last) = v;
+    } else {
+      constexpr int i = p - A_ROUNDS;
+      if constexpr (LAZY) {
+        f32x2 sc[4], sh[4];
+        if constexpr (SS_LDS) {
+          const int c0 = (tid % PPR) * EPP;
+          const float4 s0 = *reinterpret_cast<const float4*>(ldsSS + c0), s1 = *reinterpret_cast<const float4*>(ldsSS + c0 + 4);
+          const float4 h0 = *reinterpret_cast<const float4*>(ldsSS + CT + c0), h1 = *reinterpret_cast<const float4*>(ldsSS + CT + c0 + 4);
+          sc[0] = f32x2{s0.x, s0.y}; sc[1] = f32x2{s0.z, s0.w}; sc[2] = f32x2{s1.x, s1.y}; sc[3] = f32x2{s1.z, s1.w};
+          sh[0] = f32x2{h0.x, h0.y}; sh[1] = f32x2{h0.z, h0.w}; sh[2] = f32x2{h1.x, h1.y}; sh[3] = f32x2{h1.z, h1.w};
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { sc[k] = xsc[k]; sh[k] = xsh[k]; }
+        }
+        bool bad;
+        if constexpr (PARTIAL) bad = outside(b_yx[i], e.b_lo, e.b_hi); else bad = (e.bad >> (4 * i)) & 15u;
+        const int keep = bad ? 0 : -1;                                  // zero padding stays exactly zero (not max(shift, 0))
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned u = (unsigned)v[k];
+          f32x2 f = f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+          f = f * sc[k];
+          f = f + sh[k];
+          const bf16_t lo = (bf16_t)f[0], hi = (bf16_t)f[1];
+          const unsigned r = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+          const s16x2 m = __builtin_elementwise_max(__builtin_bit_cast(s16x2, r), __builtin_bit_cast(s16x2, relu_keep));
+          v[k] = __builtin_bit_cast(int, m) & keep;
+        }
+      }
+      *reinterpret_cast<i32x4*>(smem + bufoff + b_loff[i]) = v;
+    }
+  };
+
+  const int t_begin = split * a.tiles_per_split;
+  const int t_end = min(t_begin + a.tiles_per_split, a.ntiles);
+  if (t_begin < t_end) {
+    Stage R;
+    Pos pos = pos_of(t_begin);
+    Edge ew;                                            // edges of the tile whose pieces are written next
+    {
+      const Src s0 = src_of(pos);
+      static_for<0, NPIECES>([&](auto p_tag) __attribute__((always_inline)) { gload_piece(s0, R, p_tag); });
+      const Edge e0{s0.bad, s0.b_lo, s0.b_hi};
+      static_for<0, NPIECES>([&](auto p_tag) __attribute__((always_inline)) { swrite_piece(0, e0, R, p_tag); });
+      pos = advance(pos, t_begin + 1 < t_end);
+      const Src s1 = src_of(pos);
+      static_for<0, NPIECES>([&](auto p_tag) __attribute__((always_inline)) { gload_piece(s1, R, p_tag); });
+      ew = Edge{s1.bad, s1.b_lo, s1.b_hi};
+    }
+    __syncthreads();
+    int curoff = 0;
+    for (int t = t_begin; t < t_end; ++t) {
+      pos = advance(pos, t + 2 < t_end);
+      const Src s2 = src_of(pos);                        // tile t+2 (the last tile again at the end of the split)
+      const int nxtoff = BUF_BYTES - curoff;
+      const char* la = smem + curoff;
+      const char* lb = la + A_BYTES + tg * HWD * PB;           // this wave's kernel row
+      const char* pa = la + (half * 8 + tr_row) * PA + (SWZ ? ((wco ^ ((tr_row >> 1) & 1)) << 6) : wco * (COT / 2) * 2) + tr_col_b;
+      const char* pb = lb + (half * 8 + tr_row) * PB + (SWZ ? 0 : wci * 64 + tr_col_b);
+      int xo[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xo[j] = SWZ ? (((wci ^ (((((j + 2 * tg) & 3) + tr_row) >> 1) & 1)) << 6) + tr_col_b) : 0;
+      short8 fa[2][CJ], fb[2];
+#pragma unroll
+      for (int j = 0; j < CJ; ++j) fa[0][j] = WFrag<bf16_t>::load(pa + j * 64, pa + j * 64 + 4 * PA);
+      fb[0] = WFrag<bf16_t>::load(pb + xo[0], pb + xo[0] + 4 * PB);
+      static_for<0, KSTEPS * 3>([&](auto u_tag) __attribute__((always_inline)) {
+        constexpr int u = decltype(u_tag)::value, ks = u / 3, kw = u % 3, n = u + 1, nks = n / 3, nkw = n % 3;
+        if constexpr (n < KSTEPS * 3) {
+          if constexpr (nkw == 0) {
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) fa[nks & 1][j] = WFrag<bf16_t>::load(pa + j * 64 + nks * 16 * PA, pa + j * 64 + (nks * 16 + 4) * PA);
+          }
+          const int xj = xo[(2 * nks + nkw) & 3];
+          fb[n & 1] = WFrag<bf16_t>::load(pb + xj + (nks * HWD + nkw) * PB, pb + xj + (nks * HWD + nkw + 4) * PB);
+          __builtin_amdgcn_sched_group_barrier(0x100, nkw == 0 ? 2 * CJ + 2 : 2, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) acc[j][kw] = WFrag<bf16_t>::mfma(fa[ks & 1][j], fb[u & 1], acc[j][kw]);
+        __builtin_amdgcn_sched_group_barrier(0x008, CJ, 0);
+        if constexpr (kw == 2) {
+          static_for<0, NPIECES>([&](auto p_tag) __attribute__((always_inline)) {
+            constexpr int p = decltype(p_tag)::value;
+            if constexpr ((2 * p + 1) * KSTEPS / (2 * NPIECES) == ks) {
+              // SALU, MFMA and ds_read instructions may cross these two fences; ds_write, buffer_load and VALU (the transform of a
+              // piece that has not arrived would pull its wait forward) may not: left alone the scheduler collects every
+              // request at the end of the tile, a quarter period ahead of its use
+              __builtin_amdgcn_sched_barrier(0x10c);
+              swrite_piece(nxtoff, ew, R, p_tag);      // tile t+1
+              gload_piece(s2, R, p_tag);               // tile t+2
+              __builtin_amdgcn_sched_barrier(0x10c);
+            }
+          });
+        }
+      });
+      ew = Edge{s2.bad, s2.b_lo, s2.b_hi};
+      __syncthreads();
+      curoff = nxtoff;
+    }
+  }
+  float* out = a.partial + (size_t)split * a.Co * 9 * a.Ci;
+#pragma unroll
+  for (int j = 0; j < CJ; ++j)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wco * (COT / 2) + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int ci = ci0 + wci * 32 + l31;
+        out[((size_t)co * 9 + tg * 3 + kw) * a.Ci + ci] = acc[j][kw][r];
       }
 }
 
@@ -859,6 +1296,7 @@ __global__ __launch_bounds__(256) void pack_weight_frag_multi_kernel(PackMultiAr
 namespace {
 int g_wgrad_co128 = 1;      // A/B switch (im2im_set_option "wgrad_co128")
 int g_wgrad_tile16 = 1;     // A/B switch "wgrad_tile16": 256-pixel tiles for the 64-output-channel form
+int g_wgrad_roll = 1;       // A/B switch "wgrad_roll": conv_wgrad_roll_kernel (rolling operand prefetch, staging spread over the MFMA phase)
 template <typename T, int TAPS>
 int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float* x_ss_hi, int Ci_lo, const void* dz, float* partial,
                  int64_t partial_bytes, float* dw, int B, int H, int W, int Ci, int Co, hipStream_t stream) {
@@ -892,10 +1330,19 @@ int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float
       a.tiles_per_split = (int)cdiv(a.ntiles, nsplit);
       nsplit = cdiv(a.ntiles, a.tiles_per_split);
       constexpr size_t smem128 = 2 * ((size_t)TH * TW * (128 * 2 + 64) + (size_t)(TH + 2) * (TW + 2) * 192) + 512;
-      auto kern = conv_wgrad_pipe_kernel<TH, TW, 128>;
+      const bool lazy = x_ss != nullptr || x_ss_hi != nullptr;
+      const bool roll = g_wgrad_roll && (int64_t)(H + 16) * W * std::max(Ci, Co) * 2 < (1ll << 31);   // 32-bit byte offsets within an image
+      const bool partial = H % TH != 0 || W % TW != 0;                                             // tiles hang over the image
+      auto kern = !roll ? conv_wgrad_pipe_kernel<TH, TW, 128>
+                  : partial ? (lazy ? conv_wgrad_roll_kernel<TH, TW, 128, true, true> : conv_wgrad_roll_kernel<TH, TW, 128, false, true>)
+                            : (lazy ? conv_wgrad_roll_kernel<TH, TW, 128, true, false> : conv_wgrad_roll_kernel<TH, TW, 128, false, false>);
       static bool attr_set = false;
       if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem128);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_pipe_kernel<TH, TW, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem128);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_roll_kernel<TH, TW, 128, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem128);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_roll_kernel<TH, TW, 128, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem128);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_roll_kernel<TH, TW, 128, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem128);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_roll_kernel<TH, TW, 128, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem128);
         attr_set = true;
       }
       hipLaunchKernelGGL(kern, dim3((unsigned)cb128, (unsigned)nsplit), dim3(768), smem128, stream, a);
@@ -909,10 +1356,19 @@ int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float
       a16.tiles_per_split = (int)cdiv(a16.ntiles, nsplit);
       nsplit = cdiv(a16.ntiles, a16.tiles_per_split);
       constexpr size_t smem16 = 2 * ((size_t)16 * 16 * 128 + (size_t)18 * 18 * 128);
-      auto kern = conv_wgrad_pipe_kernel<16, 16, 64>;
+      const bool lazy = x_ss != nullptr || x_ss_hi != nullptr;
+      const bool roll = g_wgrad_roll && Co % 64 == 0 && (int64_t)(H + 16) * W * std::max(Ci, Co) * 2 < (1ll << 31);
+      const bool partial = H % 16 != 0 || W % 16 != 0;
+      auto kern = !roll ? conv_wgrad_pipe_kernel<16, 16, 64>
+                  : partial ? (lazy ? conv_wgrad_roll_kernel<16, 16, 64, true, true> : conv_wgrad_roll_kernel<16, 16, 64, false, true>)
+                            : (lazy ? conv_wgrad_roll_kernel<16, 16, 64, true, false> : conv_wgrad_roll_kernel<16, 16, 64, false, false>);   // (the roll kernel has no output-channel masking)
       static bool attr_set = false;
       if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_pipe_kernel<16, 16, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_roll_kernel<16, 16, 64, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_roll_kernel<16, 16, 64, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_roll_kernel<16, 16, 64, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_roll_kernel<16, 16, 64, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem16);
         attr_set = true;
       }
       hipLaunchKernelGGL(kern, dim3((unsigned)cblocks, (unsigned)nsplit), dim3(768), smem16, stream, a16);
@@ -1009,6 +1465,7 @@ extern "C" int im2im_set_option(const char* key, int32_t value) {
   if (std::string(key) == "conv_splitk") { im2im::set_conv_splitk(value); return IM2IM_OK; }
   if (std::string(key) == "wgrad_co128") { g_wgrad_co128 = value; return IM2IM_OK; }
   if (std::string(key) == "wgrad_tile16") { g_wgrad_tile16 = value; return IM2IM_OK; }
+  if (std::string(key) == "wgrad_roll") { g_wgrad_roll = value; return IM2IM_OK; }
   if (std::string(key) == "bn_fused_small") { im2im::set_bn_fused_small(value); return IM2IM_OK; }
   return im2im::fail_invalid("unknown option");
 }

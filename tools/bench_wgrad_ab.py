@@ -26,7 +26,7 @@ for (h, ci, co, split) in LAYERS:
     dz = torch.randn(B, h, h, co, device=dev, generator=g).to(torch.bfloat16)
     ss = torch.stack([torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev)]).contiguous()
     fl = 2.0 * B * h * h * ci * co * 9
-    fn = lambda: nn_ops.conv_wgrad(x, dz, 9, x_ss=ss, x_hi=xh)
+    fn = lambda: nn_ops.conv_wgrad(x, dz, 9, x_ss=None if os.environ.get('BENCH_NOLAZY') else ss, x_hi=xh)
     times = {m: [] for m in MODES}
     outs = {}
     for m in MODES:
