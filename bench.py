@@ -106,8 +106,9 @@ CONFIGS = {
                       size=32, n_in=1, depth=2, batch=32, calib_total=64, num_lambdas=50, lam=(0.0, 6.0), dtype="bf16"),
     "temca1024": dict(label="TEMCA2-shaped 1024x1024 tiles, 5-level (deeper) UNet (BASELINE configs[3])",
                       size=1024, n_in=1, depth=5, batch=4, calib_total=256, num_lambdas=100, lam=(7.0, 10.0), dtype="bf16"),
-    "bsbcm512": dict(label="BSBCM-shaped 512x512, 2 input channels, 4-level UNet (BASELINE configs[4]; dtype fp8 = e4m3 / e5m2 operands in the forward, "
-                           "data-gradient and weight-gradient 3x3 convs of the layers with >= 128 input channels, everything else bf16)",
+    "bsbcm512": dict(label="BSBCM-shaped 512x512, 2 input channels, 4-level UNet (BASELINE configs[4]; dtype fp8 = e4m3 / e5m2 operands in the forward and "
+                           "data-gradient 3x3 convs of the layers with >= 128 input channels, everything else bf16 -- the weight gradients too: the bf16 "
+                           "kernel is the faster one since round 4, the fp8 one is behind IM2IM_FP8_WGRAD=1)",
                      size=512, n_in=2, depth=4, batch=16, calib_total=256, num_lambdas=2000, lam=(0.0, 6.0), dtype="fp8"),
 }
 
@@ -397,7 +398,7 @@ def roofline_leg(wl, config_name, full=True):
         roof_fp8 = dict(_agg(f8, PEAK_FP8_TFLOPS), kernel="conv_fp8_kernel (3x3 convs with e4m3 / e5m2 operands)")
         roof_dgrad = dict(roof, kernel="conv_igemm_kernel (bf16: the launches the fp8 kernels do not cover)")
         roof = roof_fp8
-    roof_w = dict(_agg(wg, peak), kernel="conv_wgrad_kernel (+ its split-K reduce)") if wg else None
+    roof_w = dict(_agg(wg, peak), kernel="conv_wgrad_roll_kernel / conv_wgrad_pipe_kernel (3x3) + conv_wgrad_kernel (1x1) + their split-K reduce") if wg else None
     if wg8 and roof_w is not None:      # fp8 mode: the eligible layers' weight gradients run on the block-scaled MFMA -> priced against ITS peak
         roof_w["fp8_launches"] = dict(_agg(wg8, PEAK_FP8_TFLOPS), kernel="conv_wgrad_fp8_kernel (e5m2 dz x e4m3 input, + its split-K reduce)")
     if not full:

@@ -10,11 +10,14 @@
 #ifndef IM2IM_WGRAD_ABL      // measurement-only: bit 0 = no global loads after the first tile, bit 1 = no LDS writes, bit 2 = no MFMA phase, bit 3 = loads of the same (cache-hot) tile, bit 4 = the dz half of the staging only for the first tile
 #define IM2IM_WGRAD_ABL 0
 #endif
-#ifndef IM2IM_WGRAD_ROLL     // 1 = rolling operand prefetch in the MFMA phase + staging spread over it (conv_wgrad_pipe_kernel)
-#define IM2IM_WGRAD_ROLL 0
+#ifndef IM2IM_ROLL_DIST      // conv_wgrad_roll_kernel: operand prefetch distance in units (1 .. 3; measured 1,076 / 1,098 / 1,066 TF over the 13 layers)
+#define IM2IM_ROLL_DIST 2
 #endif
-#ifndef IM2IM_WGRAD_MID      // 0 = tile t+1 staged after the MFMAs of tile t; n = after k-step n/8 of them (see conv_wgrad_pipe_kernel)
-#define IM2IM_WGRAD_MID 0
+#ifndef IM2IM_ROLL_PIN       // ... sched_group_barrier pins "reads, then MFMAs" per unit
+#define IM2IM_ROLL_PIN 1
+#endif
+#ifndef IM2IM_ROLL_SLOT      // ... where a tile's staging pieces go: 0 = spread over the k-steps, 1 = first half, 2 = second half
+#define IM2IM_ROLL_SLOT 0
 #endif
 #include <string>
 #include <type_traits>
@@ -451,115 +454,12 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
     }
   };
 
-#if IM2IM_WGRAD_ROLL
-  // MFMA phase with a ROLLING operand prefetch: the fragments of unit u+1 (unit = one (k-step, kw): CJ MFMAs on one x fragment) are
-  // requested before the MFMAs of unit u are issued, so a wave's LDS latency runs under its own MFMAs instead of only under the
-  // other two waves of its SIMD (the compiler's own order is read -> s_waitcnt lgkmcnt(0) -> two MFMAs).  hook(k-step) runs after a
-  // k-step's last MFMAs were issued (the staging of the next tile, spread over the phase).
-  auto compute_roll = [&](int buf, auto&& hook) __attribute__((always_inline)) {
-    const char* la = smem + buf * BUF_BYTES;
-    const char* lb = la + A_BYTES + tg * HWD * PB;
-    const char* pa = la + (half * 8 + tr_row) * PA + (SWZ ? ((wco ^ ((tr_row >> 1) & 1)) << 6) : wco * (COT / 2) * 2) + tr_col_b;
-    const char* pb = lb + (half * 8 + tr_row) * PB + (SWZ ? 0 : wci * 64 + tr_col_b);
-    int xo[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) xo[j] = SWZ ? (((wci ^ (((((j + 2 * tg) & 3) + tr_row) >> 1) & 1)) << 6) + tr_col_b) : 0;
-    short8 fa[2][CJ], fb[2];
-#pragma unroll
-    for (int j = 0; j < CJ; ++j) fa[0][j] = WFrag<bf16_t>::load(pa + j * 64, pa + j * 64 + 4 * PA);
-    fb[0] = WFrag<bf16_t>::load(pb + xo[0], pb + xo[0] + 4 * PB);
-    static_for<0, KSTEPS * 3>([&](auto u_tag) __attribute__((always_inline)) {
-      constexpr int u = decltype(u_tag)::value, ks = u / 3, kw = u % 3, n = u + 1, nks = n / 3, nkw = n % 3;
-      if constexpr (n < KSTEPS * 3) {
-        if constexpr (nkw == 0) {
-#pragma unroll
-          for (int j = 0; j < CJ; ++j) fa[nks & 1][j] = WFrag<bf16_t>::load(pa + j * 64 + nks * 16 * PA, pa + j * 64 + (nks * 16 + 4) * PA);
-        }
-        const int xj = xo[(2 * nks + nkw) & 3];
-        fb[n & 1] = WFrag<bf16_t>::load(pb + xj + (nks * HWD + nkw) * PB, pb + xj + (nks * HWD + nkw + 4) * PB);
-        __builtin_amdgcn_sched_group_barrier(0x100, nkw == 0 ? 2 * CJ + 2 : 2, 0);
-      }
-#pragma unroll
-      for (int j = 0; j < CJ; ++j) acc[j][kw] = WFrag<bf16_t>::mfma(fa[ks & 1][j], fb[u & 1], acc[j][kw]);
-      __builtin_amdgcn_sched_group_barrier(0x008, CJ, 0);
-      if constexpr (kw == 2) hook(std::integral_constant<int, ks>{});
-    });
-  };
-#endif
-
   const int t_begin = split * a.tiles_per_split;
   const int t_end = min(t_begin + a.tiles_per_split, a.ntiles);
   if (t_begin < t_end) {
     Stage R;
     gload(t_begin, R);
     swrite(0, R);
-#if IM2IM_WGRAD_ROLL
-    // rolling operand prefetch + staging spread over the MFMA phase (see IM2IM_WGRAD_MID == 9 below)
-    if (t_begin + 1 < t_end) gload(t_begin + 1, R);
-    __syncthreads();
-    int cur = 0;
-    for (int t = t_begin; t < t_end; ++t) {
-      const bool more1 = t + 1 < t_end, more2 = t + 2 < t_end;
-      const TilePos tp2 = tile_pos(more2 ? t + 2 : t);
-      compute_roll(cur, [&](auto ks_tag) __attribute__((always_inline)) {
-        constexpr int ks = decltype(ks_tag)::value;
-        static_for<0, NPIECES>([&](auto p_tag) __attribute__((always_inline)) {
-          constexpr int p = decltype(p_tag)::value;
-          if constexpr ((2 * p + 1) * KSTEPS / (2 * NPIECES) == ks) {
-            if (more1) swrite_piece(cur ^ 1, R, p);
-            if (more2) gload_piece(tp2, R, p);
-          }
-        });
-      });
-      __syncthreads();
-      cur ^= 1;
-    }
-#elif IM2IM_WGRAD_MID == 9
-    // Staging SPREAD over a tile's MFMA phase: after k-step slot(p) of tile t, this thread's piece p of tile t+1 (requested at the same
-    // point of tile t-1: one whole tile period in flight) goes to the other LDS buffer and the request for its piece p of tile
-    // t+2 follows at once -- a handful of transform / ds_write / address instructions between two k-steps' MFMAs instead of a
-    // staging phase of all twelve waves in front of the barrier, which is followed by MFMA work at once.  Same registers (a piece's
-    // registers are live for one period either way), same LDS, same arithmetic.
-    if (t_begin + 1 < t_end) gload(t_begin + 1, R);
-    __syncthreads();
-    int cur = 0;
-    for (int t = t_begin; t < t_end; ++t) {
-      const bool more1 = t + 1 < t_end, more2 = t + 2 < t_end;
-      const TilePos tp2 = tile_pos(more2 ? t + 2 : t);
-      static_for<0, KSTEPS>([&](auto ks_tag) __attribute__((always_inline)) {
-        constexpr int ks = decltype(ks_tag)::value;
-        compute(cur, std::integral_constant<int, ks>{}, std::integral_constant<int, ks + 1>{});
-        static_for<0, NPIECES>([&](auto p_tag) __attribute__((always_inline)) {
-          constexpr int p = decltype(p_tag)::value;
-          if constexpr ((2 * p + 1) * KSTEPS / (2 * NPIECES) == ks) {
-            if (more1) swrite_piece(cur ^ 1, R, p);
-            if (more2) gload_piece(tp2, R, p);
-          }
-        });
-      });
-      __syncthreads();
-      cur ^= 1;
-    }
-#elif IM2IM_WGRAD_MID
-    // Staging in the MIDDLE of a tile's MFMA phase: tile t+1 (requested one whole tile period earlier) goes to the other LDS buffer
-    // after k-step MIDK of tile t and the request for tile t+2 follows it, so the transform + ds_write instructions of one wave run
-    // beside the other waves' MFMAs instead of all twelve waves staging together in front of the barrier, and the barrier is
-    // followed by MFMA work at once.  Same registers, same LDS, same arithmetic.
-    constexpr int MIDK = KSTEPS * IM2IM_WGRAD_MID / 8;
-    if (t_begin + 1 < t_end) gload(t_begin + 1, R);
-    __syncthreads();
-    int cur = 0;
-    for (int t = t_begin; t < t_end; ++t) {
-      compute(cur, std::integral_constant<int, 0>{}, std::integral_constant<int, MIDK>{});
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < t_end) swrite(cur ^ 1, R);
-      if (t + 2 < t_end) gload(t + 2, R);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(cur, std::integral_constant<int, MIDK>{}, std::integral_constant<int, KSTEPS>{});
-      __syncthreads();
-      cur ^= 1;
-    }
-#else
     __syncthreads();
     int cur = 0;
     for (int t = t_begin; t < t_end; ++t) {
@@ -578,7 +478,6 @@ __global__ __launch_bounds__(768) void conv_wgrad_pipe_kernel(WgradArgs a) {
       __syncthreads();
       cur ^= 1;
     }
-#endif
   }
   float* out = a.partial + (size_t)split * a.Co * 9 * a.Ci;
 #pragma unroll
@@ -846,28 +745,37 @@ __global__ __launch_bounds__(768) void conv_wgrad_roll_kernel(WgradArgs a) {
       int xo[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) xo[j] = SWZ ? (((wci ^ (((((j + 2 * tg) & 3) + tr_row) >> 1) & 1)) << 6) + tr_col_b) : 0;
-      short8 fa[2][CJ], fb[2];
-#pragma unroll
-      for (int j = 0; j < CJ; ++j) fa[0][j] = WFrag<bf16_t>::load(pa + j * 64, pa + j * 64 + 4 * PA);
-      fb[0] = WFrag<bf16_t>::load(pb + xo[0], pb + xo[0] + 4 * PB);
-      static_for<0, KSTEPS * 3>([&](auto u_tag) __attribute__((always_inline)) {
-        constexpr int u = decltype(u_tag)::value, ks = u / 3, kw = u % 3, n = u + 1, nks = n / 3, nkw = n % 3;
-        if constexpr (n < KSTEPS * 3) {
+      // operand ring: the fragments of unit u + DIST are requested before the MFMAs of unit u issue
+      constexpr int DIST = IM2IM_ROLL_DIST, NU = KSTEPS * 3;
+      static_assert(DIST >= 1 && DIST <= 3, "the x ring holds DIST + 1 fragments, the dz ring two k-steps");
+      short8 fa[2][CJ], fb[DIST + 1];
+      auto req = [&](auto n_tag) __attribute__((always_inline)) {                  // request the fragments unit n needs
+        constexpr int n = decltype(n_tag)::value, nks = n / 3, nkw = n % 3;
+        if constexpr (n < NU) {
           if constexpr (nkw == 0) {
 #pragma unroll
             for (int j = 0; j < CJ; ++j) fa[nks & 1][j] = WFrag<bf16_t>::load(pa + j * 64 + nks * 16 * PA, pa + j * 64 + (nks * 16 + 4) * PA);
           }
           const int xj = xo[(2 * nks + nkw) & 3];
-          fb[n & 1] = WFrag<bf16_t>::load(pb + xj + (nks * HWD + nkw) * PB, pb + xj + (nks * HWD + nkw + 4) * PB);
-          __builtin_amdgcn_sched_group_barrier(0x100, nkw == 0 ? 2 * CJ + 2 : 2, 0);
+          fb[n % (DIST + 1)] = WFrag<bf16_t>::load(pb + xj + (nks * HWD + nkw) * PB, pb + xj + (nks * HWD + nkw + 4) * PB);
         }
+      };
+      static_for<0, DIST>([&](auto n_tag) __attribute__((always_inline)) { req(n_tag); });
+      static_for<0, NU>([&](auto u_tag) __attribute__((always_inline)) {
+        constexpr int u = decltype(u_tag)::value, ks = u / 3, kw = u % 3, n = u + DIST;
+        req(std::integral_constant<int, n>{});
+#if IM2IM_ROLL_PIN
+        if constexpr (n < NU) __builtin_amdgcn_sched_group_barrier(0x100, n % 3 == 0 ? 2 * CJ + 2 : 2, 0);
+#endif
 #pragma unroll
-        for (int j = 0; j < CJ; ++j) acc[j][kw] = WFrag<bf16_t>::mfma(fa[ks & 1][j], fb[u & 1], acc[j][kw]);
+        for (int j = 0; j < CJ; ++j) acc[j][kw] = WFrag<bf16_t>::mfma(fa[ks & 1][j], fb[u % (DIST + 1)], acc[j][kw]);
+#if IM2IM_ROLL_PIN
         __builtin_amdgcn_sched_group_barrier(0x008, CJ, 0);
+#endif
         if constexpr (kw == 2) {
           static_for<0, NPIECES>([&](auto p_tag) __attribute__((always_inline)) {
             constexpr int p = decltype(p_tag)::value;
-            if constexpr ((2 * p + 1) * KSTEPS / (2 * NPIECES) == ks) {
+            if constexpr ((IM2IM_ROLL_SLOT == 0 ? (2 * p + 1) * KSTEPS / (2 * NPIECES) : IM2IM_ROLL_SLOT == 1 ? p * KSTEPS / (2 * NPIECES) : KSTEPS - 1 - (NPIECES - 1 - p) * KSTEPS / (2 * NPIECES)) == ks) {
               // SALU, MFMA and ds_read instructions may cross these two fences; ds_write, buffer_load and VALU (the transform of a
               // piece that has not arrived would pull its wait forward) may not: left alone the scheduler collects every
               // request at the end of the tile, a quarter period ahead of its use

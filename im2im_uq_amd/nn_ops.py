@@ -304,7 +304,11 @@ def packed_fp8(weight: torch.Tensor, want_dgrad: bool):
 
 
 FP8_DGRAD = os.environ.get("IM2IM_FP8_DGRAD", "1") != "0"     # fp8 mode: data-gradients on the fp8 kernel too (e5m2 operand)
-FP8_WGRAD = os.environ.get("IM2IM_FP8_WGRAD", "1") != "0"     # [r4] ... and the weight gradients of those layers (e5m2 dz x e4m3 input)
+# [r4] ... and, on request, the weight gradients of those layers (e5m2 dz x e4m3 input, conv_wgrad_fp8_kernel).  Off by default since
+# conv_wgrad_roll_kernel: the bf16 weight gradient is now the faster one on 9 of the 11 eligible layer shapes (6.98 vs 7.61 ms over
+# them at batch 78, profiles/r04_ab_experiments.txt section 20) -- the fp8 kernel converts bf16 operands on the fly and is bound by
+# those VALU instructions, not by its MFMAs
+FP8_WGRAD = os.environ.get("IM2IM_FP8_WGRAD", "0") != "0"
 
 
 _fp8_grad_scales = WeakTensorKeyDictionary()        # conv weight -> Fp8GradScale; NOT an attribute of the Parameter: Parameter.__reduce_ex__
