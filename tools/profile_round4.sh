@@ -3,7 +3,7 @@
 #   default bench line; rocprofv3 kernel stats of the train leg (overlapped = as timed, and isolated = weight-gradient stream
 #   off), of the calibration leg, of the batch-10 step (isolated); PMC FETCH_SIZE / WRITE_SIZE passes (each alone with
 #   --kernel-trace) for the calibration and conv kernels; SQ MFMA-busy / LDS counters of the conv kernels on two layer shapes.
-tag=${1:-r04}
+tag=${1:-r04}   # (evidence files are named per round; a re-run inside the round overwrites them)
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
