@@ -18,7 +18,7 @@ for f in glob.glob(os.path.join(root, "gpurun_out", f"{tag}_pmc_sq", "p*", "**",
     b, h, w, ci, co = shape.split(",")
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        fam = "conv_igemm" if "conv_igemm" in k else "conv_wgrad_pipe" if "conv_wgrad_pipe" in k else None
+        fam = "conv_igemm" if "conv_igemm" in k else "conv_wgrad_roll" if "conv_wgrad_roll" in k else "conv_wgrad_pipe" if "conv_wgrad_pipe" in k else None
         if fam:
             d[f"{fam} {ci}->{co} @{h}x{w} B{b}"][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {"note": "rocprofv3 --pmc passes of tools/profile_round4.sh over tools/bench_conv.py (--kernel-trace only, one counter group per pass): MFMA "
