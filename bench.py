@@ -107,8 +107,8 @@ CONFIGS = {
     "temca1024": dict(label="TEMCA2-shaped 1024x1024 tiles, 5-level (deeper) UNet (BASELINE configs[3])",
                       size=1024, n_in=1, depth=5, batch=4, calib_total=256, num_lambdas=100, lam=(7.0, 10.0), dtype="bf16"),
     "bsbcm512": dict(label="BSBCM-shaped 512x512, 2 input channels, 4-level UNet (BASELINE configs[4]; dtype fp8 = e4m3 / e5m2 operands in the forward and "
-                           "data-gradient 3x3 convs of the layers with >= 128 input channels, everything else bf16 -- the weight gradients too: the bf16 "
-                           "kernel is the faster one since round 4, the fp8 one is behind IM2IM_FP8_WGRAD=1)",
+                           "data-gradient 3x3 convs of the layers with >= 128 input channels, and in the weight gradients of those with 64 output "
+                           "channels -- elsewhere the bf16 weight-gradient kernel is as fast or faster, IM2IM_FP8_WGRAD=1 forces fp8; everything else bf16)",
                      size=512, n_in=2, depth=4, batch=16, calib_total=256, num_lambdas=2000, lam=(0.0, 6.0), dtype="fp8"),
 }
 

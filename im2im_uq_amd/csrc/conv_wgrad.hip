@@ -1047,6 +1047,294 @@ __global__ __launch_bounds__(768) void conv_wgrad_fp8_kernel(Fp8WgradArgs fa_) {
       }
 }
 
+// [r4b] conv_wgrad_fp8_kernel rebuilt the way conv_wgrad_roll_kernel rebuilt the bf16 kernel (same LDS byte images, fragments and
+// accumulation order as conv_wgrad_fp8_kernel: bit-identical partial sums): a tile iteration is ONE basic block; the next unit's x
+// fragment (4 transposing reads) is requested before a unit's MFMAs issue; this thread's piece p of tile t+1 is converted and written
+// after unit p of tile t and the request for its piece p of tile t+2 follows (a whole tile period in flight); buffer loads with
+// offsets computed once, out-of-image halo pieces through offset 0xffffffff = zero fill; the conversions on packed fp32 pairs
+// (v_pk_mul_f32 / v_pk_add_f32, clamp + ReLU in one v_med3_f32, v_cvt_pk_{bf8,fp8}_f32).  The conversion of bf16 operands to fp8 is
+// what this kernel's time goes to: ~24 VALU instructions per dz piece and ~30 per x piece against 12 MFMAs of 64 cycles per tile.
+template <int COT, bool LAZY, bool PARTIAL>
+__global__ __launch_bounds__(768) void conv_wgrad_fp8_roll_kernel(Fp8WgradArgs fa_) {
+  using T = bf16_t;
+  const WgradArgs& a = fa_.w;
+  constexpr int NT = 768;
+  constexpr int TH = 8, TW = 16, HH = TH + 2, HWD = TW + 2, HPX = HH * HWD, M = TH * TW;
+  constexpr int CT = 64, CJ = COT / 64;
+  constexpr int PA = COT + 32, PB = CT + 32;           // byte pitches of the fp8 tiles (see conv_wgrad_fp8_kernel)
+  constexpr int PPRA = COT / 8, PPR = CT / 8;          // 16-byte bf16 source pieces (8 channels) per pixel
+  constexpr int A_BYTES = M * PA, B_BYTES = HPX * PB, BUF_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_PIECES = M * PPRA, B_PIECES = HPX * PPR;
+  constexpr int A_ROUNDS = (A_PIECES + NT - 1) / NT, B_ROUNDS = (B_PIECES + NT - 1) / NT, NPIECES = A_ROUNDS + B_ROUNDS;
+  static_assert(A_PIECES >= NT && B_PIECES >= NT, "a thread without a piece repeats its piece of the previous round");
+  constexpr int A_PXR = NT / PPRA;                     // dz pixels per staging round: whole tile rows
+  static_assert(A_PXR % TW == 0, "a dz round = whole tile rows");
+  constexpr int KSTEPS = M / 64, NU = KSTEPS * 3;      // k-step = 64 pixels = four tile rows; unit = one (k-step, kw)
+  static_assert(NPIECES <= NU, "one staging piece per unit");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tg = wave >> 2;                          // kernel row kh
+  const int wco = (wave >> 1) & 1, wci = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ci_tiles = a.Ci / CT;
+  int cb = blockIdx.x, split = blockIdx.y;
+#if IM2IM_WGRAD_XCD
+  if ((gridDim.y & 7) == 0) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, j = lin >> 3;
+    split = (j / (int)gridDim.x) * 8 + xcd;
+    cb = j % (int)gridDim.x;
+  }
+#endif
+  const int co0 = (cb / ci_tiles) * COT, ci0 = (cb % ci_tiles) * CT;
+  const WgradSrc<T> xs(a, ci0);
+  const T* __restrict__ xg = xs.x;
+  const T* __restrict__ dzg = reinterpret_cast<const T*>(a.dz) + co0;
+
+  f32x16 acc[CJ][3];
+#pragma unroll
+  for (int j = 0; j < CJ; ++j)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
+
+  // delayed scaling of dz: s = 2^(14 - e); the MFMA multiplies the A operand by 2^(scale_a - 127) = 1 / s
+  float dzs = 1.f;
+  int scale_a = 127;
+  {
+    const float amax = *fa_.amax_in;
+    if (amax > 0.f && amax < 3.0e38f) {
+      int e;
+      frexpf(amax, &e);
+      dzs = ldexpf(1.f, 14 - e);
+      scale_a = 127 - (14 - e);
+      if (scale_a < 1) { scale_a = 127; dzs = 1.f; }
+    }
+  }
+  constexpr int scale_b = 127 - 4;
+
+  // ---- per-thread staging constants (see conv_wgrad_roll_kernel) ----
+  const int a_pix = tid / PPRA, a_part = tid % PPRA;
+  const int a_goff = ((a_pix / TW) * a.W + a_pix % TW) * a.Co * 2 + a_part * 16;
+  const int a_round_b = (A_PXR / TW) * a.W * a.Co * 2;
+  const int a_loff = a_pix * PA + a_part * 8;
+  constexpr bool A_WRAP = A_ROUNDS * NT > A_PIECES;
+  // (the last round's offsets are not kept in registers: a_goff + (wrapped ? A_ROUNDS - 2 : A_ROUNDS - 1) rounds, from an opaque
+  // thread id so that the compiler does not hoist them out of the tile loop and spill them)
+  auto last_round = [&]() __attribute__((always_inline)) -> int { int t = tid; asm("" : "+v"(t)); return (A_WRAP && (A_ROUNDS - 1) * NT + t >= A_PIECES) ? A_ROUNDS - 2 : A_ROUNDS - 1; };
+  const int a_yx = ((a_pix / TW) << 16) | (a_pix % TW);
+  int b_goff[B_ROUNDS], b_loff[B_ROUNDS], b_yx[PARTIAL ? B_ROUNDS : 1];
+  unsigned b_edge = 0;
+#pragma unroll
+  for (int i = 0; i < B_ROUNDS; ++i) {
+    int q = i * NT + tid;
+    if ((i + 1) * NT > B_PIECES && q >= B_PIECES) q -= NT;
+    const int pix = q / PPR, part = q % PPR, hy = pix / HWD, hx = pix % HWD;
+    b_goff[i] = ((hy * a.W + hx) * xs.stride + part * 8) * 2;
+    b_loff[i] = A_BYTES + pix * PB + part * 8;
+    b_edge |= (unsigned)((hy == 0) | ((hy == HH - 1) << 1) | ((hx == 0) << 2) | ((hx == HWD - 1) << 3)) << (4 * i);
+    if constexpr (PARTIAL) b_yx[i] = (hy << 16) | hx;
+  }
+
+  // coefficients of the x operand's conversion, times the activation pre-scale 2^4, in LDS behind the tile buffers: lazy BatchNorm
+  // (scale, shift) or (16, 0); lower clamp 0 (= the ReLU) or -448
+  float* ldsSS = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);
+  const bool lazy_x = LAZY && xs.sc != nullptr;
+  const float x_lo = lazy_x ? 0.f : -FP8W_E4M3_MAX;
+  if constexpr (LAZY) {
+    if (tid < CT) { ldsSS[tid] = (lazy_x ? xs.sc[tid] : 1.f) * FP8W_XSCALE; ldsSS[CT + tid] = lazy_x ? xs.sh[tid] * FP8W_XSCALE : 0.f; }
+    __syncthreads();
+  }
+
+  struct Pos { int tx, ty, b; };
+  auto pos_of = [&](int t) __attribute__((always_inline)) -> Pos { Pos p; p.tx = t % a.tilesX; t /= a.tilesX; p.ty = t % a.tilesY; p.b = t / a.tilesY; return p; };
+  auto advance = [&](Pos p, bool go) __attribute__((always_inline)) -> Pos {
+    const int wx = (p.tx + 1 == a.tilesX), wy = wx & (p.ty + 1 == a.tilesY);
+    Pos n;
+    n.tx = wx ? 0 : p.tx + 1;
+    n.ty = wy ? 0 : p.ty + wx;
+    n.b = p.b + wy;
+    n.tx = go ? n.tx : p.tx; n.ty = go ? n.ty : p.ty; n.b = go ? n.b : p.b;
+    return n;
+  };
+  auto outside = [&](int yx, int lo, int hi) __attribute__((always_inline)) -> bool {
+    const s16x2 d1 = __builtin_bit_cast(s16x2, yx) - __builtin_bit_cast(s16x2, hi), d2 = __builtin_bit_cast(s16x2, yx) - __builtin_bit_cast(s16x2, lo);
+    return ((__builtin_bit_cast(int, d1) & ~__builtin_bit_cast(int, d2)) & (int)0x80008000) != (int)0x80008000;
+  };
+  struct Src { __amdgpu_buffer_rsrc_t dz, x; unsigned bad; int a_hi, b_lo, b_hi; };
+  auto src_of = [&](Pos p) __attribute__((always_inline)) -> Src {
+    const int y0 = p.ty * TH, x0 = p.tx * TW;
+    const T* dzb = dzg + (((size_t)p.b * a.H + y0) * a.W + x0) * a.Co;
+    const T* xb = xg + (((ptrdiff_t)p.b * a.H + y0 - 1) * a.W + x0 - 1) * (ptrdiff_t)xs.stride;
+    const unsigned em = (unsigned)((y0 == 0) | ((y0 + TH == a.H) << 1) | ((x0 == 0) << 2) | ((x0 + TW == a.W) << 3));
+    Src s;
+    s.dz = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dzb), 0, 0x7fffffff, 0x00020000);
+    s.x = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xb), 0, 0x7fffffff, 0x00020000);
+    s.bad = b_edge & (em * 0x11111111u);
+    s.a_hi = (min(a.H - y0, 0x7fff) << 16) | min(a.W - x0, 0x7fff);
+    s.b_lo = ((y0 == 0) << 16) | (x0 == 0);
+    s.b_hi = (min(a.H - y0 + 1, 0x7fff) << 16) | min(a.W - x0 + 1, 0x7fff);
+    return s;
+  };
+  struct Stage { i32x4 v[NPIECES]; };
+  auto gload_piece = [&](const Src& s, Stage& R, auto p_tag) __attribute__((always_inline)) {
+    constexpr int p = decltype(p_tag)::value;
+    if constexpr (p < A_ROUNDS - 1) {
+      int off = a_goff;
+      if constexpr (PARTIAL) off = outside(a_yx + ((p * (A_PXR / TW)) << 16), 0, s.a_hi) ? -1 : off;
+      R.v[p] = __builtin_amdgcn_raw_buffer_load_b128(s.dz, off, p * a_round_b, 0);
+    } else if constexpr (p == A_ROUNDS - 1) {
+      const int lr = last_round();
+      int off = a_goff + lr * a_round_b;
+      if constexpr (PARTIAL) off = outside(a_yx + ((lr * (A_PXR / TW)) << 16), 0, s.a_hi) ? -1 : off;
+      R.v[p] = __builtin_amdgcn_raw_buffer_load_b128(s.dz, off, 0, 0);
+    } else {
+      constexpr int i = p - A_ROUNDS;
+      bool bad;
+      if constexpr (PARTIAL) bad = outside(b_yx[i], s.b_lo, s.b_hi); else bad = (s.bad >> (4 * i)) & 15u;
+      R.v[p] = __builtin_amdgcn_raw_buffer_load_b128(s.x, bad ? -1 : b_goff[i], 0, 0);
+    }
+  };
+  struct Edge { unsigned bad; int b_lo, b_hi; };
+  auto swrite_piece = [&](int bufoff, const Edge& e, const Stage& R, auto p_tag) __attribute__((always_inline)) {
+    constexpr int p = decltype(p_tag)::value;
+    const i32x4 v = R.v[p];
+    f32x2 f[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const unsigned u = (unsigned)v[k]; f[k] = f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
+    int lo, hi;
+    if constexpr (p < A_ROUNDS) {                      // dz: e5m2 under the delayed scale (a zero-filled piece stays zero)
+      const f32x2 sc = f32x2{dzs, dzs};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { f[k] = f[k] * sc; f[k][0] = __builtin_amdgcn_fmed3f(f[k][0], -FP8W_E5M2_MAX, FP8W_E5M2_MAX); f[k][1] = __builtin_amdgcn_fmed3f(f[k][1], -FP8W_E5M2_MAX, FP8W_E5M2_MAX); }
+      lo = __builtin_amdgcn_cvt_pk_bf8_f32(f[0][0], f[0][1], 0, false); lo = __builtin_amdgcn_cvt_pk_bf8_f32(f[1][0], f[1][1], lo, true);
+      hi = __builtin_amdgcn_cvt_pk_bf8_f32(f[2][0], f[2][1], 0, false); hi = __builtin_amdgcn_cvt_pk_bf8_f32(f[3][0], f[3][1], hi, true);
+      const int dst = a_loff + (p < A_ROUNDS - 1 ? p : last_round()) * A_PXR * PA;
+      *reinterpret_cast<uint2*>(smem + bufoff + dst) = make_uint2((unsigned)lo, (unsigned)hi);
+    } else {                                           // x: e4m3 of 16 * (lazy BatchNorm+ReLU of z | x)
+      constexpr int i = p - A_ROUNDS;
+      if constexpr (LAZY) {
+        const int c0 = (tid % PPR) * 8;
+        {                                              // (in two halves: all sixteen coefficients at once are sixteen registers the wide form lacks)
+          const float4 s0 = *reinterpret_cast<const float4*>(ldsSS + c0), h0 = *reinterpret_cast<const float4*>(ldsSS + CT + c0);
+          f[0] = f[0] * f32x2{s0.x, s0.y}; f[1] = f[1] * f32x2{s0.z, s0.w};
+          f[0] = f[0] + f32x2{h0.x, h0.y}; f[1] = f[1] + f32x2{h0.z, h0.w};
+        }
+        if constexpr (COT > 64) __builtin_amdgcn_sched_barrier(0);
+        {
+          const float4 s1 = *reinterpret_cast<const float4*>(ldsSS + c0 + 4), h1 = *reinterpret_cast<const float4*>(ldsSS + CT + c0 + 4);
+          f[2] = f[2] * f32x2{s1.x, s1.y}; f[3] = f[3] * f32x2{s1.z, s1.w};
+          f[2] = f[2] + f32x2{h1.x, h1.y}; f[3] = f[3] + f32x2{h1.z, h1.w};
+        }
+      } else {
+        const f32x2 sc = f32x2{FP8W_XSCALE, FP8W_XSCALE};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f[k] = f[k] * sc;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { f[k][0] = __builtin_amdgcn_fmed3f(f[k][0], x_lo, FP8W_E4M3_MAX); f[k][1] = __builtin_amdgcn_fmed3f(f[k][1], x_lo, FP8W_E4M3_MAX); }
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0][0], f[0][1], 0, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[1][0], f[1][1], lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[2][0], f[2][1], 0, false); hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[3][0], f[3][1], hi, true);
+      if constexpr (LAZY) {                            // zero padding stays exactly zero (not max(shift, 0))
+        bool bad;
+        if constexpr (PARTIAL) bad = outside(b_yx[i], e.b_lo, e.b_hi); else bad = (e.bad >> (4 * i)) & 15u;
+        const int keep = bad ? 0 : -1;
+        lo &= keep; hi &= keep;
+      }
+      *reinterpret_cast<uint2*>(smem + bufoff + b_loff[i]) = make_uint2((unsigned)lo, (unsigned)hi);
+    }
+  };
+
+  // fragment addressing (conv_wgrad_fp8_kernel): 16-lane group g reads channel sub-block (g & 1) * 16 of the wave's 32, pixels
+  // (g >> 1) * 32 ... of the k-step; lane q of the group supplies pixel row q >> 1 and the 8-byte half q & 1 of the block
+  const int g = lane >> 4, q = lane & 15;
+  auto tr8 = [&](const char* ptr) __attribute__((always_inline)) -> i32x2 { return __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_i32x2*)(lds_char*)ptr); };
+
+  const int t_begin = split * a.tiles_per_split;
+  const int t_end = min(t_begin + a.tiles_per_split, a.ntiles);
+  if (t_begin < t_end) {
+    Stage R;
+    Pos pos = pos_of(t_begin);
+    Edge ew;
+    {
+      const Src s0 = src_of(pos);
+      static_for<0, NPIECES>([&](auto p_tag) __attribute__((always_inline)) { gload_piece(s0, R, p_tag); });
+      const Edge e0{s0.bad, s0.b_lo, s0.b_hi};
+      static_for<0, NPIECES>([&](auto p_tag) __attribute__((always_inline)) { swrite_piece(0, e0, R, p_tag); });
+      pos = advance(pos, t_begin + 1 < t_end);
+      const Src s1 = src_of(pos);
+      static_for<0, NPIECES>([&](auto p_tag) __attribute__((always_inline)) { gload_piece(s1, R, p_tag); });
+      ew = Edge{s1.bad, s1.b_lo, s1.b_hi};
+    }
+    __syncthreads();
+    int curoff = 0;
+    for (int t = t_begin; t < t_end; ++t) {
+      pos = advance(pos, t + 2 < t_end);
+      const Src s2 = src_of(pos);
+      const int nxtoff = BUF_BYTES - curoff;
+      const char* la = smem + curoff;
+      const char* lb = la + A_BYTES + tg * HWD * PB;
+      const char* pa = la + ((g >> 1) * 32 + (q >> 1)) * PA + wco * (COT / 2) + (g & 1) * 16 + (q & 1) * 8;
+      const char* pb = lb + ((g >> 1) * 2 * HWD + (q >> 1)) * PB + wci * 32 + (g & 1) * 16 + (q & 1) * 8;
+      // x fragments: two sets, the next unit's requested before this unit's MFMAs issue -- or ONE (COT = 128: 96 accumulators leave no
+      // registers for the second), refilled right after the unit's MFMAs were issued, like the dz fragments
+      constexpr int FB_SETS = COT > 64 ? 1 : 2;
+      i32x8 fa[CJ], fb[FB_SETS];
+      auto load_fa = [&](auto ks_tag) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ks_tag)::value;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { const i32x2 w = tr8(pa + j * 32 + (ks * 64 + 8 * i) * PA); fa[j][2 * i] = w[0]; fa[j][2 * i + 1] = w[1]; }
+      };
+      auto load_fb = [&](auto n_tag) __attribute__((always_inline)) {
+        constexpr int n = decltype(n_tag)::value, ks = n / 3, kw = n % 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const i32x2 w = tr8(pb + ((ks * 4 + (i >> 1)) * HWD + (i & 1) * 8 + kw) * PB); fb[n % FB_SETS][2 * i] = w[0]; fb[n % FB_SETS][2 * i + 1] = w[1]; }
+      };
+      load_fa(std::integral_constant<int, 0>{});
+      load_fb(std::integral_constant<int, 0>{});
+      static_for<0, NU>([&](auto u_tag) __attribute__((always_inline)) {
+        constexpr int u = decltype(u_tag)::value, ks = u / 3, kw = u % 3;
+        if constexpr (FB_SETS == 2 && u + 1 < NU) {
+          load_fb(std::integral_constant<int, u + 1>{});
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < CJ; ++j)
+          acc[j][kw] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[j], fb[u % FB_SETS], acc[j][kw], 1, 0, 0, scale_a, 0, scale_b);
+        __builtin_amdgcn_sched_group_barrier(0x008, CJ, 0);
+        if constexpr (FB_SETS == 1 && u + 1 < NU) load_fb(std::integral_constant<int, u + 1>{});
+        if constexpr (kw == 2 && ks + 1 < KSTEPS) load_fa(std::integral_constant<int, ks + 1>{});     // one dz fragment set: refilled after its last MFMAs
+        if constexpr (u < NPIECES) {
+          // (see conv_wgrad_roll_kernel; with 96 accumulators the coefficient ds_reads must not be hoisted out of their piece either)
+          __builtin_amdgcn_sched_barrier(COT > 64 ? 0x00c : 0x10c);
+          swrite_piece(nxtoff, ew, R, u_tag);          // piece u of tile t+1
+          gload_piece(s2, R, u_tag);                   // piece u of tile t+2
+          __builtin_amdgcn_sched_barrier(COT > 64 ? 0x00c : 0x10c);
+        }
+      });
+      ew = Edge{s2.bad, s2.b_lo, s2.b_hi};
+      __syncthreads();
+      curoff = nxtoff;
+    }
+  }
+  float* out = a.partial + (size_t)split * a.Co * 9 * a.Ci;
+#pragma unroll
+  for (int j = 0; j < CJ; ++j)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wco * (COT / 2) + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int ci = ci0 + wci * 32 + l31;
+        out[((size_t)co * 9 + tg * 3 + kw) * a.Ci + ci] = acc[j][kw][r];
+      }
+}
+
 // sum partial[nsplit][Co][TAPS][Ci] over splits and write torch layout dw[Co][Ci][TAPS].  Block = 64 outputs x 4 split
 // lanes (lane s adds splits s, s+4, ... in order, the four partial sums are combined in a fixed order): deterministic,
 // and the many-split / few-output case (the 1x1 OutConv) does not serialise on one thread per output.
@@ -1204,6 +1492,7 @@ __global__ __launch_bounds__(256) void pack_weight_frag_multi_kernel(PackMultiAr
 namespace {
 int g_wgrad_co128 = 1;      // A/B switch (im2im_set_option "wgrad_co128")
 int g_wgrad_tile16 = 1;     // A/B switch "wgrad_tile16": 256-pixel tiles for the 64-output-channel form
+int g_wgrad_fp8_co128 = 1;  // A/B switch "wgrad_fp8_co128": the fp8 weight gradient's 128-output-channel form where Co % 128 == 0
 int g_wgrad_roll = 1;       // A/B switch "wgrad_roll": conv_wgrad_roll_kernel (rolling operand prefetch, staging spread over the MFMA phase)
 template <typename T, int TAPS>
 int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float* x_ss_hi, int Ci_lo, const void* dz, float* partial,
@@ -1374,6 +1663,7 @@ extern "C" int im2im_set_option(const char* key, int32_t value) {
   if (std::string(key) == "wgrad_co128") { g_wgrad_co128 = value; return IM2IM_OK; }
   if (std::string(key) == "wgrad_tile16") { g_wgrad_tile16 = value; return IM2IM_OK; }
   if (std::string(key) == "wgrad_roll") { g_wgrad_roll = value; return IM2IM_OK; }
+  if (std::string(key) == "wgrad_fp8_co128") { g_wgrad_fp8_co128 = value; return IM2IM_OK; }
   if (std::string(key) == "bn_fused_small") { im2im::set_bn_fused_small(value); return IM2IM_OK; }
   return im2im::fail_invalid("unknown option");
 }
@@ -1433,7 +1723,7 @@ extern "C" int im2im_conv_wgrad_fp8(const void* x, const float* x_scale_shift, c
   WgradArgs a{x, dz, reinterpret_cast<float*>(workspace), B, H, W, Ci, Co, (int)cdiv(H, TH), (int)cdiv(W, TW), 0, 0, x_scale_shift,
               x_hi, x_scale_shift_hi, Ci_lo};
   a.ntiles = B * a.tilesY * a.tilesX;
-  const bool wide = Co % 128 == 0;
+  const bool wide = g_wgrad_fp8_co128 && Co % 128 == 0;
   const int cot = wide ? 128 : 64;
   const int cblocks = (Co / cot) * (Ci / 64);
   const size_t wsz = (size_t)Co * 9 * Ci * sizeof(float);
@@ -1446,12 +1736,36 @@ extern "C" int im2im_conv_wgrad_fp8(const void* x, const float* x_scale_shift, c
   a.tiles_per_split = (int)cdiv(a.ntiles, nsplit);
   nsplit = cdiv(a.ntiles, a.tiles_per_split);
   Fp8WgradArgs fa{a, amax_prev};
+  const bool roll = g_wgrad_roll && (int64_t)(H + 16) * W * std::max(Ci, Co) * 2 < (1ll << 31);   // 32-bit byte offsets within an image
+  const bool lazy = x_scale_shift != nullptr || x_scale_shift_hi != nullptr, partial = H % TH != 0 || W % TW != 0;
   if (wide) {
     constexpr size_t smem = 2 * ((size_t)TH * TW * (128 + 32) + (size_t)(TH + 2) * (TW + 2) * 96) + 512;
-    hipLaunchKernelGGL(conv_wgrad_fp8_kernel<128>, dim3((unsigned)cblocks, (unsigned)nsplit), dim3(768), smem, stream, fa);
+    auto kern = !roll ? conv_wgrad_fp8_kernel<128>
+                : partial ? (lazy ? conv_wgrad_fp8_roll_kernel<128, true, true> : conv_wgrad_fp8_roll_kernel<128, false, true>)
+                          : (lazy ? conv_wgrad_fp8_roll_kernel<128, true, false> : conv_wgrad_fp8_roll_kernel<128, false, false>);
+    static bool attr_set = false;
+    if (!attr_set) {
+      const void* ks[] = {reinterpret_cast<const void*>(conv_wgrad_fp8_kernel<128>), reinterpret_cast<const void*>(conv_wgrad_fp8_roll_kernel<128, true, true>),
+                          reinterpret_cast<const void*>(conv_wgrad_fp8_roll_kernel<128, false, true>), reinterpret_cast<const void*>(conv_wgrad_fp8_roll_kernel<128, true, false>),
+                          reinterpret_cast<const void*>(conv_wgrad_fp8_roll_kernel<128, false, false>)};
+      for (const void* k : ks) hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)cblocks, (unsigned)nsplit), dim3(768), smem, stream, fa);
   } else {
     constexpr size_t smem = 2 * ((size_t)TH * TW * (64 + 32) + (size_t)(TH + 2) * (TW + 2) * 96) + 512;
-    hipLaunchKernelGGL(conv_wgrad_fp8_kernel<64>, dim3((unsigned)cblocks, (unsigned)nsplit), dim3(768), smem, stream, fa);
+    auto kern = !roll ? conv_wgrad_fp8_kernel<64>
+                : partial ? (lazy ? conv_wgrad_fp8_roll_kernel<64, true, true> : conv_wgrad_fp8_roll_kernel<64, false, true>)
+                          : (lazy ? conv_wgrad_fp8_roll_kernel<64, true, false> : conv_wgrad_fp8_roll_kernel<64, false, false>);
+    static bool attr_set = false;
+    if (!attr_set) {
+      const void* ks[] = {reinterpret_cast<const void*>(conv_wgrad_fp8_kernel<64>), reinterpret_cast<const void*>(conv_wgrad_fp8_roll_kernel<64, true, true>),
+                          reinterpret_cast<const void*>(conv_wgrad_fp8_roll_kernel<64, false, true>), reinterpret_cast<const void*>(conv_wgrad_fp8_roll_kernel<64, true, false>),
+                          reinterpret_cast<const void*>(conv_wgrad_fp8_roll_kernel<64, false, false>)};
+      for (const void* k : ks) hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)cblocks, (unsigned)nsplit), dim3(768), smem, stream, fa);
   }
   if (int rc = check_launch("conv_wgrad_fp8_kernel")) return rc;
   const size_t total = (size_t)Co * 9 * Ci;

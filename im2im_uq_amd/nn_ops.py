@@ -304,11 +304,12 @@ def packed_fp8(weight: torch.Tensor, want_dgrad: bool):
 
 
 FP8_DGRAD = os.environ.get("IM2IM_FP8_DGRAD", "1") != "0"     # fp8 mode: data-gradients on the fp8 kernel too (e5m2 operand)
-# [r4] ... and, on request, the weight gradients of those layers (e5m2 dz x e4m3 input, conv_wgrad_fp8_kernel).  Off by default since
-# conv_wgrad_roll_kernel: the bf16 weight gradient is now the faster one on 9 of the 11 eligible layer shapes (6.98 vs 7.61 ms over
-# them at batch 78, profiles/r04_ab_experiments.txt section 20) -- the fp8 kernel converts bf16 operands on the fly and is bound by
-# those VALU instructions, not by its MFMAs
-FP8_WGRAD = os.environ.get("IM2IM_FP8_WGRAD", "0") != "0"
+# [r4] ... and the weight gradients of those layers (e5m2 dz x e4m3 input, conv_wgrad_fp8_roll_kernel): "auto" = where the fp8 kernel is
+# the faster one, i.e. the layers with 64 output channels (x1.12-1.17 over the bf16 roll kernel; on the 128-channel-wide layers the two
+# are level -- its 96 accumulators + staged tile + conversions do not fit 168 registers -- and at 40x40 the bf16 kernel leads by 5 %:
+# profiles/r04_ab_experiments.txt section 20); "1" = every eligible layer, "0" = none
+FP8_WGRAD = os.environ.get("IM2IM_FP8_WGRAD", "auto")
+FP8_WGRAD = {"0": False, "1": True}.get(FP8_WGRAD, "auto")
 
 
 _fp8_grad_scales = WeakTensorKeyDictionary()        # conv weight -> Fp8GradScale; NOT an attribute of the Parameter: Parameter.__reduce_ex__
@@ -909,7 +910,8 @@ class ConvStats(torch.autograd.Function):
             # fp8 mode: this layer's dz scale slots, taken ONCE per step (the weight gradient reads `previous`, the data-gradient
             # below reads it too and maintains the other two)
             fp8_slots = ctx.fp8_gs.slots(dz) if ctx.fp8_dgrad else None
-            fp8_w = ctx.fp8_dgrad and FP8_WGRAD and dz.dtype == BF16 and dz.shape[3] % 64 == 0 and ci % 64 == 0
+            fp8_w = (ctx.fp8_dgrad and FP8_WGRAD and dz.dtype == BF16 and dz.shape[3] % 64 == 0 and ci % 64 == 0
+                     and (FP8_WGRAD is True or dz.shape[3] % 128 != 0))
 
             def wgrad(out, key):
                 if fp8_w:

@@ -403,7 +403,7 @@ def test_conv_wgrad_fp8_vs_cpu_on_identically_quantised_operands(case):
 
 
 def test_fp8_mode_train_step_uses_the_fp8_weight_gradient():
-    """fp8 mode: the layers whose data-gradient is fp8 can take the fp8 weight gradient too (IM2IM_FP8_WGRAD; off by default since the bf16 roll kernel is faster); the step
+    """fp8 mode: the layers whose data-gradient is fp8 take the fp8 weight gradient too where it is the faster one (IM2IM_FP8_WGRAD: "auto" = the 64-output-channel layers, 1 = all, 0 = none); the step
     is finite and its gradients stay within fp8-sized distance of the step with bf16 weight gradients."""
     from im2im_uq_amd import nn_ops
     from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty

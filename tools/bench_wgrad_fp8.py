@@ -10,6 +10,10 @@ import torch
 from im2im_uq_amd import nn_ops
 
 dev = "cuda:0"
+for kv in os.environ.get("BENCH_OPT", "").split(","):          # e.g. BENCH_OPT=wgrad_fp8_co128=0
+    if "=" in kv:
+        from im2im_uq_amd import hip_ops
+        hip_ops.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 78
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 320
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 7
