@@ -309,3 +309,72 @@ def test_bn_sums_in_one_launch_for_few_partial_rows(rows, c):
     mask = (z.float() * ss[0] + ss[1] > 0).double()
     gd = da.double() * mask
     torch.testing.assert_close(res[1][2].double(), gd.sum(0).cpu(), rtol=1e-5, atol=1e-4)          # dbeta
+
+
+# ------------------------------------------------------------------------------------------------
+# conv_wgrad_roll_kernel / conv_wgrad_fp8_roll_kernel (csrc/conv_wgrad.hip): the weight gradient of nn.Conv2d under loss.backward()
+# (reference: core/models/trunks/unet_parts.py:16,19 at core/scripts/train.py:159).  Same LDS images, fragments and accumulation order as
+# the pipe kernels they replace => the SAME BITS, for every form: 128- / 64-output-channel tiles, lazy / plain / split input, tiles that
+# hang over the image (40- and 20-pixel rows, odd extents), splits of one or two tiles (the pipeline's prologue and its repeated last tile).
+WG_CASES = [
+    # (B, H, W, Ci, Co, split_in, lazy)
+    (3, 32, 32, 64, 128, False, True),      # 128-wide form, full tiles
+    (2, 40, 40, 128, 128, False, True),     # ... tiles hang over the 40-pixel rows (PARTIAL)
+    (2, 20, 20, 64, 256, False, False),     # ... 20x20, plain input
+    (1, 24, 48, 128, 128, True, True),      # ... split input: the low half lazy, the high half plain
+    (2, 64, 64, 64, 64, False, True),       # 64-output-channel form on 256-pixel swizzled tiles
+    (1, 64, 80, 128, 64, True, True),       # ... split input
+    (1, 72, 88, 64, 64, False, False),      # ... overhanging 16x16 tiles, plain input
+    (1, 8, 16, 64, 128, False, True),       # ONE tile in the whole problem
+    (1, 16, 16, 64, 128, False, False),     # two tiles
+]
+
+
+@pytest.mark.parametrize("case", WG_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_roll_weight_gradient_bit_identical_to_the_pipe_kernel(case):
+    from im2im_uq_amd import hip_ops, nn_ops
+    b, h, w, ci, co, split, lazy = case
+    g = torch.Generator(device=DEV).manual_seed(7)
+    cin = ci // 2 if split else ci
+    x = torch.randn(b, h, w, cin, device=DEV, generator=g).to(torch.bfloat16)
+    xh = torch.randn(b, h, w, cin, device=DEV, generator=g).to(torch.bfloat16) if split else None
+    dz = torch.randn(b, h, w, co, device=DEV, generator=g).to(torch.bfloat16)
+    ss = torch.stack([torch.rand(cin, device=DEV, generator=g) + 0.5, torch.randn(cin, device=DEV, generator=g)]).contiguous() if lazy else None
+    outs = {}
+    try:
+        for mode in (0, 1):
+            hip_ops.set_option("wgrad_roll", mode)
+            outs[mode] = nn_ops.conv_wgrad(x, dz, 9, x_ss=ss, x_hi=xh).clone()
+    finally:
+        hip_ops.set_option("wgrad_roll", 1)
+    assert torch.equal(outs[0], outs[1])
+    # and against torch on the CPU (fp32 math on the bf16 operands; the kernels accumulate in fp32 in another order)
+    a = x.float()
+    if lazy:
+        a = torch.clamp_min(a * ss[0] + ss[1], 0).to(torch.bfloat16).float()
+    if split:
+        a = torch.cat([a, xh.float()], 3)
+    ref = torch.nn.grad.conv2d_weight(a.permute(0, 3, 1, 2).cpu(), (co, ci, 3, 3), dz.float().permute(0, 3, 1, 2).cpu(), padding=1)
+    got = outs[1].reshape(co, ci, 3, 3).cpu()
+    assert float((got - ref).norm() / ref.norm()) < 2e-5
+
+
+@pytest.mark.parametrize("case", [c for c in WG_CASES if c[3] % 64 == 0 and c[4] % 64 == 0][:7], ids=lambda c: "x".join(str(v) for v in c))
+def test_fp8_roll_weight_gradient_bit_identical_to_the_fp8_pipe_kernel(case):
+    from im2im_uq_amd import hip_ops, nn_ops
+    b, h, w, ci, co, split, lazy = case
+    g = torch.Generator(device=DEV).manual_seed(11)
+    cin = ci // 2 if split else ci
+    x = torch.randn(b, h, w, cin, device=DEV, generator=g).to(torch.bfloat16)
+    xh = torch.randn(b, h, w, cin, device=DEV, generator=g).to(torch.bfloat16) if split else None
+    dz = (torch.randn(b, h, w, co, device=DEV, generator=g) * 1e-3).to(torch.bfloat16)
+    amax = dz.float().abs().max().reshape(1).contiguous()
+    ss = torch.stack([torch.rand(cin, device=DEV, generator=g) + 0.5, torch.randn(cin, device=DEV, generator=g)]).contiguous() if lazy else None
+    outs = {}
+    try:
+        for mode in (0, 1):
+            hip_ops.set_option("wgrad_roll", mode)
+            outs[mode] = nn_ops.conv_wgrad_fp8(x, dz, amax.data_ptr(), x_ss=ss, x_hi=xh).clone()
+    finally:
+        hip_ops.set_option("wgrad_roll", 1)
+    assert torch.equal(outs[0], outs[1])
