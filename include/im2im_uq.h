@@ -126,6 +126,8 @@ int im2im_rcps_scan(const float* table, int64_t N, int32_t L, int64_t row_stride
 
 /* Run-time switch for within-process A/B measurements of kernel variants (tools/, bench.py); no reference counterpart.
  * "wgrad_co128" / "wgrad_tile16": 0 switches the 128-output-channel / 256-pixel-tile forms of the weight gradient off;
+ * "wgrad_roll": 0 = the bf16 and fp8 3x3 weight gradients on conv_wgrad_pipe_kernel / conv_wgrad_fp8_kernel instead of the roll
+ *   kernels (default 1; same bits either way); "wgrad_fp8_co128": 0 = the fp8 weight gradient's 64-output-channel form everywhere;
  * "conv_splitk": 0 = im2im_conv_fwd_split_ws never splits, n = it aims at n * 256 workgroups (default 3);
  * "bn_fused_small": 0 = BatchNorm statistics / backward sums always in two stages (default 1: one launch for <= 256 partial rows). */
 int im2im_set_option(const char* key, int32_t value);
