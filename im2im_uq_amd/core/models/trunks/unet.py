@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from ... import _pkg  # noqa: F401
-from .unet_parts import DoubleConv, Down, OutConv, Up
+from .unet_parts import DoubleConv, Down, OutConv, Up, _cdt
 
 
 def unet_plan(n_channels_in, depth=4, base=64, bilinear=True):
@@ -46,7 +46,11 @@ class UNet(nn.Module):
     def forward(self, x):
         if not self.training and not torch.is_grad_enabled():
             # inference: the last block hands OutConv's 1x1 to its own conv epilogue when it can (nn_ops.conv_bn_relu_eval tail=)
-            h = self.features(x, tail=self.out.conv)
+            # -- unless OutConv carries its own compute dtype or anyone listens on it (forward hooks: feature extraction)
+            out, conv = self.out, self.out.conv
+            hooked = any(getattr(m, a, None) for m in (out, conv) for a in ("_forward_hooks", "_forward_pre_hooks"))
+            fuse = not hooked and _cdt(out) == _cdt(getattr(self, f"up{getattr(self, 'depth', 4)}").conv)
+            h = self.features(x, tail=conv if fuse else None)
             return h if getattr(h, "_im2im_tail_done", False) else self.out(h)
         return self.out(self.features(x))
 

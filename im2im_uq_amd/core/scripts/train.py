@@ -225,8 +225,11 @@ def broadcast_module_state(net, src=0, buffers_only=False):
     with torch.no_grad():
         for t in ([] if buffers_only else list(net.parameters())) + list(net.buffers()):
             if t.numel():
-                dist.broadcast(t.detach(), src=src)      # detach() shares the version counter (`.data` would not bump it:
-                                                         # the packed-weight caches of nn_ops key on it)
+                dist.broadcast(t.detach(), src=src)
+    # c10d collectives write in place WITHOUT bumping the version counter (no ADInplaceOrView kernel; `_version` is the same before and
+    # after, through `.data` and `.detach()` alike), and the packed-weight / folded-BatchNorm caches of nn_ops key on it: forget them,
+    # or a rank other than `src` that ran a forward before the broadcast would keep serving operands packed from its old weights
+    nn_ops.invalidate_packed()
 
 
 class GlobalBatchSampler(torch.utils.data.Sampler):
@@ -352,6 +355,24 @@ class GraphedStep:
             return True
         return world == 1 and labels_numel <= int(os.environ.get("IM2IM_HIP_GRAPH_MAX_PIXELS", str(1 << 18)))
 
+    _hook_note_done = False
+
+    @staticmethod
+    def foreign_hook_owner(net, sync=None):
+        """name of the first module / parameter that carries a hook this class does not account for, or None"""
+        own = sync.own_hook_ids() if sync is not None else set()
+        for mname, m in net.named_modules():
+            for name in ("_forward_hooks", "_forward_pre_hooks", "_backward_hooks", "_backward_pre_hooks"):
+                if getattr(m, name, None):
+                    return f"module '{mname or type(m).__name__}' ({name[1:]})"
+        for pname, p in net.named_parameters():
+            if getattr(p, "_backward_hooks", None):
+                return f"parameter '{pname}' (tensor hook)"
+            post = getattr(p, "_post_accumulate_grad_hooks", None)
+            if post and any(k not in own for k in post):
+                return f"parameter '{pname}' (post-accumulate-grad hook)"
+        return None
+
     @staticmethod
     def has_foreign_hooks(net, sync=None):
         """a replayed graph runs no Python: forward / backward hooks on a module and tensor hooks on a parameter (wandb.watch
@@ -380,8 +401,18 @@ class GraphedStep:
             forced = os.environ.get("IM2IM_HIP_GRAPH") == "1"
         if forced:
             return True
-        return (all(type(m).__module__.startswith(("im2im_uq_amd.", "torch.nn.modules.")) for m in net.modules())
-                and not GraphedStep.has_foreign_hooks(net, sync))
+        if not all(type(m).__module__.startswith(("im2im_uq_amd.", "torch.nn.modules.")) for m in net.modules()):
+            return False
+        owner = GraphedStep.foreign_hook_owner(net, sync)
+        if owner is not None and not GraphedStep._hook_note_done:
+            GraphedStep._hook_note_done = True
+            # wandb.watch(net) (train_net calls it, reference :122) registers parameter hooks: with a live wandb run auto mode
+            # would silently never graph -- say so once
+            msg = (f"HIP-graph training step not used in auto mode: {owner} carries a hook that a replayed graph would not run "
+                   f"(wandb.watch registers such hooks). Set `hip_graph: true` in the config (or IM2IM_HIP_GRAPH=1) to graph anyway.")
+            logging.warning(msg)
+            print(msg)
+        return owner is None
 
     # ------------------------------------------------------------------ the pieces of a step
     def _fwd_bwd(self):
@@ -408,8 +439,14 @@ class GraphedStep:
         return (tuple(p.data_ptr() for p in self.params), tuple(b.data_ptr() for b in self.net.buffers() if b is not None),
                 nn_ops._Scratch.addresses())
 
+    def _drop_graph(self):
+        if self.graph is not None:
+            self.graph = None
+            nn_ops._Scratch.unpin()
+
     def _capture(self, cur):
         nn_ops._Scratch.pinned = True
+        allocs_before = self.opt._ctr_allocs if self.adam_in_graph else None
         steps_before = [(p, self.opt.state[p].get("step")) for p in self.params if self.opt.state.get(p)] if self.adam_in_graph else []
         ctrs_before = dict(self.opt._ctrs) if self.adam_in_graph else None
         graph = torch.cuda.CUDAGraph()
@@ -432,8 +469,11 @@ class GraphedStep:
                 if self.in_graph_opt:
                     self.opt.step()
                 self.loss = loss.detach() * self.weight if self.sync is not None else loss.detach()
+            if allocs_before is not None and self.opt._ctr_allocs != allocs_before:
+                raise RuntimeError("FusedAdam allocated a step counter inside the capture (a replay would reset the step count)")
         except Exception as e:  # noqa: BLE001
             self.failed = True
+            nn_ops._Scratch.pinned = nn_ops._Scratch.graphs > 0
             self.error = f"{type(e).__name__}: {e}"
             if self.sync is not None:
                 self.sync.deferred = False
@@ -454,6 +494,8 @@ class GraphedStep:
             if self.sync is not None:
                 self.sync.deferred = False
         self.graph = graph
+        nn_ops._Scratch.pin()
+        self.hyper = self.opt.hyper_key() if self.adam_in_graph else None     # lr / betas / eps are frozen into the graph by value
         self.grads = [p.grad for p in self.params]            # without a GradSync: the graph's own gradient tensors
         self.stepped = [p for p in self.params if p.grad is not None]    # what the captured optimizer step updates
         self.addr = self._addresses()
@@ -479,7 +521,10 @@ class GraphedStep:
         if self.graph is not None and self._addresses() != self.addr:
             # parameters / buffers moved (train_net's checkpoint does net.cpu() ... net.to(device)) or a scratch buffer grew:
             # the captured addresses are stale
-            self.graph, self.done = None, 0
+            self._drop_graph()
+            self.done = 0
+        if self.graph is not None and self.adam_in_graph and self.opt.hyper_key() != self.hyper:
+            self._drop_graph()                                # an LR scheduler stepped / group['lr'] was edited: capture again (no warm-up needed)
         if self.graph is None and self.done < self.WARM:
             self.stream.wait_stream(cur)
             with torch.cuda.stream(self.stream):

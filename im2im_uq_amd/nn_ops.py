@@ -69,6 +69,22 @@ class _Scratch:
     bufs = {}
     pinned = False
     retired = []
+    graphs = 0                 # live captured graphs (GraphedStep): `pinned` while > 0
+
+    @classmethod
+    def pin(cls):
+        cls.graphs += 1
+        cls.pinned = True
+
+    @classmethod
+    def unpin(cls):
+        """a captured graph was dropped: when it was the last one, nothing can write to the retired buffers any more"""
+        cls.graphs = max(cls.graphs - 1, 0)
+        if cls.graphs == 0:
+            cls.pinned = False
+            if cls.retired:
+                torch.cuda.synchronize()       # replays still in flight
+                cls.retired.clear()
 
     @classmethod
     def get(cls, nbytes: int, device, key: str = "a") -> torch.Tensor:
@@ -149,7 +165,8 @@ def pack_weight(w: torch.Tensor, dtype, want_wd=True):
 # Staleness is detected by (storage address, version counter).  In-place writes through `p.data` (legacy optimizers written as
 # `p.data.add_`, EMA swaps as `p.data.copy_`, `dist.broadcast(p.data)`) do NOT bump the counter: call invalidate_packed()
 # (or touched(p)) after such a write, write through `p.detach()` / under torch.no_grad() instead, or set IM2IM_BATCH_PACK=0 to
-# re-pack on every forward.  The package's own writers (FusedAdam, broadcast_module_state, load_state_dict) all bump it.
+# re-pack on every forward.  The package's own writers: FusedAdam and load_state_dict bump it; broadcast_module_state cannot (c10d
+# collectives do not touch the counter whichever alias they are given) and calls invalidate_packed() after its broadcasts.
 BATCH_WEIGHT_PACKING = os.environ.get("IM2IM_BATCH_PACK", "1") != "0"
 _pack_registry = {}        # id(weight) -> weakref(weight)
 _pack_cache = {}           # (id(weight), dtype) -> (data_ptr, version, wf, wd)
@@ -1815,34 +1832,49 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.capturable = bool(capturable)
-        self._ctrs = {}            # (device index, steps taken so far) -> (int64[1] device counter, float32[2] coefficient scratch)
+        self._ctrs = {}            # (param group, device index, steps taken so far) -> (int64[1] device counter, float32[2] coefficients)
+        self._ctr_allocs = 0       # counters created so far (GraphedStep: none may be created inside a capture)
 
     def __setstate__(self, state):
         super().__setstate__(state)
         self.__dict__.setdefault("capturable", False)
         self.__dict__.setdefault("_ctrs", {})
+        self.__dict__.setdefault("_ctr_allocs", 0)
 
-    def _counter(self, device, taken):
-        key = (torch.device(device).index, int(taken))
+    def hyper_key(self):
+        """what a captured step() froze by value (im2im_adam_step_dev takes lr, betas, eps as scalars): a graph holder compares
+        this between replays and re-captures when an LR scheduler / a manual edit of `group['lr']` changed it."""
+        return tuple((float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])) for g in self.param_groups)
+
+    def _counter(self, gi, device, taken):
+        # keyed per PARAM GROUP: two groups on one device at the same step count each own a counter (sharing the key, the second
+        # group's lookup missed, allocated a fresh one and dropped the first -- which a captured graph could still be writing)
+        key = (int(gi), torch.device(device).index, int(taken))
         ctr = self._ctrs.pop(key, None)
         if ctr is None:
+            if torch.cuda.is_current_stream_capturing():
+                # a torch.full captured here would reset the step count at every replay
+                raise _lib.Im2ImError("FusedAdam(capturable): a step counter would be created inside a graph capture; "
+                                      "run one eager step() with the same parameters first")
             ctr = (torch.full((1,), int(taken), dtype=torch.int64, device=device), torch.zeros(2, dtype=F32, device=device))
-        self._ctrs[(key[0], key[1] + 1)] = ctr                # where the next step will look for it
+            self._ctr_allocs += 1
+        self._ctrs[(key[0], key[1], key[2] + 1)] = ctr        # where the next step will look for it
         return ctr
 
     def advance(self, params):
         """host-side bookkeeping of ONE optimizer step that a replayed HIP graph performed on the device: step counts, the
         counter table, and the parameters' version counters (the packed-weight caches key on them)."""
+        group_of = {id(p): gi for gi, g in enumerate(self.param_groups) for p in g["params"]}
         moved = set()
         for p in params:
             st = self.state.get(p)
             if st:
-                moved.add((p.device.index, int(st["step"])))
+                moved.add((group_of.get(id(p), 0), p.device.index, int(st["step"])))
                 st["step"] += 1
         for key in moved:
             ctr = self._ctrs.pop(key, None)
             if ctr is not None:
-                self._ctrs[(key[0], key[1] + 1)] = ctr
+                self._ctrs[(key[0], key[1], key[2] + 1)] = ctr
         touched(*params)
 
     @torch.no_grad()
@@ -1852,7 +1884,7 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         join_side_streams()                       # weight gradients computed on the second stream (no-op when none are pending)
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             by_step = {}                      # bias correction is per parameter (torch.optim.Adam): one launch per distinct step count
             for p in group["params"]:
                 if p.grad is None:
@@ -1879,7 +1911,7 @@ class FusedAdam(torch.optim.Optimizer):
                 ptrs = (arr(*[it[0].data_ptr() for it in items]), arr(*[it[1].data_ptr() for it in items]),
                         arr(*[it[2].data_ptr() for it in items]), arr(*[it[3].data_ptr() for it in items]))
                 if self.capturable:
-                    ctr, coef = self._counter(dev, step - 1)
+                    ctr, coef = self._counter(gi, dev, step - 1)
                     check(lib.im2im_adam_step_dev(n, *ptrs, sizes, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                                   dptr(ctr), dptr(coef), stream_ptr(dev)), "im2im_adam_step_dev")
                 else:

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IM2IM_ABI_VERSION 1
+#define IM2IM_ABI_VERSION 2
 #define IM2IM_OK 0
 #define IM2IM_ERR_INVALID (-1)     /* bad argument / unsupported shape */
 #define IM2IM_ERR_HIP (-2)         /* a HIP runtime call or launch failed */

@@ -66,7 +66,15 @@ def _worker(rank, world, port, tmpdir):
             with torch.no_grad():
                 for p in model.parameters():
                     p.add_(0.01)
+        # [r5] ... and that already RAN forwards (train and eval) on its own weights, so every packed-weight / folded-BatchNorm
+        # cache of nn_ops holds operands of the pre-broadcast weights; c10d broadcasts do not bump version counters
+        with torch.no_grad():
+            model(x[:2].to(DEV))
+            model.eval(); pre = model(x[:2].to(DEV)).cpu(); model.train()
         broadcast_module_state(model)                         # ... is overwritten with rank 0's weights
+        with torch.no_grad():
+            model.eval(); post = model(x[:2].to(DEV)).cpu(); model.train()
+        torch.save({"pre": pre, "post": post}, os.path.join(tmpdir, f"bcast_{rank}.pt"))
         sync = GradSync(model.parameters())
         lo, hi = GlobalBatchSampler.share(5, rank, world)     # 3 + 2 images
         sync.zero_grad()
@@ -97,6 +105,10 @@ def _worker(rank, world, port, tmpdir):
 def test_two_rank_step_matches_dataparallel_oracle_and_sharded_metrics_match_single_process(tmp_path):
     from oracle import model as om
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    # [r5] a forward after the broadcast uses the broadcast weights on every rank (stale packed operands would reproduce `pre`)
+    b0, b1 = torch.load(tmp_path / "bcast_0.pt"), torch.load(tmp_path / "bcast_1.pt")
+    assert not torch.equal(b0["pre"], b1["pre"])                                # the ranks did start from different weights
+    assert torch.equal(b0["post"], b0["pre"]) and torch.equal(b1["post"], b0["post"])
     r0 = torch.load(tmp_path / "step_0.pt")
     r1 = torch.load(tmp_path / "step_1.pt")
     for k in r0["grads"]:
