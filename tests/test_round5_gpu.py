@@ -157,8 +157,12 @@ def _distance(a, ref):
 def test_fp8_training_tracks_fp32_training_then_calibrates_alike():
     """600 steps, 2 input channels, 64 x 64: fp8 mode (e4m3 forward, e5m2 data-gradient under delayed scaling, fp8 weight gradient
     where routed) against fp32 mode, with fp32 against a 1e-4-perturbed fp32 run as the yardstick and the bf16 run beside it.
-    Measured on MI355X (fp32' | bf16 | fp8, all vs fp32): see the printed table; the bounds asserted are the bf16 test's
-    absolute ones widened to what e4m3 operands cost (module docstring of tests/test_train_parity_gpu.py for the method)."""
+    Measured on MI355X (profiles/r05_tests_round5.txt; fp32' | bf16 | fp8, all vs fp32): tail-200 loss 1.8 % | 5.3 % | 4.7 %;
+    lambda-hat 3 | 2 | 3 grid steps of 100; prediction images (rel. L2) 4.6 % | 3.3 % | 5.5 %; calibrated lower edge 7.9 % | 4.9 % |
+    8.7 %; upper edge 13.2 % | 5.6 % | 9.6 %; mean calibrated interval size 0.148 | 0.117 | 0.136 (fp32 0.130); validation risk
+    0.047-0.050 for all four (alpha = 0.1): after 600 steps the fp8 run is as far from the fp32 run as a second fp32 run is.
+    The bounds asserted are the bf16 test's absolute ones widened for e4m3 / e5m2 operands (method: module docstring of
+    tests/test_train_parity_gpu.py)."""
     from im2im_uq_amd.core.datasets.synthetic import SyntheticDenoiseDataset
     steps, n_in = 600, 2
     ds = SyntheticDenoiseDataset(num_images=96 * 3, num_inputs=n_in, side=64, noise=0.1, seed=5)
@@ -201,7 +205,9 @@ def test_fp8_backward_survives_a_gradient_spike_and_recovers_within_two_steps():
     nn_ops.Fp8GradScale).  A loss that jumps x100 for ONE step (a bad batch) overshoots that headroom 28-fold: the conversion must
     saturate, not overflow to inf / NaN; the step after runs on a scale 100x too large (values 6-7 binades further down e5m2's
     16-binade range); two steps after the spike the error is back at the steady-state level.  Weights are fixed, so every step's
-    exact answer is the same bf16-backward gradient times the step's factor."""
+    exact answer is the same bf16-backward gradient times the step's factor.  Measured (profiles/r05_tests_round5.txt): median
+    relative L2 of the parameter gradients vs the bf16 backward 0.133 at every normal step -- the step right after the spike
+    included: e5m2's range absorbs a 100x too large scale -- and 0.914 on the spike step itself (saturated, finite)."""
     from im2im_uq_amd import nn_ops
     from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
     from im2im_uq_amd.core.models.trunks.unet import UNet
@@ -238,7 +244,7 @@ def test_fp8_backward_survives_a_gradient_spike_and_recovers_within_two_steps():
     assert med[0] < 0.15 and med[1] < 0.15                         # steady state (tests/test_fp8_gpu.py holds the same bound)
     assert med[4] < 0.15 and med[5] < 0.15                         # recovered two steps after the spike
     assert med[4] <= med[1] * 1.5 + 0.02
-    assert med[3] < 0.6                                            # the step on the stale (too large) scale: degraded, not broken
+    assert med[3] < 0.3                                            # the step on the stale (too large) scale (measured: no worse)
 
 
 # ------------------------------------------------------------------------------------------------ ADVICE r4 (host logic on the GPU)
