@@ -317,11 +317,8 @@ def distributed_record(job, wl, backend, steps=10):
     against the xGMI links) and how much of the exchange a training step does NOT hide: the same step with and without GradSync."""
     import torch.distributed as tdist
     dev, world = job.dev, job.world
-    props = torch.cuda.get_device_properties(dev)
-    me = {"rank": job.rank, "local_device_index": dev.index, "name": props.name,
-          "uuid": str(getattr(props, "uuid", "")) or None,
-          "pci_bus_id": ("%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))),
-          "pid": os.getpid()}
+    from im2im_uq_amd import launch
+    me = launch.device_identity(dev, job.rank)
     ranks = [me]
     if world > 1:
         ranks = [None] * world
@@ -329,7 +326,9 @@ def distributed_record(job, wl, backend, steps=10):
     rec = {"backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else None, "world_size": world,
            "allreduce_bytes_per_step": wl.allreduce_bytes, "gpus_visible": torch.cuda.device_count(),
            "under_torch_distributed_run": os.environ.get("TORCHELASTIC_RUN_ID") is not None, "ranks": ranks,
-           "distinct_devices": len({(r["uuid"], r["pci_bus_id"], r["local_device_index"]) for r in ranks})}
+           "distinct_devices": launch.distinct_devices(ranks)}
+    if world > 1 and backend == "nccl" and rec["distinct_devices"] != world:      # launch.verify_world already refused this at start-up
+        raise SystemExit(f"{world} RCCL ranks on {rec['distinct_devices']} distinct devices")
     try:
         rec["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
     except Exception:  # noqa: BLE001
@@ -777,6 +776,14 @@ def main():
             line["roofline_bf16_igemm"] = roof_dgrad
         if strong:
             line["strong"] = strong
+        if world > 1:
+            # [r5] the two numbers a reader of a scaling run wants first, at the top level: the config-faithful strong-scaling step
+            # (the reference's global batch of 78 split over the ranks) and the part of the gradient exchange a step does not hide
+            line["strong_ms_per_step"] = strong["ms_per_step"] if strong else (tr["ms_per_step"] if args.scaling == "strong" else None)
+            line["strong_imgs_per_s"] = strong["value"] if strong else (train_ips if args.scaling == "strong" else None)
+            line["grad_exchange_exposed_ms"] = dist_info.get("grad_exchange_exposed_ms")
+            line["allreduce_ms"] = dist_info.get("allreduce_ms")
+            line["distinct_devices"] = dist_info.get("distinct_devices")
         if others:
             line["other_configs"] = others
         if pipeline:

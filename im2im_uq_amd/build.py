@@ -25,6 +25,7 @@ SOURCES = {
     "common.cpp": [],
     "hb_bound.cpp": ["-ffp-contract=off"],
     "rcps.hip": ["-ffp-contract=off"],
+    "conv_roll.hip": ["-ffp-contract=off"],   # [r5] same rounding rule for its lazy BatchNorm+ReLU staging
     "conv_mfma.hip": ["-ffp-contract=off"],   # lazy BatchNorm+ReLU in the operand staging must round exactly like bn_relu_apply
     # (the same lazy transform on the weight gradient's x operand); max-ILP machine scheduling: +1.2 % on the 13 BASELINE weight
     # gradients (949-951 -> 957-964 TF, profiles/r04_ab_experiments.txt section 9) -- and -15 % on conv_mfma.hip, which keeps the default

@@ -8,6 +8,7 @@ themselves under `torch.distributed.run` when they are asked for N > 1 GPUs and 
 """
 from __future__ import annotations
 
+import datetime
 import os
 import socket
 import subprocess
@@ -69,10 +70,47 @@ def init_distributed(expected_world: int | None = None):
     if world == 1:
         return None, 0, 1, dev, None
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # a rank that never shows up must fail the job within a minute, not hang it until the driver's clock runs out
+    timeout = datetime.timedelta(seconds=int(os.environ.get("IM2IM_RENDEZVOUS_TIMEOUT_S", "60")))
     if backend == "nccl":
-        dist.init_process_group(backend="nccl", device_id=dev)
+        dist.init_process_group(backend="nccl", device_id=dev, timeout=timeout)
     else:
-        dist.init_process_group(backend=backend)
+        dist.init_process_group(backend=backend, timeout=timeout)
     if dist.get_world_size() != world:
         raise SystemExit(f"process group has {dist.get_world_size()} ranks, expected {world}")
+    verify_world(dist, rank, world, dev, backend)
     return dist, rank, world, dev, backend
+
+
+def device_identity(dev, rank: int) -> dict:
+    """what tells two ranks' GPUs apart: index, name, uuid, PCI bus id (+ the pid that holds it)"""
+    import torch
+    props = torch.cuda.get_device_properties(dev)
+    return {"rank": rank, "local_device_index": dev.index, "name": props.name, "uuid": str(getattr(props, "uuid", "")) or None,
+            "pci_bus_id": ("%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))),
+            "pid": os.getpid()}
+
+
+def distinct_devices(ranks) -> int:
+    return len({(r["uuid"], r["pci_bus_id"], r["local_device_index"]) for r in ranks})
+
+
+def verify_world(dist, rank: int, world: int, dev, backend: str):
+    """[r5] first collective of the job, right after the rendezvous: every rank's device identity is gathered over the job's own
+    process group and a one-element all-reduce counts the ranks that answer.  N ranks over RCCL on fewer than N distinct devices,
+    or a communicator that sums to anything but N, is a non-zero exit on EVERY rank here -- before any benchmark leg has run --
+    instead of a line that says n_gpus = N about a job that was not.  (gloo with IM2IM_DIST_BACKEND=gloo is the functional-test
+    path: ranks may share a GPU there and only the rank count is checked.)  Returns the gathered identities."""
+    import torch
+    ranks = [None] * world
+    dist.all_gather_object(ranks, device_identity(dev, rank))
+    one = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(one)
+    n = int(round(float(one.item())))
+    if n != world:
+        raise SystemExit(f"[rank {rank}] the {backend} communicator summed {n} ranks, expected {world}")
+    nd = distinct_devices(ranks)
+    if backend == "nccl" and nd != world:
+        raise SystemExit(f"[rank {rank}] {world} RCCL ranks sit on {nd} distinct device(s): "
+                         + ", ".join(f"rank {r['rank']} -> {r['pci_bus_id']}" for r in ranks))
+    return ranks

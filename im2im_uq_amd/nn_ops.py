@@ -422,6 +422,8 @@ def conv_fwd_fp8(x, wq, wscale, bias=None, scale_shift=None, relu=False, want_st
 
 if os.environ.get("IM2IM_BN_FUSED_SMALL") is not None:   # A/B: one-launch BatchNorm sums for <= 256 partial rows (default on)
     check(lib.im2im_set_option(b"bn_fused_small", int(os.environ["IM2IM_BN_FUSED_SMALL"])), "im2im_set_option")
+if os.environ.get("IM2IM_CONV_ROLL") is not None:         # A/B: 0 = conv_igemm_kernel also for the 64-output-channel full-resolution layers
+    check(lib.im2im_set_option(b"conv_roll", int(os.environ["IM2IM_CONV_ROLL"])), "im2im_set_option")
 if os.environ.get("IM2IM_CONV_SPLITK") is not None:       # A/B of the split-K target (see im2im_set_option): 0 = off
     check(lib.im2im_set_option(b"conv_splitk", int(os.environ["IM2IM_CONV_SPLITK"])), "im2im_set_option")
 
@@ -808,11 +810,14 @@ def smallconv_wgrad(s_nchw, l_nhwc, l_major, want_bias):
 # ----------------------------------------------------------------------------------------- autograd
 LAZY_ATTR = "_im2im_lazy_ss"
 LINK_ATTR = "_im2im_bn_link"
-FUSE_BN_REDUCE = os.environ.get("IM2IM_FUSE_BN_REDUCE", "0") == "1"    # opt-in: a conv that is the only consumer of a lazy activation folds that layer's BatchNorm-backward
-                          # reduction into its own data-gradient epilogue (im2im_conv_dgrad_bn).  Measured (tools/bench_bn_fuse.py,
-                          # profiles): every layer gains 0.02-0.18 ms in isolation, but in the step the power-limited MFMA
-                          # kernels pay for the extra epilogue work and the net is +0.5 % -- not worth making the conv kernel
-                          # slower, so the separate bandwidth-bound reduction stays the default
+FUSE_BN_REDUCE = os.environ.get("IM2IM_FUSE_BN_REDUCE", "1") != "0"    # a conv that is the only consumer of a lazy activation folds that layer's BatchNorm-backward
+                          # reduction into its own data-gradient epilogue (im2im_conv_dgrad_bn): one pass over da and z fewer per layer
+                          # and one launch fewer.  [r5] default ON: with the round-4 weight-gradient kernels the step gains 1.2 % at
+                          # batch 78 (41.01 -> 40.54 ms, two alternating pairs on one box) and 2.0 % at the per-GPU batch of 10
+                          # (7.04 -> 6.90 ms), profiles/r05_ab_experiments.txt section 3 -- rounds 1-4 measured +0.2..0.6 % and left it off.
+                          # The price is visible in the conv kernel's own number: the data-gradients that carry the sums run ~5 %
+                          # slower (the epilogue reads z and does ~8 VALU per value), so `roofline.achieved` of conv_igemm drops
+                          # while img/s rises; IM2IM_FUSE_BN_REDUCE=0 restores the separate bandwidth-bound reduction
 
 
 class BnLink:

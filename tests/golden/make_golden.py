@@ -499,6 +499,39 @@ def g14(only_parts=()):
         save("g14_" + name, **rec)
 
 
+# ---------------------------------------------------------------- G19 Adam trajectory on WELL-CONDITIONED weights
+def g19():
+    """[r5] the whole inner loop of train_net (core/scripts/train.py:141-165: forward, loss, zero_grad, backward, Adam step) for TEN
+    steps on a network with the reference's own DEFAULT initialisation (nn.Conv2d / nn.BatchNorm2d defaults under a fixed
+    torch.manual_seed -- what router.py trains from), not the closed-form det_state weights of G5 whose dead channels make Adam's
+    sign(g) updates a coin flip.  A depth-2, base-32 assembly of the reference's DoubleConv / Down / Up / OutConv (RefUNetDepth
+    below) keeps the stored initial + final state_dicts small; noise images (no max-pool / ReLU near-ties); lr 1e-4."""
+    torch.manual_seed(1234)
+    model = add_uncertainty(RefUNetDepth(1, 1, 2, base=32), dict(PARAMS))
+    init = {k: v.clone() for k, v in model.state_dict().items()}
+    lr, steps, nb, hw = 1e-4, 10, 4, 32
+    fix_randomness(19)
+    ys = torch.rand(steps, nb, 1, hw, hw)
+    xs = ys + 0.1 * torch.randn(steps, nb, 1, hw, hw)
+    opt = torch.optim.Adam(model.parameters(), lr=lr)     # train.py:120
+    model.train()
+    losses = []
+    for s in range(steps):
+        pred = model(xs[s])                                # train.py:152
+        loss = model.loss_fn(pred, ys[s])                  # train.py:153
+        losses.append(loss.item())
+        opt.zero_grad(); loss.backward(); opt.step()       # train.py:158-162
+    model.eval()
+    with torch.no_grad():
+        probe = model(xs[0])
+    rec = {"losses": np.array(losses), "x": xs, "y": ys, "lr": np.array(lr), "probe_out": probe, "depth": np.array(2), "base": np.array(32)}
+    for k, v in init.items():
+        rec["init." + k] = v
+    for k, v in model.state_dict().items():
+        rec["final." + k] = v.clone()
+    save("g19_adam_trajectory_default_init", **rec)
+
+
 # ---------------------------------------------------------------- G17 UNets of other depths, from the reference's own parts
 class RefUNetDepth(nn.Module):
     """the reference's DoubleConv / Down / Up / OutConv assembled by the recipe of core/models/trunks/unet.py:20-46 for
@@ -674,7 +707,7 @@ def g18():
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
-    for name, fn in (("g1_g2", g1_g2), ("g3", g3), ("g4", g4), ("g5", g5), ("g6", g6), ("g7", g7), ("g8", g8),
+    for name, fn in (("g1_g2", g1_g2), ("g3", g3), ("g4", g4), ("g5", g5), ("g19", g19), ("g6", g6), ("g7", g7), ("g8", g8),
                      ("g9_g10", g9_g10), ("g11", g11), ("g12", g12), ("g13", g13), ("g14", g14), ("g15", g15), ("g16", g16), ("g17", g17), ("g18", g18)):
         if not only or name in only:
             fn()

@@ -305,3 +305,14 @@ def test_graphed_step_policy_helpers_on_cpu():
         def forward(self, x):
             return x
     assert not GraphedStep.static_module(torch.nn.Sequential(net, Mine()), {})
+
+
+def test_distinct_devices_counts_physical_devices_not_ranks():
+    """[r5] launch.distinct_devices: what `bench.py --gpus N` holds against N before it runs anything (uuid, PCI bus id and local
+    index together identify a device; two ranks on one GPU are ONE device)."""
+    from im2im_uq_amd import launch
+    a = {"rank": 0, "uuid": "GPU-a", "pci_bus_id": "0000:05:00", "local_device_index": 0, "pid": 1}
+    b = {"rank": 1, "uuid": "GPU-b", "pci_bus_id": "0000:15:00", "local_device_index": 1, "pid": 2}
+    assert launch.distinct_devices([a, b]) == 2
+    assert launch.distinct_devices([a, dict(a, rank=1, pid=2)]) == 1
+    assert launch.distinct_devices([a, b, dict(b, rank=2, pid=3), dict(a, rank=3, pid=4)]) == 2

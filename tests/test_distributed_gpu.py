@@ -66,6 +66,11 @@ def test_bench_gpus_2_spawns_its_own_ranks():
     assert ds["distinct_devices"] == 1 and all(r["local_device_index"] == 0 for r in ds["ranks"])
     assert ds["allreduce_ms"] > 0 and ds["allreduce_busbw_gbs"] > 0
     assert ds["step_ms_with_grad_exchange"] > 0 and ds["step_ms_without_grad_exchange"] > 0 and "grad_exchange_exposed_ms" in ds
+    # [r5] ... and repeats the scaling run's first-look numbers at the top level
+    assert d["strong_ms_per_step"] == d["strong"]["ms_per_step"] and d["strong_imgs_per_s"] == d["strong"]["value"]
+    assert d["grad_exchange_exposed_ms"] == ds["grad_exchange_exposed_ms"] and d["allreduce_ms"] == ds["allreduce_ms"]
+    assert d["distinct_devices"] == 1
+    assert "other_configs" not in d and "fastmri_pipeline" not in d and d["fp32"] is None and d["cpu_baseline"] is None   # N > 1 runs only the scaling legs
 
 
 def test_bench_gpus_2_over_rccl_needs_two_gpus():
@@ -78,3 +83,41 @@ def test_bench_gpus_2_over_rccl_needs_two_gpus():
                        capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     assert r.returncode != 0 and "need 2 GPUs" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def _verify_worker(rank, world, port, tmpdir):
+    import torch
+    import torch.distributed as dist
+    from im2im_uq_amd import launch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    out = {}
+    try:
+        ranks = launch.verify_world(dist, rank, world, dev, "gloo")          # functional-test backend: a shared GPU is allowed
+        out["ok"] = [r["rank"] for r in ranks] == [0, 1] and launch.distinct_devices(ranks) == 1
+        try:
+            launch.verify_world(dist, rank, world, dev, "nccl")              # the measured backend's rule on the same (shared-GPU) world
+            out["refused"] = None
+        except SystemExit as e:
+            out["refused"] = str(e)
+    finally:
+        dist.destroy_process_group()
+    with open(os.path.join(tmpdir, f"verify_{rank}.json"), "w") as f:
+        json.dump(out, f)
+
+
+def test_verify_world_refuses_n_rccl_ranks_on_fewer_devices(tmp_path):
+    """[r5] launch.verify_world (called by init_distributed right after the rendezvous, so by `bench.py --gpus N` before any leg):
+    every rank learns every rank's device over the job's own process group; two ranks that would be RCCL ranks on ONE device are a
+    SystemExit naming the devices on BOTH ranks, the rank count is checked by a one-element all-reduce.  (Two ranks, gloo, one GPU.)"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_verify_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for rank in (0, 1):
+        out = json.load(open(tmp_path / f"verify_{rank}.json"))
+        assert out["ok"] is True
+        assert out["refused"] and "2 RCCL ranks sit on 1 distinct device" in out["refused"]

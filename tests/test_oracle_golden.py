@@ -105,6 +105,23 @@ def test_g5_adam_trajectory():
     np.testing.assert_allclose(st[k].flatten().numpy()[::max(1, st[k].numel() // 512)][:512], g["sample." + k], atol=2e-4)
 
 
+def test_g19_adam_trajectory_on_default_init():
+    """[r5] ten steps of the reference's inner loop (train.py:141-165) from its own default initialisation (fixture G19): the oracle
+    walks the same trajectory -- every loss and every tensor of the final state_dict to 1e-6 (bit-equal on the torch build that
+    generated the fixture), so the `-m gpu` test that compares the HIP path with G19 compares it with the oracle too."""
+    g = load_golden("g19_adam_trajectory_default_init")
+    st = {k[len("init."):]: T(v) for k, v in g.items() if k.startswith("init.")}
+    assert om.unet_depth(st) == int(g["depth"]) == 2
+    x, y = T(g["x"]), T(g["y"])
+    losses = om.train_steps(st, [(x[i], y[i]) for i in range(x.shape[0])], PARAMS, lr=float(g["lr"]))
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-6)
+    for k, v in st.items():
+        np.testing.assert_allclose(v.numpy(), g["final." + k], rtol=0, atol=1e-6, err_msg=k)
+    with torch.no_grad():
+        probe = om.model_forward(x[0], st, training=False)
+    np.testing.assert_allclose(probe.numpy(), g["probe_out"], rtol=0, atol=1e-6)
+
+
 def test_g6_nested_sets():
     g = load_golden("g6_nested_sets")
     out = T(g["output"])

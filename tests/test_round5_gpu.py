@@ -354,3 +354,141 @@ def test_eval_fused_outconv_respects_hooks_and_a_dtype_override_on_outconv():
         assert not getattr(feat, "_im2im_tail_done", False) and feat.dtype == torch.float32
         model.baseModel.out.compute_dtype = None
         assert torch.equal(model(x), ref)
+
+
+# ------------------------------------------------------------------------------------------------ conv_roll64_kernel (csrc/conv_roll.hip)
+ROLL_CASES = [
+    # B, H, W, Ci, Co, split input, lazy input
+    (1, 64, 64, 96, 64, False, False),       # three 32-channel chunks = six units, every tile touches an image edge
+    (3, 64, 128, 64, 64, False, True),       # odd batch, lazy BatchNorm+ReLU on the staged input
+    (2, 96, 80, 128, 64, True, True),        # [skip, upsampled] from two tensors, only the first one lazy (the Up block's first conv)
+    (1, 64, 64, 32, 192, False, False),      # three 64-channel output blocks per pixel tile, one unit pair
+    (5, 320, 320, 64, 64, False, True),      # BASELINE layer shape: 1,000 tiles on 512 persistent workgroups (runs of 1-2 tiles)
+]
+
+
+@pytest.mark.parametrize("case", ROLL_CASES)
+def test_conv_roll64_kernel_vs_cpu_and_vs_conv_igemm(case):
+    """the persistent, software-pipelined kernel of the 64-output-channel full-resolution layers (option conv_roll = 1; the default
+    routes these launches to conv_igemm_kernel) against F.conv2d in fp32 on operands quantised as the kernel sees them (bf16
+    tolerance 1.5e-2 relative L2, worst element 6 % of the RMS) and against conv_igemm_kernel on the same inputs: same values up
+    to the order of the fp32 sums (1e-4 relative L2; one bf16 ulp on single elements), same BatchNorm partial statistics
+    (count exact, mean / M2 to 1e-5 after merging), forward with statistics, the folded eval epilogue and the plain
+    data-gradient form."""
+    import torch.nn.functional as F
+    from im2im_uq_amd import hip_ops, nn_ops
+    from test_kernels_gpu import merged_moments
+    b, h, w, ci, co, split, lazy = case
+    BF = torch.bfloat16
+    g = torch.Generator().manual_seed(7)
+    cin = ci // 2 if split else ci
+    x = torch.randn(b, h, w, cin, generator=g).to(BF)
+    xh = torch.randn(b, h, w, cin, generator=g).to(BF) if split else None
+    wt = torch.randn(co, ci, 3, 3, generator=g) * (ci * 9) ** -0.5
+    bias = torch.randn(co, generator=g) * 0.1
+    ss = torch.stack([torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.5]) if lazy else None
+    fold = torch.stack([torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g)])
+    # CPU reference: the staged operand is bf16(max(x * scale + shift, 0)) for the lazy source, x itself otherwise
+    a_lo = x.float()
+    if lazy:
+        a_lo = torch.relu(a_lo * ss[0] + ss[1]).to(BF).float()
+    a_full = torch.cat([a_lo, xh.float()], dim=3) if split else a_lo
+    ref = F.conv2d(a_full.permute(0, 3, 1, 2), wt.to(BF).float(), bias, padding=1)
+    wf, wd = nn_ops.pack_weight(wt.to(DEV), BF)
+    xd, xhd, ssd = x.to(DEV), (xh.to(DEV) if split else None), (ss.to(DEV) if lazy else None)
+    got = {}
+    try:
+        for mode in (0, 1):
+            hip_ops.set_option("conv_roll", mode)
+            y, st = nn_ops.conv_fwd(xd, wf, bias.to(DEV), want_stats=True, in_ss=ssd, x_hi=xhd)
+            y2 = nn_ops.conv_fwd(xd, wf, None, fold.to(DEV), relu=True, in_ss=ssd, x_hi=xhd)
+            y3 = nn_ops.conv_fwd(xd, wf, in_ss=ssd, x_hi=xhd)                 # EPI 0 (what a data-gradient launch is)
+            torch.cuda.synchronize()
+            got[mode] = (y.float().cpu(), st.cpu(), y2.float().cpu(), y3.float().cpu())
+    finally:
+        hip_ops.set_option("conv_roll", 0)
+    y, st, y2, y3 = got[1]
+    ref_nhwc = ref.permute(0, 2, 3, 1)
+    assert rel_l2(y, ref_nhwc) < 1.5e-2
+    assert float((y - ref_nhwc).abs().max()) < 6e-2 * float(ref_nhwc.pow(2).mean().sqrt())
+    ref2 = torch.relu((ref_nhwc - bias) * fold[0] + fold[1])
+    assert rel_l2(y2, ref2) < 1.5e-2
+    assert rel_l2(y3, ref_nhwc - bias) < 1.5e-2
+    for k in (0, 2, 3):                                       # the same numbers as conv_igemm_kernel up to summation order
+        assert rel_l2(got[1][k], got[0][k]) < 1e-4, k
+    n1, m1, q1 = merged_moments(st)
+    n0, m0, q0 = merged_moments(got[0][1])
+    assert torch.equal(n1, n0) and float((n1 - b * h * w).abs().max()) == 0.0
+    yst = y.double().reshape(-1, co)
+    np.testing.assert_allclose(m1.numpy(), yst.mean(0).numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(q1.numpy(), ((yst - yst.mean(0)) ** 2).sum(0).numpy(), rtol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ G19: the train loop on well-conditioned weights
+def test_g19_adam_trajectory_on_default_init_fp32():
+    """fixture G19 (tests/golden/make_golden.py g19): TEN steps of the reference's inner training loop (core/scripts/train.py:141-165,
+    torch.optim.Adam lr 1e-4) on the reference's own default initialisation (depth-2 / base-32 assembly of its DoubleConv / Down /
+    Up / OutConv, noise images) -- weights on which the trajectory is well-conditioned, unlike G5's closed-form ones.  fp32 mode:
+    the WHOLE loss trajectory within 1e-3 relative, the eval-mode probe within 1e-3 relative L2, and after the ten steps every
+    state_dict tensor equals the reference's within what ten Adam steps can differ by -- EXCEPT the documented ones: the ten
+    pre-BatchNorm conv biases (the reference feeds Adam their rounding-noise gradients and they drift by up to 2.7e-4; here their
+    gradient is exactly zero and they stay put) and, with them, the running means they shift (running_mean - bias,
+    what eval mode uses, is compared instead)."""
+    from im2im_uq_amd import nn_ops
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from im2im_uq_amd.core.models.trunks.unet import UNet
+    from conftest import load_golden
+    g = load_golden("g19_adam_trajectory_default_init")
+    nn_ops.set_compute_dtype("fp32")
+    model = add_uncertainty(UNet(1, 1, depth=int(g["depth"]), base=int(g["base"])), dict(PARAMS))
+    init = {k[len("init."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("init.")}
+    assert list(model.state_dict().keys()) == list(init.keys())
+    model.load_state_dict(init)
+    model = model.to(DEV).train()
+    lr = float(g["lr"])
+    opt = nn_ops.FusedAdam(model.parameters(), lr=lr)
+    x, y = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["y"]).to(DEV)
+    losses = []
+    for s in range(x.shape[0]):
+        loss = model.loss_fn(model(x[s]), y[s])
+        losses.append(loss.item())
+        opt.zero_grad(); loss.backward(); opt.step()
+    print("\n[g19] losses HIP " + " ".join(f"{v:.6f}" for v in losses) + "\n      reference " + " ".join(f"{v:.6f}" for v in g["losses"]))
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-3)                  # the whole trajectory
+    assert losses[-1] < 0.85 * losses[0]
+    model.eval()
+    with torch.no_grad():
+        probe = model(x[0])
+    assert rel_l2(probe.cpu(), g["probe_out"]) < 1e-3
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    pre_bn_bias = [k for k in sd if k.endswith(".double_conv.0.bias") or k.endswith(".double_conv.3.bias")]
+    assert len(pre_bn_bias) == 10
+    worst = {}
+    for k, v in sd.items():
+        ref = torch.from_numpy(g["final." + k])
+        if k in pre_bn_bias:
+            assert torch.equal(v, init[k])                                      # zero gradient: Adam never moves them here
+            assert 1e-5 < float((ref - init[k]).abs().max()) < 5 * 10 * lr     # ... while the reference's drift on rounding noise
+            continue
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(ref) == x.shape[0]
+            continue
+        slack = 0.0
+        if k.endswith("running_mean"):
+            # an average of the batch means of conv + bias over the ten steps: the reference's carries its drifting bias with the
+            # weights of the ten steps, so minus the FINAL bias it still differs by up to that layer's drift -- nothing else
+            bias_k = k[:-len("1.running_mean")] + "0.bias" if k.endswith(".1.running_mean") else k[:-len("4.running_mean")] + "3.bias"
+            ref_bias = torch.from_numpy(g["final." + bias_k])
+            slack = float((ref_bias - init[bias_k]).abs().max())
+            v, ref = v - sd[bias_k], ref - ref_bias
+        d = (v.double() - ref.double()).abs()
+        worst[k] = (float(d.max()), float(d.median()), float(ref.abs().max()), slack)
+    big = sorted(worst.items(), key=lambda kv: -kv[1][0])[:4]
+    print("[g19] largest per-tensor max |diff| after 10 steps: " + "; ".join(f"{k} {v[0]:.2e} (median {v[1]:.1e})" for k, v in big))
+    notrm = {k: v for k, v in worst.items() if not k.endswith("running_mean")}
+    print("[g19] ... outside the running means: " + "; ".join(f"{k} {v[0]:.2e} (median {v[1]:.1e})" for k, v in sorted(notrm.items(), key=lambda kv: -kv[1][0])[:4]))
+    for k, (m, md, scale, slack) in worst.items():
+        # a weight whose gradient is ~0 can take +-lr steps of either sign in two fp32 implementations: bound = the ten steps; the
+        # typical element must agree to rounding noise (+ the bias drift the reference's running means carry, see above)
+        assert m <= 2 * 10 * lr + 1e-5 * scale + slack, (k, m)
+        assert md <= 2e-6 + 1e-5 * scale + slack, (k, md)
