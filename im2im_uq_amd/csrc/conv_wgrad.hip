@@ -1493,6 +1493,7 @@ namespace {
 int g_wgrad_co128 = 1;      // A/B switch (im2im_set_option "wgrad_co128")
 int g_wgrad_tile16 = 1;     // A/B switch "wgrad_tile16": 256-pixel tiles for the 64-output-channel form
 int g_wgrad_fp8_co128 = 1;  // A/B switch "wgrad_fp8_co128": the fp8 weight gradient's 128-output-channel form where Co % 128 == 0
+int g_wgrad_wgs = 256;      // A/B switch "wgrad_wgs": workgroups a bf16 3x3 weight-gradient launch aims at (split-K slabs = this / channel blocks)
 int g_wgrad_roll = 1;       // A/B switch "wgrad_roll": conv_wgrad_roll_kernel (rolling operand prefetch, staging spread over the MFMA phase)
 template <typename T, int TAPS>
 int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float* x_ss_hi, int Ci_lo, const void* dz, float* partial,
@@ -1508,7 +1509,7 @@ int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float
   const size_t wsz = (size_t)Co * TAPS * Ci * sizeof(float);
   int64_t max_split = partial_bytes / (int64_t)wsz;
   if (max_split < 1) return fail_invalid("wgrad: workspace smaller than one weight-sized slab");
-  int64_t nsplit = cdiv((IS_BF16 && TAPS == 9) ? 256 : (TAPS == 1 ? 1536 : 512), cblocks);   // pipelined kernel: one workgroup per CU; 1x1: latency-bound, many small blocks
+  int64_t nsplit = cdiv((IS_BF16 && TAPS == 9) ? g_wgrad_wgs : (TAPS == 1 ? 1536 : 512), cblocks);   // pipelined kernel: one workgroup per CU; 1x1: latency-bound, many small blocks
   if (nsplit > a.ntiles) nsplit = a.ntiles;
   if (nsplit > max_split) nsplit = max_split;
   if (nsplit < 1) nsplit = 1;
@@ -1520,7 +1521,7 @@ int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float
     const bool wide = g_wgrad_co128 && Co % 128 == 0;         // 128 output channels per workgroup (see the kernel)
     if (wide) {
       const int cb128 = (Co / 128) * (Ci / 64);
-      nsplit = cdiv(256, cb128);
+      nsplit = cdiv(g_wgrad_wgs, cb128);
       if (nsplit > a.ntiles) nsplit = a.ntiles;
       if (nsplit > max_split) nsplit = max_split;
       if (nsplit < 1) nsplit = 1;
@@ -1663,6 +1664,7 @@ extern "C" int im2im_set_option(const char* key, int32_t value) {
   if (std::string(key) == "wgrad_co128") { g_wgrad_co128 = value; return IM2IM_OK; }
   if (std::string(key) == "wgrad_tile16") { g_wgrad_tile16 = value; return IM2IM_OK; }
   if (std::string(key) == "wgrad_roll") { g_wgrad_roll = value; return IM2IM_OK; }
+  if (std::string(key) == "wgrad_wgs") { g_wgrad_wgs = value > 0 ? value : 256; return IM2IM_OK; }
   if (std::string(key) == "wgrad_fp8_co128") { g_wgrad_fp8_co128 = value; return IM2IM_OK; }
   if (std::string(key) == "bn_fused_small") { im2im::set_bn_fused_small(value); return IM2IM_OK; }
   if (std::string(key) == "conv_roll") { im2im::set_conv_roll(value); return IM2IM_OK; }
@@ -1730,7 +1732,7 @@ extern "C" int im2im_conv_wgrad_fp8(const void* x, const float* x_scale_shift, c
   const size_t wsz = (size_t)Co * 9 * Ci * sizeof(float);
   const int64_t max_split = workspace_bytes / (int64_t)wsz;
   if (max_split < 1) return fail_invalid("wgrad_fp8: workspace smaller than one weight-sized slab");
-  int64_t nsplit = cdiv(256, cblocks);
+  int64_t nsplit = cdiv(g_wgrad_wgs, cblocks);
   if (nsplit > a.ntiles) nsplit = a.ntiles;
   if (nsplit > max_split) nsplit = max_split;
   if (nsplit < 1) nsplit = 1;

@@ -364,6 +364,7 @@ def conv_wgrad_fp8(x, dz, amax_prev, x_ss=None, x_hi=None, x_ss_hi=None, scratch
     nbytes = lib.im2im_conv_wgrad_workspace_bytes(b, h, w_, ci, co, 9)
     ws = _Scratch.get(nbytes, x.device, scratch_key)
     dw = torch.empty((co, ci, 9), dtype=F32, device=x.device) if out is None else out
+    _set_wgrad_width(x.device)
     ev = TIMER.wrap(f"conv_wgrad_fp8_kernel<{128 if co % 128 == 0 else 64}>", 2.0 * b * h * w_ * co * ci * 9, x.device) if TIMER else None
     check(lib.im2im_conv_wgrad_fp8(dptr(x), dptr(x_ss), dptr(x_hi), dptr(x_ss_hi), ci_lo, dptr(dz), amax_prev, dptr(dw), dptr(ws), ws.numel(),
                                    b, h, w_, ci, co, stream_ptr(x.device)), "im2im_conv_wgrad_fp8")
@@ -626,6 +627,26 @@ def _on_side_stream(device, tensors, fn, after=None):
         fn()
 
 
+# [r5] width of a bf16 3x3 weight-gradient launch (split-K slabs = workgroups / channel blocks, one 768-thread workgroup per CU):
+# ALONE on the chip it wants every CU (256 workgroups: 1,070 TF over the 17 layers against 720 at 128); issued from the side stream
+# it shares the chip with the main stream's data-gradients and BatchNorm passes, and half the width is the faster STEP -- the other
+# kernels keep half the CUs, the fp32 partial slabs (written by the kernel, read back by wgrad_reduce) halve: batch 78 39.07 ->
+# 38.59 ms, per-GPU batch 10 6.68 -> 6.35 ms (64: 6.97, 96: 6.35, 160: 6.50, 192: 6.30 / 38.95; profiles/r05_ab_experiments.txt
+# section 5).  IM2IM_WGRAD_WGS pins one width for both cases (A/B runs).
+_WGS_PIN = os.environ.get("IM2IM_WGRAD_WGS")
+WGRAD_WGS_ALONE = int(_WGS_PIN) if _WGS_PIN else 256
+WGRAD_WGS_SIDE = int(_WGS_PIN) if _WGS_PIN else int(os.environ.get("IM2IM_WGRAD_WGS_SIDE", "128"))
+_wgs_now = [256]
+
+
+def _set_wgrad_width(device):
+    side = _side_streams.get(torch.device(device).index)
+    want = WGRAD_WGS_SIDE if (side is not None and torch.cuda.current_stream(device) == side) else WGRAD_WGS_ALONE
+    if want != _wgs_now[0]:
+        check(lib.im2im_set_option(b"wgrad_wgs", want), "im2im_set_option")
+        _wgs_now[0] = want
+
+
 def conv_wgrad(x, dz, taps, x_ss=None, x_hi=None, x_ss_hi=None, scratch_key="a", out=None):
     """x [B,H,W,Ci], dz [B,H,W,Co] -> dw [Co,Ci,taps] fp32 (x_ss: lazy BatchNorm+ReLU of x, as in conv_fwd; x_hi: second
     half of the input channels as in conv_fwd).  out: a preallocated [Co,Ci,taps] fp32 result."""
@@ -639,6 +660,7 @@ def conv_wgrad(x, dz, taps, x_ss=None, x_hi=None, x_ss_hi=None, scratch_key="a",
         raise _lib.Im2ImError(f"conv wgrad: unsupported channels Ci={ci} Co={co}")
     ws = _Scratch.get(nbytes, x.device, scratch_key)
     dw = torch.empty((co, ci, taps), dtype=F32, device=x.device) if out is None else out
+    _set_wgrad_width(x.device)
     ev = TIMER.wrap(_tile_name("wgrad", h, w_, co, taps, x.dtype), 2.0 * b * h * w_ * co * ci * taps, x.device) if TIMER else None
     check(lib.im2im_conv_wgrad_split(dptr(x), dptr(x_ss), dptr(x_hi), dptr(x_ss_hi), ci_lo, dptr(dz), dptr(dw), dptr(ws), ws.numel(),
                                      b, h, w_, ci, co, taps, _DT[x.dtype], stream_ptr(x.device)), "im2im_conv_wgrad_split")

@@ -105,6 +105,9 @@ def _worker_rccl(rank, world, port, tmpdir):
         objs = [None]
         dist.all_gather_object(objs, {"rank": rank, "device": torch.cuda.current_device()})      # bench.py's per-rank device record
         assert objs[0]["rank"] == 0
+        from im2im_uq_amd import launch                     # [r5] the start-up check of `bench.py --gpus N`, on RCCL: identities gathered,
+        ids = launch.verify_world(dist, rank, world, torch.device(DEV), "nccl")      # ranks counted by an all-reduce, devices distinct
+        assert len(ids) == 1 and ids[0]["local_device_index"] == 0 and launch.distinct_devices(ids) == 1
         torch.cuda.synchronize()
         ver = ".".join(str(v) for v in torch.cuda.nccl.version())
         torch.save({"le": le, "ls": ls, "lg": lg, "se": se, "ss": ss, "sg": sg, "rccl": ver, "sum": float(t.sum()),
