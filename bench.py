@@ -737,7 +737,7 @@ def main():
     others = pipeline = None
     if default_run and world == 1:
         others = {}
-        for name, kw in (("batch10", dict(config="fastmri", batch=10, steps=10, warmup=3, calib=False)),
+        for name, kw in (("batch10", dict(config="fastmri", batch=10, steps=40, warmup=8, calib=False)),
                          ("denoise32", dict(config="denoise32", steps=40, warmup=6)), ("temca1024", dict(config="temca1024", steps=3)),
                          ("bsbcm512_fp8", dict(config="bsbcm512", steps=4)), ("bsbcm512_bf16", dict(config="bsbcm512", steps=4, dtype="bf16", calib=False))):
             try:
