@@ -842,6 +842,14 @@ FUSE_BN_REDUCE = os.environ.get("IM2IM_FUSE_BN_REDUCE", "1") != "0"    # a conv 
                           # while img/s rises; IM2IM_FUSE_BN_REDUCE=0 restores the separate bandwidth-bound reduction
 
 
+# ... but only where the normalised tensor has >= 128 channels, and not in OutConv's 1x1 data-gradient: on the 64-channel
+# full-resolution layers the fused launch costs what the separate reduction did (rocprofv3, batch 78: conv_igemm<32,16,64,EPI 3>
+# 896 us against 530 us for EPI 0 + a 0.32 ms reduction; the 1x1: 520 vs 273 us) -- the step is the same either way (39.03 / 39.01
+# vs 39.02 / 39.08 ms, batch 10 6.44 / 6.43 vs 6.48 / 6.45) and the conv kernels stay leaner (conv roofline 929 -> 954 TF)
+FUSE_BN_MIN_CH = int(os.environ.get("IM2IM_FUSE_BN_MIN_CH", "128"))
+FUSE_BN_1X1 = os.environ.get("IM2IM_FUSE_BN_1X1", "0") != "0"
+
+
 class BnLink:
     """what a lazy activation's consumers need to start its BatchNorm backward for it: the producer's z and coefficients,
     how many consumers read the activation in this forward, and (set by the consumer's backward) the partial sums."""
@@ -978,7 +986,7 @@ class ConvStats(torch.autograd.Function):
                 dw = wgrad(None, "a").view(dz.shape[3], ci, 3, 3)
             link = ctx.link
             fuse = (FUSE_BN_REDUCE and xin_hi is None and link is not None and link.consumers == 1 and link.z.dtype == dz.dtype
-                    and not ctx.fp8_dgrad)
+                    and not ctx.fp8_dgrad and link.z.shape[3] >= FUSE_BN_MIN_CH)
             b_first = 0
             if (xin_hi is not None or ctx.needs_input_grad[0]) and not fuse and not ctx.fp8_dgrad:
                 b_first = halves.b_first if halves is not None else _pipeline_split(dz)
@@ -1552,7 +1560,7 @@ class Conv1x1(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             link = ctx.link
-            if FUSE_BN_REDUCE and link is not None and link.consumers == 1 and link.z.dtype == dy.dtype:
+            if FUSE_BN_REDUCE and FUSE_BN_1X1 and link is not None and link.consumers == 1 and link.z.dtype == dy.dtype:
                 dx, link.partial = conv_dgrad_bn(dy, wd, link.z, link.ss, link.mi)     # as in ConvStats.backward
                 dx = nchw(dx)
             else:

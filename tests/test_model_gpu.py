@@ -397,6 +397,8 @@ def test_batchnorm_backward_sums_from_dgrad_epilogue_match_separate_reduction(dt
     from im2im_uq_amd import nn_ops
     x, y = om.det_images(3, 1, 50, 46, salt=7)
     res = []
+    monkeypatch.setattr(nn_ops, "FUSE_BN_MIN_CH", 0)          # [r5] every eligible layer, also the 64-channel ones and OutConv's 1x1
+    monkeypatch.setattr(nn_ops, "FUSE_BN_1X1", True)          # that the default policy leaves to the separate reduction
     for fused in (True, False):
         monkeypatch.setattr(nn_ops, "FUSE_BN_REDUCE", fused)
         model = build(1, dt)
