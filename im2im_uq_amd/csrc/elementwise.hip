@@ -815,7 +815,10 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
 // stored) and goes straight on with the BatchNorm backward.  APPLY = false: partial sums of g*mask and g*mask*xhat
 // (partial[block][2][C], fixed-order LDS combine => deterministic); APPLY = true: dz.
 // Windows include the odd last row/column (those pixels are not pooled and receive da only).
-template <typename T, bool APPLY>
+// FULL [r5]: H and W even and da present (every skip layer of the UNet at its benchmarked sizes): all four pixels of every window
+// exist and are pooled, so the loads, the arg-max and the stores are one straight line -- no exec branches around the nine loads
+// (with them the compiler cannot count its vmcnt waits and drains the queue at every merge point).  Same arithmetic.
+template <typename T, bool APPLY, bool FULL>
 __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const T* __restrict__ da, const T* __restrict__ dpool,
                                                                 const T* __restrict__ z, const float* __restrict__ scale_shift,
                                                                 const float* __restrict__ mean_invstd,
@@ -841,22 +844,27 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_kernel(const T* __restri
     const int b = row / Hc, yo = row - b * Hc;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < rowvecs; idx += gridDim.x * 256) {
       const int xo = idx >> rv.vshift;
-      const bool pooled = yo < Ho && xo < Wo;
+      const bool pooled = FULL || (yo < Ho && xo < Wo);
       float zz[4][N], g[4][N];
       bool ok[4];
       int64_t off[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int yy = 2 * yo + (q >> 1), xx = 2 * xo + (q & 1);
-        ok[q] = yy < H && xx < W;
+        ok[q] = FULL || (yy < H && xx < W);
         off[q] = ((((int64_t)b * H + yy) * W + xx) * (int64_t)C) + c0;
-        if (ok[q]) {
+        if constexpr (FULL) {
           Vec16<T>::load(z + off[q], zz[q]);
-          if (da) Vec16<T>::load(da + off[q], g[q]);
-        }
-        if (!ok[q] || !da) {
+          Vec16<T>::load(da + off[q], g[q]);
+        } else {
+          if (ok[q]) {
+            Vec16<T>::load(z + off[q], zz[q]);
+            if (da) Vec16<T>::load(da + off[q], g[q]);
+          }
+          if (!ok[q] || !da) {
 #pragma unroll
-          for (int k = 0; k < N; ++k) g[q][k] = 0.f;
+            for (int k = 0; k < N; ++k) g[q][k] = 0.f;
+          }
         }
       }
       if (pooled) {
@@ -1604,6 +1612,7 @@ inline dim3 row_grid(int rowvecs, int64_t rows) {
 inline int ew_blocks(int64_t n) { int64_t b = cdiv(n, 256); if (b > 256 * 32) b = 256 * 32; if (b < 1) b = 1; return (int)b; }
 
 // BatchNorm-backward sums: partial[R][2][C] -> dgamma, dbeta, coef; one launch for few rows, two stages otherwise
+int g_pool_bwd_full = 1;                                     // im2im_set_option("pool_bwd_full", 0 / 1): branch-free bn_relu_pool_bwd for even extents
 int g_bn_fused_small = 1;                                    // im2im_set_option("bn_fused_small", 0 / 1): A/B switch
 inline int launch_bn_bwd_sums(const float* partial, int64_t R, int C, double count, double* tmp, float* dgamma, float* dbeta,
                               float* coef, hipStream_t stream) {
@@ -1619,7 +1628,7 @@ inline int launch_bn_bwd_sums(const float* partial, int64_t R, int C, double cou
 }
 
 }  // namespace
-namespace im2im { void set_bn_fused_small(int v) { g_bn_fused_small = v; } }
+namespace im2im { void set_bn_fused_small(int v) { g_bn_fused_small = v; } void set_pool_bwd_full(int v) { g_pool_bwd_full = v; } }
 
 // ================================================================================================
 extern "C" int64_t im2im_reduce_workspace_bytes(int64_t K) { return im2im::reduce_tmp_bytes(K); }
@@ -1744,18 +1753,21 @@ extern "C" int im2im_bn_relu_bwd_phase(const void* da, const void* z, const floa
   });
 }
 
+constexpr int POOL_BWD_MAX_BLOCKS = 6144;
+int g_pool_bwd_blocks = 2048;                                // im2im_set_option("pool_bwd_blocks", n <= 6144): A/B -- 1,536 / 2,048 / 6,144 measured equal (r05_ab_experiments.txt section 6)
+namespace im2im { void set_pool_bwd_blocks(int v) { g_pool_bwd_blocks = v > 0 && v <= POOL_BWD_MAX_BLOCKS ? v : POOL_BWD_MAX_BLOCKS; } }
 namespace {
 inline dim3 pool_bwd_grid(int B, int H, int W, int vpr) {
   const int Hc = (H + 1) / 2, Wc = (W + 1) / 2;
   int gx = (int)cdiv((int64_t)Wc * vpr, 256);
   if (gx > 16) gx = 16;
-  int64_t gy = std::min<int64_t>((int64_t)B * Hc, std::max<int64_t>(2048 / gx, 1));
+  int64_t gy = std::min<int64_t>((int64_t)B * Hc, std::max<int64_t>(g_pool_bwd_blocks / gx, 1));
   return dim3((unsigned)gx, (unsigned)gy);
 }
 }  // namespace
 
 extern "C" int64_t im2im_bn_relu_pool_bwd_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C) {
-  const int64_t nblk = 2048 + 16;                               // upper bound of pool_bwd_grid's block count
+  const int64_t nblk = POOL_BWD_MAX_BLOCKS + 16;                // upper bound of pool_bwd_grid's block count
   return nblk * 2 * C * (int64_t)sizeof(float) + reduce_tmp_bytes(2 * (int64_t)C) + 2 * (int64_t)C * sizeof(float);
 }
 
@@ -1774,18 +1786,23 @@ extern "C" int im2im_bn_relu_pool_bwd(const void* da, const void* dpool, const v
   const dim3 grid = pool_bwd_grid(B, H, W, vpr);
   const int64_t nblk = (int64_t)grid.x * grid.y;
   float* partial = (float*)ws;
-  double* tmp = (double*)((char*)ws + (int64_t)(2048 + 16) * 2 * C * sizeof(float));
+  double* tmp = (double*)((char*)ws + (int64_t)(POOL_BWD_MAX_BLOCKS + 16) * 2 * C * sizeof(float));
   float* coef = (float*)((char*)tmp + reduce_tmp_bytes(2 * (int64_t)C));
   const double count = (double)B * H * W;
   return for_dtype(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
     const RowVec rv = make_rowvec(vpr);
-    hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<T, false>), grid, dim3(256), 0, stream, (const T*)da, (const T*)dpool, (const T*)z,
-                       scale_shift, mean_invstd, (const float*)nullptr, (T*)nullptr, partial, B, H, W, (int)C, rv);
+    const bool full = da != nullptr && H % 2 == 0 && W % 2 == 0 && g_pool_bwd_full;
+    if (full) hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<T, false, true>), grid, dim3(256), 0, stream, (const T*)da, (const T*)dpool, (const T*)z,
+                                 scale_shift, mean_invstd, (const float*)nullptr, (T*)nullptr, partial, B, H, W, (int)C, rv);
+    else hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<T, false, false>), grid, dim3(256), 0, stream, (const T*)da, (const T*)dpool, (const T*)z,
+                            scale_shift, mean_invstd, (const float*)nullptr, (T*)nullptr, partial, B, H, W, (int)C, rv);
     if (int rc = check_launch("bn_relu_pool_bwd_kernel<reduce>")) return rc;
     if (int rc = launch_bn_bwd_sums(partial, nblk, (int)C, count, tmp, dgamma, dbeta, coef, stream)) return rc;
-    hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<T, true>), grid, dim3(256), 0, stream, (const T*)da, (const T*)dpool, (const T*)z,
-                       scale_shift, mean_invstd, (const float*)coef, (T*)dz, (float*)nullptr, B, H, W, (int)C, rv);
+    if (full) hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<T, true, true>), grid, dim3(256), 0, stream, (const T*)da, (const T*)dpool, (const T*)z,
+                                 scale_shift, mean_invstd, (const float*)coef, (T*)dz, (float*)nullptr, B, H, W, (int)C, rv);
+    else hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<T, true, false>), grid, dim3(256), 0, stream, (const T*)da, (const T*)dpool, (const T*)z,
+                            scale_shift, mean_invstd, (const float*)coef, (T*)dz, (float*)nullptr, B, H, W, (int)C, rv);
     return check_launch("bn_relu_pool_bwd_kernel<apply>");
   });
 }

@@ -423,6 +423,10 @@ def conv_fwd_fp8(x, wq, wscale, bias=None, scale_shift=None, relu=False, want_st
 
 if os.environ.get("IM2IM_BN_FUSED_SMALL") is not None:   # A/B: one-launch BatchNorm sums for <= 256 partial rows (default on)
     check(lib.im2im_set_option(b"bn_fused_small", int(os.environ["IM2IM_BN_FUSED_SMALL"])), "im2im_set_option")
+if os.environ.get("IM2IM_POOL_BWD_BLOCKS") is not None:   # A/B: workgroups of bn_relu_pool_bwd (default 6144; 2048 until round 5)
+    check(lib.im2im_set_option(b"pool_bwd_blocks", int(os.environ["IM2IM_POOL_BWD_BLOCKS"])), "im2im_set_option")
+if os.environ.get("IM2IM_POOL_BWD_FULL") is not None:     # A/B: 0 = the branching form of bn_relu_pool_bwd also for even extents
+    check(lib.im2im_set_option(b"pool_bwd_full", int(os.environ["IM2IM_POOL_BWD_FULL"])), "im2im_set_option")
 if os.environ.get("IM2IM_CONV_ROLL") is not None:         # A/B: 0 = conv_igemm_kernel also for the 64-output-channel full-resolution layers
     check(lib.im2im_set_option(b"conv_roll", int(os.environ["IM2IM_CONV_ROLL"])), "im2im_set_option")
 if os.environ.get("IM2IM_CONV_SPLITK") is not None:       # A/B of the split-K target (see im2im_set_option): 0 = off
