@@ -428,7 +428,7 @@ def roofline_leg(wl, config_name, full=True):
     try:
         # counter-based utilisation from the committed PMC passes (busy MFMA cycles / elapsed SIMD cycles at the clock the chip
         # actually ran): a second reading beside `frac`, which divides FLOP/s by the nominal-clock peak
-        name = next(n for n in ("r04_pmc_mfma_busy.json", "r02_pmc_mfma_busy.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        name = next(n for n in ("r05_pmc_mfma_busy.json", "r04_pmc_mfma_busy.json", "r02_pmc_mfma_busy.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
         with open(os.path.join(ROOT, "profiles", name)) as f:
             busy = json.load(f)
         if conf["dtype"] == "bf16" and config_name == "fastmri":

@@ -70,8 +70,11 @@ def init_distributed(expected_world: int | None = None):
     if world == 1:
         return None, 0, 1, dev, None
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    # a rank that never shows up must fail the job within a minute, not hang it until the driver's clock runs out
-    timeout = datetime.timedelta(seconds=int(os.environ.get("IM2IM_RENDEZVOUS_TIMEOUT_S", "60")))
+    # a rank that never shows up must fail the job, not hang it until the driver's clock runs out.  The same timeout is the
+    # watchdog of every later collective on the nccl backend, and on a fresh box the ranks' first `import torch` alone can be
+    # a minute or two apart: 300 s, not 60 (a WRONG world -- too few devices or ranks -- is refused by verify_world within
+    # seconds of the rendezvous, which is the check that has to be fast)
+    timeout = datetime.timedelta(seconds=int(os.environ.get("IM2IM_RENDEZVOUS_TIMEOUT_S", "300")))
     if backend == "nccl":
         dist.init_process_group(backend="nccl", device_id=dev, timeout=timeout)
     else:
