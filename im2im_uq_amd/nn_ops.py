@@ -546,6 +546,7 @@ def join_side_streams():
     _side_busy.clear()
     _callback_queued.clear()
     _halves.clear()
+    _wgrad_calls[0] = 0
 
 
 def _queue_join(idx):
@@ -643,9 +644,15 @@ WGRAD_WGS_SIDE = int(_WGS_PIN) if _WGS_PIN else int(os.environ.get("IM2IM_WGRAD_
 _wgs_now = [256]
 
 
+WGRAD_TAIL_FULL_FROM = int(os.environ.get("IM2IM_WGRAD_TAIL_FULL_FROM", "0"))   # A/B: 3x3 weight gradients number >= this of a backward pass (1-based) run at the alone-width
+_wgrad_calls = [0]
+
+
 def _set_wgrad_width(device):
     side = _side_streams.get(torch.device(device).index)
-    want = WGRAD_WGS_SIDE if (side is not None and torch.cuda.current_stream(device) == side) else WGRAD_WGS_ALONE
+    _wgrad_calls[0] += 1
+    tail = WGRAD_TAIL_FULL_FROM > 0 and _wgrad_calls[0] >= WGRAD_TAIL_FULL_FROM
+    want = WGRAD_WGS_SIDE if (side is not None and torch.cuda.current_stream(device) == side and not tail) else WGRAD_WGS_ALONE
     if want != _wgs_now[0]:
         check(lib.im2im_set_option(b"wgrad_wgs", want), "im2im_set_option")
         _wgs_now[0] = want
