@@ -148,11 +148,19 @@ def cpu_baseline(hw, legs=((4, 5), (8, 3)), n_cal_e2e=48):
     for k in st:
         if k.endswith("num_batches_tracked"):
             st[k] = torch.zeros((), dtype=torch.int64)
+    # [r5] the sample is BOUNDED in time, not only in size: the host of a GPU box is shared (a run next to three busy pods took 4 min
+    # here instead of 40 s), so every piece measures its first unit and shrinks to what ~10 s buy; `sample` says what was run
+    t_start = time.perf_counter()
     train = []
     for batch, steps in legs:
+        if train and (time.perf_counter() - t_start > 15.0 or train[0]["seconds"] / train[0]["steps"] * (batch / train[0]["batch"]) > 5.0):
+            break                                                           # slow host: the first leg already is the sample
         x = torch.randn(batch, 1, hw, hw)
         y = torch.rand(batch, 1, hw, hw)
+        t0 = time.perf_counter()
         om.train_steps(st, [(x, y)], PARAMS, lr=1e-4)                       # warm-up step
+        t_warm = time.perf_counter() - t0
+        steps = max(1, min(steps, int(8.0 / max(t_warm, 1e-3))))
         t0 = time.perf_counter()
         om.train_steps(st, [(x, y)] * steps, PARAMS, lr=1e-4)
         dt = time.perf_counter() - t0
@@ -163,17 +171,27 @@ def cpu_baseline(hw, legs=((4, 5), (8, 3)), n_cal_e2e=48):
     out, lab = oc.synth_outputs(n_cal, 1, hw, hw, seed=0)
     lambdas = torch.linspace(0, 6, n_lam)
     t0 = time.perf_counter()
+    done = 0
     for lam in lambdas:
         oc.losses_at(out, lab, lam)
+        done += 1
+        if done >= 10 and time.perf_counter() - t0 > 8.0:
+            break
+    n_lam = done
     dt_cal = time.perf_counter() - t0
     per_img_lambda = dt_cal / (n_cal * n_lam)
     # calibrate end to end as the reference does it: eval forward over the set, then the per-lambda loop from the top of
     # the grid down to where the scan stops (here ~550 of 1000 lambdas, the same stop point as the GPU leg's data)
     xe = torch.randn(n_cal_e2e, 1, hw, hw)
     t0 = time.perf_counter()
+    fwd_done = 0
     with torch.no_grad():
         for s in range(0, n_cal_e2e, 16):
             om.model_forward(xe[s:s + 16], st, training=False)
+            fwd_done += min(16, n_cal_e2e - s)
+            if time.perf_counter() - t0 > 8.0:
+                break
+    n_cal_e2e = fwd_done
     dt_fwd = time.perf_counter() - t0
     visited = 550
     e2e_per_img = dt_fwd / n_cal_e2e + visited * per_img_lambda
@@ -626,6 +644,16 @@ def fastmri_pipeline_record(job, batches=(16, 64), reps=5):
     return out
 
 
+_T0 = time.perf_counter()
+
+
+def _phase(name):
+    """wall-clock marks on stderr (the JSON line on stdout stays the only stdout output): where a run's time goes"""
+    if os.environ.get("RANK", "0") == "0":
+        sys.stderr.write(f"[bench {time.perf_counter() - _T0:7.1f} s] {name}\n")
+        sys.stderr.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -674,7 +702,9 @@ def main():
                    and args.uncertainty_type == "quantiles" and args.legs == "train,calib" and not args.no_extras)
 
     if default_run and world == 1 and not args.no_live_pmc:
+        _phase("live PMC passes start")
         LIVE_TRAFFIC.update(live_pmc_traffic())             # before this process allocates anything: the passes have the GPU to themselves
+        _phase("live PMC passes done")
 
     from im2im_uq_amd import nn_ops
     wl = Workload(job, conf, args.uncertainty_type, strong=args.scaling == "strong")
@@ -683,8 +713,10 @@ def main():
 
     # ---------------------------------------------------------------- train leg
     tr = {"imgs_per_s": float("nan"), "ms_per_step": float("nan"), "host_enqueue_ms_per_step": None}
+    _phase("workload built")
     if "train" in legs:
         tr = wl.train_leg(args.steps, args.warmup)
+        _phase("train leg done")
     else:
         args.no_roofline = True
     train_ips = tr["imgs_per_s"]
@@ -707,6 +739,7 @@ def main():
                 "frac_of_fp32_peak_whole_step": ips32 * wl.train_flop / 1e12 / PEAK_FP32_TFLOPS,
                 "note": "same step in the parity mode (v_mfma_f32_32x32x2_f32, fp32 storage): the reference's own precision"}
 
+    _phase("roofline + fp32 legs done")
     dist_info = distributed_record(job, wl, backend) if "train" in legs else {"world_size": world}
 
     if "calib" not in legs:
@@ -722,6 +755,7 @@ def main():
     # ---------------------------------------------------------------- calibration leg
     calib = calib_leg(wl, max(1, args.steps // 5), calib_images=args.calib_images)
     wl.release()
+    _phase("calibration leg done")
 
     # ---------------------------------------------------------------- companions in the same run
     strong = None
@@ -751,12 +785,14 @@ def main():
         except Exception as e:  # noqa: BLE001
             pipeline = {"error": f"{type(e).__name__}: {e}"}
 
+    _phase("other configs + pipeline done")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(320)
         if calib and cpu.get("calib_end_to_end"):
             calib["vs_cpu_end_to_end"] = calib["value"] / cpu["calib_end_to_end"]["value"]
 
+    _phase("cpu baseline done")
     if rank == 0:
         what = "quantile regression" if args.uncertainty_type == "quantiles" else args.uncertainty_type
         line = {
