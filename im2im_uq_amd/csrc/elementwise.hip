@@ -1613,10 +1613,11 @@ inline int ew_blocks(int64_t n) { int64_t b = cdiv(n, 256); if (b > 256 * 32) b 
 
 // BatchNorm-backward sums: partial[R][2][C] -> dgamma, dbeta, coef; one launch for few rows, two stages otherwise
 int g_pool_bwd_full = 1;                                     // im2im_set_option("pool_bwd_full", 0 / 1): branch-free bn_relu_pool_bwd for even extents
-int g_bn_fused_small = 1;                                    // im2im_set_option("bn_fused_small", 0 / 1): A/B switch
+int g_bn_fused_small = 1;                                    // im2im_set_option("bn_fused_small", 0 / 1 / n): off / up to BN_FUSED_MAX_ROWS partial rows / up to n rows
+inline int64_t bn_fused_rows() { return g_bn_fused_small <= 0 ? -1 : g_bn_fused_small == 1 ? BN_FUSED_MAX_ROWS : g_bn_fused_small; }
 inline int launch_bn_bwd_sums(const float* partial, int64_t R, int C, double count, double* tmp, float* dgamma, float* dbeta,
                               float* coef, hipStream_t stream) {
-  if (R <= BN_FUSED_MAX_ROWS && g_bn_fused_small) {
+  if (R <= bn_fused_rows()) {
     hipLaunchKernelGGL(bn_bwd_sums_fused_kernel, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, stream, partial, R, C, count, dgamma, dbeta, coef);
     return check_launch("bn_bwd_sums_fused_kernel");
   }
@@ -1641,7 +1642,7 @@ extern "C" int im2im_bn_finalize(const float* partial, int64_t R, int32_t C, int
   IM2IM_REQUIRE(partial && gamma && beta && mean_invstd && scale_shift && ws && R > 0 && C > 0 && count > 0);
   IM2IM_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
   IM2IM_REQUIRE(!centered || running_mean);
-  if (R <= BN_FUSED_MAX_ROWS && g_bn_fused_small) {
+  if (R <= bn_fused_rows()) {
     hipLaunchKernelGGL(bn_stats_fused_kernel, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, stream, partial, R, (int)C, gamma, beta,
                        running_mean, running_var, momentum, eps, (int)centered, mean_invstd, scale_shift, (long long*)num_batches_tracked);
     return check_launch("bn_stats_fused_kernel");

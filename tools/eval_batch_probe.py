@@ -19,7 +19,7 @@ model = add_uncertainty(UNet(1, 1), params).to(dev).eval()
 N = 624
 x = torch.randn(N, 1, 320, 320, device=dev)
 for rnd in range(2):
-    for bs in (4, 8, 13, 16, 24, 39, 52, 78, 104, 156):
+    for bs in (39, 78, 156, 312, 624):
         with torch.no_grad():
             for s in range(0, min(N, 4 * bs), bs):
                 model(x[s:s + bs])
