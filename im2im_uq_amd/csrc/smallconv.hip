@@ -37,8 +37,12 @@ struct S2LArgs {
 // channel group for all its pixels of the 16x16 tile: with one input channel the 9x8 weights stay in registers
 // (W_REGS), otherwise they are read from LDS; BatchNorm partial statistics are accumulated per thread and combined
 // over the lanes that share a channel group (xor-shuffles), then over the four waves.
-template <typename T, int CL, bool W_REGS>
-__global__ __launch_bounds__(256) void smallconv_s2l_kernel(S2LArgs a) {
+// LEAN [r5]: the training launch of the first conv as the bench runs it (one input plane, statistics, no folded affine / ReLU, the
+// image a whole number of tiles): the epilogue's eval-only code and the bounds tests are compiled out and the tile's eight passes
+// run as two rounds of four -- half the live accumulators, so three workgroups per CU instead of two hide each other's load and
+// store phases.  Same arithmetic in the same order: bit-identical output and statistics.
+template <typename T, int CL, bool W_REGS, bool LEAN = false>
+__global__ __launch_bounds__(256, LEAN ? 3 : 1) void smallconv_s2l_kernel(S2LArgs a) {
   constexpr int G = CL / 8;                 // channel groups (lanes per pixel)
   constexpr int PPP = 256 / G;              // pixels per pass
   constexpr int PASSES = TS * TS / PPP;
@@ -87,6 +91,44 @@ __global__ __launch_bounds__(256) void smallconv_s2l_kernel(S2LArgs a) {
   // (or held in registers) serves PASSES pixels; per output the summation order stays bias, then (s, tap) ascending
   const int q = tid / G;
   const int qy = q / TS, qx = q % TS;                    // pixel of pass p: (qy + p * PPP / TS, qx)
+  if constexpr (LEAN) {
+    static_assert(W_REGS && PASSES % 2 == 0, "one input plane, weights in registers");
+    constexpr int HP = PASSES / 2;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      float av[HP][8];
+#pragma unroll
+      for (int p = 0; p < HP; ++p)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) av[p][k] = b0[k];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int p = 0; p < HP; ++p) {
+          const float xv = s_in[0][qy + (r * HP + p) * (PPP / TS) + tap / 3][qx + tap % 3];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) av[p][k] = __builtin_fmaf(xv, wreg[tap][k], av[p][k]);
+        }
+#pragma unroll
+      for (int p = 0; p < HP; ++p) {
+        const int ty = qy + (r * HP + p) * (PPP / TS);
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = to_float(from_float<T>(av[p][k]));
+        T* o = outb + ((size_t)(y0 + ty) * a.W + x0 + qx) * CL;
+        constexpr int N = Vec16<T>::N;
+#pragma unroll
+        for (int k = 0; k < 8; k += N) Vec16<T>::store_nt(o + k, acc + k);
+        if (r == 0 && p == 0) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) K[k] = acc[k];
+        }
+        cnt += 1.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float d = acc[k] - K[k]; s1[k] += d; s2[k] += d * d; }
+      }
+    }
+  } else {
   float accv[PASSES][8];
 #pragma unroll
   for (int p = 0; p < PASSES; ++p)
@@ -151,6 +193,7 @@ __global__ __launch_bounds__(256) void smallconv_s2l_kernel(S2LArgs a) {
       for (int k = 0; k < 8; ++k) { const float d = acc[k] - K[k]; s1[k] += d; s2[k] += d * d; }
     }
   }
+  }   // !LEAN
   if (a.stats) {
     // thread -> (count, mean, M2); merged over the lanes that share the channel group, then over the four waves
     const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
@@ -965,7 +1008,8 @@ __global__ __launch_bounds__(256) void smallconv_wgrad_final_kernel(const double
   else dw[((size_t)s * CL + l) * 9 + (8 - tp)] = (float)v;
 }
 
-// IM2IM_SMALLCONV_VALU: bit mask that forces the VALU forms (A/B runs): 1 = heads forward, 2 = heads data-gradient, 4 = weight gradient
+// IM2IM_SMALLCONV_VALU: bit mask that forces the VALU forms (A/B runs): 1 = heads forward, 2 = heads data-gradient, 4 = weight gradient;
+// 16 = the generic form of smallconv_s2l_kernel also for the training launch of the first conv (LEAN off)
 inline int valu_mask() {
   static const int m = [] { const char* e = getenv("IM2IM_SMALLCONV_VALU"); return e ? atoi(e) : 0; }();
   return m;
@@ -1010,7 +1054,9 @@ extern "C" int im2im_smallconv_s2l_fwd(const float* in, const float* w, const fl
     }
     // (an exact-fp32 MFMA form of this layer was measured slower than the VALU kernel: K = 9*CS is too short to pay for the
     // LDS round trip of the accumulators -- 0.60 vs 0.50 ms at batch 78, 320x320, CS = 1)
-    if (CS == 1) hipLaunchKernelGGL((smallconv_s2l_kernel<T, decltype(cl)::value, true>), grid, dim3(256), 0, stream, a);
+    if (CS == 1 && a.stats && !a.scale_shift && !a.relu && H % TS == 0 && W % TS == 0 && !(valu_mask() & 16))
+      hipLaunchKernelGGL((smallconv_s2l_kernel<T, decltype(cl)::value, true, true>), grid, dim3(256), 0, stream, a);
+    else if (CS == 1) hipLaunchKernelGGL((smallconv_s2l_kernel<T, decltype(cl)::value, true>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((smallconv_s2l_kernel<T, decltype(cl)::value, false>), grid, dim3(256), 0, stream, a);
     return check_launch("smallconv_s2l_kernel");
   });

@@ -492,3 +492,39 @@ def test_g19_adam_trajectory_on_default_init_fp32():
         # typical element must agree to rounding noise (+ the bias drift the reference's running means carry, see above)
         assert m <= 2 * 10 * lr + 1e-5 * scale + slack, (k, m)
         assert md <= 2e-6 + 1e-5 * scale + slack, (k, md)
+
+
+# ------------------------------------------------------------------------------------------------ the LEAN first conv (csrc/smallconv.hip)
+_S2L_SNIPPET = r"""
+import sys, torch
+sys.path.insert(0, {root!r})
+from im2im_uq_amd import nn_ops
+g = torch.Generator().manual_seed(5)
+x = torch.randn(3, 1, 64, 96, generator=g).cuda()
+w = (torch.randn(1, 9, 64, generator=g) * 0.3).cuda()
+b = (torch.randn(64, generator=g) * 0.1).cuda()
+y, st = nn_ops.smallconv_s2l(x, w, b, None, 64, torch.bfloat16, want_stats=True)
+torch.cuda.synchronize()
+torch.save({{"y": y.cpu(), "st": st.cpu()}}, {out!r})
+"""
+
+
+def test_lean_first_conv_is_bit_identical_to_the_generic_kernel(tmp_path):
+    """[r5] smallconv_s2l_kernel<..., LEAN> (the training launch of the 1 -> 64 first conv, unet_parts.py:16 with in_channels = 1: eval-only
+    epilogue code and bounds tests compiled out, the tile's passes in two rounds so three workgroups fit a CU; 0.45 -> 0.33 ms at batch
+    78) against the generic form of the same kernel (IM2IM_SMALLCONV_VALU=16, read once per process -- hence two child processes):
+    same output bits, same statistics rows."""
+    import subprocess
+    import sys as _sys
+    from conftest import ROOT
+    import os as _os
+    outs = {}
+    for name, mask in (("lean", "0"), ("generic", "16")):
+        path = str(tmp_path / f"{name}.pt")
+        env = dict(_os.environ, IM2IM_SMALLCONV_VALU=mask)
+        r = subprocess.run([_sys.executable, "-c", _S2L_SNIPPET.format(root=ROOT, out=path)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs[name] = torch.load(path)
+    assert torch.equal(outs["lean"]["y"], outs["generic"]["y"])
+    assert torch.equal(outs["lean"]["st"], outs["generic"]["st"])
+    assert bool(torch.isfinite(outs["lean"]["y"].float()).all()) and float(outs["lean"]["y"].float().abs().max()) > 0
