@@ -41,7 +41,8 @@ struct S2LArgs {
 // image a whole number of tiles): the epilogue's eval-only code and the bounds tests are compiled out and the tile's eight passes
 // run as two rounds of four -- half the live accumulators, so three workgroups per CU instead of two hide each other's load and
 // store phases.  Same arithmetic in the same order: bit-identical output and statistics.
-template <typename T, int CL, bool W_REGS, bool LEAN = false>
+// LEAN = 2: the same for the INFERENCE launch (folded BatchNorm affine + ReLU, no statistics).
+template <typename T, int CL, bool W_REGS, int LEAN = 0>
 __global__ __launch_bounds__(256, LEAN ? 3 : 1) void smallconv_s2l_kernel(S2LArgs a) {
   constexpr int G = CL / 8;                 // channel groups (lanes per pixel)
   constexpr int PPP = 256 / G;              // pixels per pass
@@ -113,19 +114,28 @@ __global__ __launch_bounds__(256, LEAN ? 3 : 1) void smallconv_s2l_kernel(S2LArg
       for (int p = 0; p < HP; ++p) {
         const int ty = qy + (r * HP + p) * (PPP / TS);
         float acc[8];
+        if constexpr (LEAN == 2) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = to_float(from_float<T>(av[p][k]));
+          for (int k = 0; k < 8; ++k) acc[k] = fmaxf(av[p][k] * sc[k] + sh[k], 0.f);      // the generic epilogue's expression, a.relu set
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc[k] = av[p][k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = to_float(from_float<T>(acc[k]));
         T* o = outb + ((size_t)(y0 + ty) * a.W + x0 + qx) * CL;
         constexpr int N = Vec16<T>::N;
 #pragma unroll
         for (int k = 0; k < 8; k += N) Vec16<T>::store_nt(o + k, acc + k);
-        if (r == 0 && p == 0) {
+        if constexpr (LEAN == 1) {
+          if (r == 0 && p == 0) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) K[k] = acc[k];
+            for (int k = 0; k < 8; ++k) K[k] = acc[k];
+          }
+          cnt += 1.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { const float d = acc[k] - K[k]; s1[k] += d; s2[k] += d * d; }
         }
-        cnt += 1.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { const float d = acc[k] - K[k]; s1[k] += d; s2[k] += d * d; }
       }
     }
   } else {
@@ -1055,7 +1065,9 @@ extern "C" int im2im_smallconv_s2l_fwd(const float* in, const float* w, const fl
     // (an exact-fp32 MFMA form of this layer was measured slower than the VALU kernel: K = 9*CS is too short to pay for the
     // LDS round trip of the accumulators -- 0.60 vs 0.50 ms at batch 78, 320x320, CS = 1)
     if (CS == 1 && a.stats && !a.scale_shift && !a.relu && H % TS == 0 && W % TS == 0 && !(valu_mask() & 16))
-      hipLaunchKernelGGL((smallconv_s2l_kernel<T, decltype(cl)::value, true, true>), grid, dim3(256), 0, stream, a);
+      hipLaunchKernelGGL((smallconv_s2l_kernel<T, decltype(cl)::value, true, 1>), grid, dim3(256), 0, stream, a);
+    else if (CS == 1 && !a.stats && a.scale_shift && a.relu && H % TS == 0 && W % TS == 0 && !(valu_mask() & 16))
+      hipLaunchKernelGGL((smallconv_s2l_kernel<T, decltype(cl)::value, true, 2>), grid, dim3(256), 0, stream, a);
     else if (CS == 1) hipLaunchKernelGGL((smallconv_s2l_kernel<T, decltype(cl)::value, true>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((smallconv_s2l_kernel<T, decltype(cl)::value, false>), grid, dim3(256), 0, stream, a);
     return check_launch("smallconv_s2l_kernel");

@@ -504,8 +504,10 @@ x = torch.randn(3, 1, 64, 96, generator=g).cuda()
 w = (torch.randn(1, 9, 64, generator=g) * 0.3).cuda()
 b = (torch.randn(64, generator=g) * 0.1).cuda()
 y, st = nn_ops.smallconv_s2l(x, w, b, None, 64, torch.bfloat16, want_stats=True)
+fold = torch.stack([torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)]).cuda()
+y2 = nn_ops.smallconv_s2l(x, w, None, fold, 64, torch.bfloat16, relu=True, flip=True)      # the inference launch (conv_bn_relu_eval)
 torch.cuda.synchronize()
-torch.save({{"y": y.cpu(), "st": st.cpu()}}, {out!r})
+torch.save({{"y": y.cpu(), "st": st.cpu(), "y2": y2.cpu()}}, {out!r})
 """
 
 
@@ -527,4 +529,5 @@ def test_lean_first_conv_is_bit_identical_to_the_generic_kernel(tmp_path):
         outs[name] = torch.load(path)
     assert torch.equal(outs["lean"]["y"], outs["generic"]["y"])
     assert torch.equal(outs["lean"]["st"], outs["generic"]["st"])
+    assert torch.equal(outs["lean"]["y2"], outs["generic"]["y2"]) and float(outs["lean"]["y2"].float().max()) > 0     # LEAN = 2, inference
     assert bool(torch.isfinite(outs["lean"]["y"].float()).all()) and float(outs["lean"]["y"].float().abs().max()) > 0
