@@ -931,7 +931,10 @@ __global__ __launch_bounds__(256) void smallconv_wgrad_mfma_kernel(SWArgs a) {
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) gload(tile + gridDim.x);
     // k-step = one tile row of 16 pixels
-#pragma unroll 1
+#ifndef IM2IM_SWG_UNROLL
+#define IM2IM_SWG_UNROLL 1
+#endif
+#pragma unroll IM2IM_SWG_UNROLL
     for (int ty = 0; ty < TS; ++ty) {
       if constexpr (IS_BF16) {
         short8 fa[MT];
