@@ -62,3 +62,12 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError, match="no CPU/PyTorch fallback"):
         _lib._load()
+
+
+def test_every_source_file_is_built():
+    """[r5] im2im_uq_amd/build.py lists its sources by name: a new csrc/*.hip that is not in the list would compile nowhere and its
+    symbols would be missing at link time only on a fresh checkout."""
+    import os
+    from im2im_uq_amd import build
+    on_disk = sorted(f for f in os.listdir(build.CSRC) if f.endswith((".hip", ".cpp")) and not f.startswith("_"))
+    assert on_disk == sorted(build.SOURCES)
