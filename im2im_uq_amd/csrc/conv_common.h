@@ -112,6 +112,7 @@ inline TileChoice pick_tile(int B, int H, int W, int Co, bool per_image = false)
 void set_conv_splitk(int v);
 void set_bn_fused_small(int v);          // elementwise.hip: one-launch BatchNorm sums for few partial rows
 void set_pool_bwd_blocks(int v);
+void set_bn_apply_keep_mb(int v);
 void set_pool_bwd_full(int v);           // elementwise.hip: branch-free bn_relu_pool_bwd for even extents (A/B)
 // conv_roll.hip [r5]: the persistent, software-pipelined kernel of the 64-output-channel full-resolution layers
 void set_conv_roll(int v);               // A/B switch (im2im_set_option "conv_roll")

@@ -1669,6 +1669,7 @@ extern "C" int im2im_set_option(const char* key, int32_t value) {
   if (std::string(key) == "bn_fused_small") { im2im::set_bn_fused_small(value); return IM2IM_OK; }
   if (std::string(key) == "pool_bwd_full") { im2im::set_pool_bwd_full(value); return IM2IM_OK; }
   if (std::string(key) == "pool_bwd_blocks") { im2im::set_pool_bwd_blocks(value); return IM2IM_OK; }
+  if (std::string(key) == "bn_apply_keep_mb") { im2im::set_bn_apply_keep_mb(value); return IM2IM_OK; }
   if (std::string(key) == "conv_roll") { im2im::set_conv_roll(value); return IM2IM_OK; }
   return im2im::fail_invalid("unknown option");
 }

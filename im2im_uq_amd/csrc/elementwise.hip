@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restr
                                                                  const float* __restrict__ scale_shift,
                                                                  const float* __restrict__ mean_invstd,
                                                                  const float* __restrict__ coef, T* __restrict__ dz,
-                                                                 int64_t nvec, int C) {
+                                                                 int64_t nvec, int C, int keep) {
   constexpr int N = Vec16<T>::N;
   const int vpr = C / N;
   const bool fixed = (256 % vpr) == 0;
@@ -348,7 +348,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(const T* __restr
       const float xhat = (zz[k] - mu[k]) * is[k];
       o[k] = sc[k] * (gg - k1[k] - xhat * k2[k]);
     }
-    Vec16<T>::store_nt(dz + i * N, o);
+    // keep [r5, A/B]: a dz small enough for the Infinity Cache is written with ordinary stores so that its two consumers (the
+    // data-gradient and the weight gradient of the same layer, next in line) may find it there; large ones are streamed
+    if (keep) Vec16<T>::store(dz + i * N, o); else Vec16<T>::store_nt(dz + i * N, o);
   };
   const int64_t stride = (int64_t)gridDim.x * 256;
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1612,6 +1614,7 @@ inline dim3 row_grid(int rowvecs, int64_t rows) {
 inline int ew_blocks(int64_t n) { int64_t b = cdiv(n, 256); if (b > 256 * 32) b = 256 * 32; if (b < 1) b = 1; return (int)b; }
 
 // BatchNorm-backward sums: partial[R][2][C] -> dgamma, dbeta, coef; one launch for few rows, two stages otherwise
+int64_t g_bn_apply_keep_bytes = 0;                           // im2im_set_option("bn_apply_keep_mb", n): dz tensors up to n MB are written with ordinary (cacheable) stores
 int g_pool_bwd_full = 1;                                     // im2im_set_option("pool_bwd_full", 0 / 1): branch-free bn_relu_pool_bwd for even extents
 int g_bn_fused_small = 1;                                    // im2im_set_option("bn_fused_small", 0 / 1 / n): off / up to BN_FUSED_MAX_ROWS partial rows / up to n rows
 inline int64_t bn_fused_rows() { return g_bn_fused_small <= 0 ? -1 : g_bn_fused_small == 1 ? BN_FUSED_MAX_ROWS : g_bn_fused_small; }
@@ -1629,7 +1632,7 @@ inline int launch_bn_bwd_sums(const float* partial, int64_t R, int C, double cou
 }
 
 }  // namespace
-namespace im2im { void set_bn_fused_small(int v) { g_bn_fused_small = v; } void set_pool_bwd_full(int v) { g_pool_bwd_full = v; } }
+namespace im2im { void set_bn_fused_small(int v) { g_bn_fused_small = v; } void set_pool_bwd_full(int v) { g_pool_bwd_full = v; } void set_bn_apply_keep_mb(int v) { g_bn_apply_keep_bytes = (int64_t)v << 20; } }
 
 // ================================================================================================
 extern "C" int64_t im2im_reduce_workspace_bytes(int64_t K) { return im2im::reduce_tmp_bytes(K); }
@@ -1703,7 +1706,7 @@ extern "C" int im2im_bn_relu_bwd(const void* da, const void* z, const float* sca
     if (int rc = launch_bn_bwd_sums(partial, cdiv(M, rpb), (int)C, (double)M, tmp, dgamma, dbeta, coef, stream)) return rc;
     const int64_t nvec = M * C / Vec16<T>::N;
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, stream, (const T*)da, (const T*)z,
-                       scale_shift, mean_invstd, coef, (T*)dz, nvec, (int)C);
+                       scale_shift, mean_invstd, coef, (T*)dz, nvec, (int)C, (int)(nvec * 16 <= g_bn_apply_keep_bytes));
     return check_launch("bn_relu_bwd_apply_kernel");
   });
 }
@@ -1749,7 +1752,7 @@ extern "C" int im2im_bn_relu_bwd_phase(const void* da, const void* z, const floa
     }
     const int64_t nvec = (row1 - row0) * C / Vec16<T>::N;
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, stream, (const T*)da + row0 * C,
-                       (const T*)z + row0 * C, scale_shift, mean_invstd, coef, (T*)dz + row0 * C, nvec, (int)C);
+                       (const T*)z + row0 * C, scale_shift, mean_invstd, coef, (T*)dz + row0 * C, nvec, (int)C, 0);
     return check_launch("bn_relu_bwd_apply_kernel");
   });
 }
@@ -1822,7 +1825,7 @@ extern "C" int im2im_bn_relu_bwd_from_partial(const void* da, const void* z, con
     if (int rc = launch_bn_bwd_sums(partial, R, (int)C, (double)M, tmp, dgamma, dbeta, coef, stream)) return rc;
     const int64_t nvec = M * C / Vec16<T>::N;
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, stream, (const T*)da, (const T*)z,
-                       scale_shift, mean_invstd, coef, (T*)dz, nvec, (int)C);
+                       scale_shift, mean_invstd, coef, (T*)dz, nvec, (int)C, (int)(nvec * 16 <= g_bn_apply_keep_bytes));
     return check_launch("bn_relu_bwd_apply_kernel");
   });
 }

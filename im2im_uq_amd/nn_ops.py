@@ -423,6 +423,8 @@ def conv_fwd_fp8(x, wq, wscale, bias=None, scale_shift=None, relu=False, want_st
 
 if os.environ.get("IM2IM_BN_FUSED_SMALL") is not None:   # A/B: one-launch BatchNorm sums for <= 256 partial rows (default on)
     check(lib.im2im_set_option(b"bn_fused_small", int(os.environ["IM2IM_BN_FUSED_SMALL"])), "im2im_set_option")
+if os.environ.get("IM2IM_BN_APPLY_KEEP_MB") is not None:   # A/B: dz tensors up to n MB written with cacheable stores (default 0: all streamed)
+    check(lib.im2im_set_option(b"bn_apply_keep_mb", int(os.environ["IM2IM_BN_APPLY_KEEP_MB"])), "im2im_set_option")
 if os.environ.get("IM2IM_POOL_BWD_BLOCKS") is not None:   # A/B: workgroups of bn_relu_pool_bwd (default 6144; 2048 until round 5)
     check(lib.im2im_set_option(b"pool_bwd_blocks", int(os.environ["IM2IM_POOL_BWD_BLOCKS"])), "im2im_set_option")
 if os.environ.get("IM2IM_POOL_BWD_FULL") is not None:     # A/B: 0 = the branching form of bn_relu_pool_bwd also for even extents
