@@ -328,6 +328,59 @@ class Workload:
         torch.cuda.empty_cache()
 
 
+def host_train_record(job, conf, device_resident_ips, n_batches=14, skip=3):
+    """train_net itself (core/scripts/train.py, the reference's loop :141-165) fed from a HOST TensorDataset in pageable memory, as a
+    reference user calls it: steady-state imgs/s between HIP events recorded at its optimizer steps, with the pinned prefetcher
+    (default) and with the reference's in-line `.to(device)` uploads (IM2IM_PREFETCH=0)."""
+    from torch.utils.data import TensorDataset
+    from im2im_uq_amd import nn_ops, prefetch
+    from im2im_uq_amd.core.models.add_uncertainty import add_uncertainty
+    from im2im_uq_amd.core.models.trunks.unet import UNet
+    from im2im_uq_amd.core.scripts.train import train_net
+    dev, B, hw, n_in = job.dev, conf["batch"], conf["size"], conf["n_in"]
+    nn_ops.set_compute_dtype(conf["dtype"])
+    cfg = dict(PARAMS, device=str(dev), batch_size=B, num_lambdas=conf["num_lambdas"], minimum_lambda=conf["lam"][0],
+               maximum_lambda=conf["lam"][1], num_validation_images=1)
+    g = torch.Generator().manual_seed(4321)
+    n = B * n_batches
+    xs = torch.randn(n, n_in, hw, hw, generator=g)            # pageable host memory
+    ys = torch.rand(n, 1, hw, hw, generator=g)
+    ds, val = TensorDataset(xs, ys), TensorDataset(xs[:2].clone(), ys[:2].clone())
+    rec = {"images_per_epoch": n, "batch": B, "memory": "pageable host TensorDataset, DataLoader(shuffle=True, num_workers=0) as train_net builds it",
+           "timed": f"HIP events at the optimizer steps {skip}..{n_batches - 1} of one train_net epoch"}
+    orig = nn_ops.FusedAdam.step
+    was = prefetch.ENABLED
+    try:
+        for key, pf in (("inline_upload", False), ("prefetched", True)):
+            prefetch.ENABLED = pf
+            events = []
+
+            def step(self, closure=None, _events=events):
+                out = orig(self, closure)
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                _events.append(e)
+                return out
+            nn_ops.FusedAdam.step = step
+            torch.manual_seed(0)
+            model = add_uncertainty(UNet(n_in, 1, depth=conf["depth"]), cfg)
+            with contextlib.redirect_stdout(io.StringIO()):
+                model = train_net(model, ds, val, dev, 1, B, cfg["lr"], False, None, 10 ** 9, 10 ** 9, config=cfg)
+            torch.cuda.synchronize()
+            nn_ops.FusedAdam.step = orig
+            ms = events[skip].elapsed_time(events[-1])
+            rec[key + "_imgs_per_s"] = B * (len(events) - 1 - skip) / ms * 1e3
+            rec[key + "_ms_per_step"] = ms / (len(events) - 1 - skip)
+            del model
+    finally:
+        nn_ops.FusedAdam.step = orig
+        prefetch.ENABLED = was
+    rec["train_imgs_per_s"] = rec["prefetched_imgs_per_s"]
+    rec["frac_of_device_resident"] = rec["prefetched_imgs_per_s"] / device_resident_ips
+    torch.cuda.empty_cache()
+    return rec
+
+
 def distributed_record(job, wl, backend, steps=10):
     """what lets a reader of the line check that N ranks on N devices really exchanged gradients: every rank's
     device (index, name, uuid / PCI bus id, gathered over the job's own process group), the RCCL version, ONE standalone
@@ -345,7 +398,7 @@ def distributed_record(job, wl, backend, steps=10):
            "allreduce_bytes_per_step": wl.allreduce_bytes, "gpus_visible": torch.cuda.device_count(),
            "under_torch_distributed_run": os.environ.get("TORCHELASTIC_RUN_ID") is not None, "ranks": ranks,
            "distinct_devices": launch.distinct_devices(ranks)}
-    if world > 1 and backend == "nccl" and rec["distinct_devices"] != world:      # launch.verify_world already refused this at start-up
+    if world > 1 and backend == "nccl" and rec["distinct_devices"] != world and launch.identifiable(ranks):      # launch.verify_world already refused this at start-up
         raise SystemExit(f"{world} RCCL ranks on {rec['distinct_devices']} distinct devices")
     try:
         rec["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -446,21 +499,25 @@ def roofline_leg(wl, config_name, full=True):
     try:
         # counter-based utilisation from the committed PMC passes (busy MFMA cycles / elapsed SIMD cycles at the clock the chip
         # actually ran): a second reading beside `frac`, which divides FLOP/s by the nominal-clock peak
-        name = next(n for n in ("r05_pmc_mfma_busy.json", "r04_pmc_mfma_busy.json", "r02_pmc_mfma_busy.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        name = next(n for n in ("r06_pmc_mfma_busy.json", "r05_pmc_mfma_busy.json", "r04_pmc_mfma_busy.json", "r02_pmc_mfma_busy.json")
+                    if os.path.exists(os.path.join(ROOT, "profiles", n)))
         with open(os.path.join(ROOT, "profiles", name)) as f:
             busy = json.load(f)
         if conf["dtype"] == "bf16" and config_name == "fastmri":
             roof["mfma_busy_cycle_frac_pmc"] = {k: round(v["mfma_busy_frac"], 3) for k, v in busy.items()
                                                 if isinstance(v, dict) and k.startswith(("conv_igemm", "conv_ws"))}
-            roof["mfma_busy_cycle_frac_pmc"]["source"] = (f"profiles/{name} (replayed: SQ counter passes over tools/bench_conv.py of "
-                                                          + ("this round's kernels)" if name.startswith("r04") else "ROUND-2 kernels -- stale)"))
+            roof["mfma_busy_cycle_frac_pmc"]["source"] = (f"profiles/{name} (replayed, not measured in this run: SQ counter passes over "
+                                                          f"tools/bench_conv.py with the round-{int(name[1:3])} kernels)")
     except Exception:  # noqa: BLE001
         pass
     return roof, roof_w, per_kernel, roof_dgrad
 
 
-def calib_leg(wl, steps, calib_images=None, scoring=True):
-    """calibrate_model end to end on this rank's share of the config's calibration split, then the scoring kernel alone."""
+def calib_leg(wl, steps, calib_images=None, scoring=True, host_images=0):
+    """calibrate_model end to end on this rank's share of the config's calibration split, then the scoring kernel alone.
+    host_images > 0: also calibrate_model on a HOST TensorDataset (pageable memory, what a reference user hands over,
+    calibrate_model.py:118-123) of the first `host_images` images, with and without the pinned prefetcher, beside the same images
+    resident in HBM -> calib["host_dataset"]."""
     from im2im_uq_amd import hip_ops
     from im2im_uq_amd._lib import lib as _abi
     from im2im_uq_amd.core.calibration.calibrate_model import calibrate_model
@@ -522,6 +579,38 @@ def calib_leg(wl, steps, calib_images=None, scoring=True):
                                   "gflop_per_image_forward": wl.fwd_flop / 1e9,
                                   "note": "eval forward of this rank's calibration shard alone, same batches as calibrate_model; in fp8 mode only the "
                                           "eligible 3x3 convs run on the fp8 MFMA, the peak is the fp8 one"}}
+    if host_images:
+        from im2im_uq_amd import prefetch
+        mh = min(int(host_images), M)
+        xh, yh = xc[:mh].cpu(), yc[:mh].cpu()                  # pageable host tensors
+        ds_dev = TensorDataset(xc[:mh], yc[:mh])
+        ds_dev.im2im_local_shard = True
+        ds_host = TensorDataset(xh, yh)
+        ds_host.im2im_local_shard = True
+
+        def run(dataset):
+            with contextlib.redirect_stdout(io.StringIO()):
+                calibrate_model(model, dataset, ccfg)
+            return float(model.lhat)
+        rec = {"images": mh, "batch": ccfg["batch_size"], "memory": "pageable host TensorDataset, DataLoader(num_workers=0) order"}
+        lh = {}
+        was = prefetch.ENABLED
+        try:
+            for key, dataset, pf in (("device_resident", ds_dev, True), ("host_inline_upload", ds_host, False), ("host_prefetched", ds_host, True)):
+                prefetch.ENABLED = pf
+                run(dataset)                                    # warm-up (pinned staging ring, allocator)
+                job.barrier()
+                t0 = time.perf_counter()
+                lh[key] = run(dataset)
+                torch.cuda.synchronize()
+                rec[key + "_imgs_per_s"] = mh / (time.perf_counter() - t0)
+        finally:
+            prefetch.ENABLED = was
+        rec["calib_imgs_per_s"] = rec["host_prefetched_imgs_per_s"]
+        rec["frac_of_device_resident"] = rec["host_prefetched_imgs_per_s"] / rec["device_resident_imgs_per_s"]
+        rec["lhat_identical"] = len(set(lh.values())) == 1
+        calib["host_dataset"] = rec
+        del xh, yh, ds_dev, ds_host
     del xc, yc, ds
     torch.cuda.empty_cache()
     if not scoring:
@@ -753,9 +842,24 @@ def main():
         return
 
     # ---------------------------------------------------------------- calibration leg
-    calib = calib_leg(wl, max(1, args.steps // 5), calib_images=args.calib_images)
+    want_host = default_run and world == 1
+    calib = calib_leg(wl, max(1, args.steps // 5), calib_images=args.calib_images, host_images=16 * conf["batch"] if want_host else 0)
     wl.release()
     _phase("calibration leg done")
+    host_ds = None
+    if want_host:
+        # [r6] what a user of train_net / calibrate_model gets from a HOST dataset (the reference's data contract), beside the HBM-resident legs
+        try:
+            ht = host_train_record(job, conf, train_ips)
+            hc = calib.get("host_dataset", {})
+            host_ds = {"train_imgs_per_s": ht["train_imgs_per_s"], "calib_imgs_per_s": hc.get("calib_imgs_per_s"),
+                       "frac_of_device_resident": {"train": ht["frac_of_device_resident"], "calib": hc.get("frac_of_device_resident")},
+                       "train_inline_upload_imgs_per_s": ht["inline_upload_imgs_per_s"],
+                       "calib_inline_upload_imgs_per_s": hc.get("host_inline_upload_imgs_per_s"), "train": ht, "calib": hc}
+        except Exception as e:  # noqa: BLE001  -- a companion record must never cost the headline line
+            host_ds = {"error": f"{type(e).__name__}: {e}"}
+        nn_ops.set_compute_dtype(conf["dtype"])
+        _phase("host-dataset legs done")
 
     # ---------------------------------------------------------------- companions in the same run
     strong = None
@@ -826,6 +930,33 @@ def main():
             line["fastmri_pipeline"] = pipeline
         if cpu:
             line["vs_cpu_train"] = train_ips / cpu["value"]
+        if host_ds:
+            line["host_dataset"] = host_ds
+        # [r6] the scalars two north-star targets hang on, at the TOP level and at the END of the line (a parser that keeps only scalars,
+        # or only the tail of the line, still carries them)
+        def _get(d, *path):
+            for k in path:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d
+        fp8, b16 = _get(others, "bsbcm512_fp8", "value"), _get(others, "bsbcm512_bf16", "value")
+        line["batch10_ms_per_step"] = _get(others, "batch10", "ms_per_step")
+        line["batch10_imgs_per_s"] = _get(others, "batch10", "value")
+        line["temca1024_imgs_per_s"] = _get(others, "temca1024", "value")
+        line["bsbcm512_fp8_over_bf16"] = (fp8 / b16) if fp8 and b16 else None
+        line["denoise32_imgs_per_s"] = _get(others, "denoise32", "value")
+        line["calib_imgs_per_s"] = _get(calib, "value")
+        line["calib_forward_frac"] = _get(calib, "forward_roofline", "frac")
+        line["calib_scoring_hbm_frac"] = _get(calib, "scoring_only", "roofline", "frac")
+        line["conv_roofline_frac"] = _get(roof, "frac")
+        line["conv_roofline_frac_in_timed_step"] = _get(roof, "frac_in_timed_step")
+        line["wgrad_roofline_frac"] = _get(roof_w, "frac")
+        line["host_train_imgs_per_s"] = _get(host_ds, "train_imgs_per_s")
+        line["host_calib_imgs_per_s"] = _get(host_ds, "calib_imgs_per_s")
+        line["host_train_frac_of_device_resident"] = _get(host_ds, "frac_of_device_resident", "train")
+        line["host_calib_frac_of_device_resident"] = _get(host_ds, "frac_of_device_resident", "calib")
+        line["cpu_baseline_imgs_per_s"] = _get(cpu, "value")
+        line["value_repeat"] = train_ips
+        line["ms_per_step_repeat"] = tr["ms_per_step"]
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -25,7 +25,6 @@ SOURCES = {
     "common.cpp": [],
     "hb_bound.cpp": ["-ffp-contract=off"],
     "rcps.hip": ["-ffp-contract=off"],
-    "conv_roll.hip": ["-ffp-contract=off"],   # [r5] same rounding rule for its lazy BatchNorm+ReLU staging
     "conv_mfma.hip": ["-ffp-contract=off"],   # lazy BatchNorm+ReLU in the operand staging must round exactly like bn_relu_apply
     # (the same lazy transform on the weight gradient's x operand); max-ILP machine scheduling: +1.2 % on the 13 BASELINE weight
     # gradients (949-951 -> 957-964 TF, profiles/r04_ab_experiments.txt section 9) -- and -15 % on conv_mfma.hip, which keeps the default
@@ -35,6 +34,25 @@ SOURCES = {
     "fastmri.hip": ["-ffp-contract=off"],
     "conv_fp8.hip": ["-ffp-contract=off"],
 }
+
+
+# [r6] measured-and-shelved kernels stay out of the default library: IM2IM_BUILD_EXPERIMENTAL=1 compiles them in (and defines the
+# macro of the same name for the dispatchers that route to them); their objects carry an ".exp" tag so the two builds never mix.
+#   conv_roll.hip: conv_roll64_kernel [r5], the persistent kernel of the 64-output-channel full-resolution layers -- correct, tested,
+#   same time as conv_igemm_kernel on this power-limited part (profiles/r05_ab_experiments.txt section 1), option "conv_roll"
+EXPERIMENTAL = os.environ.get("IM2IM_BUILD_EXPERIMENTAL", "0") == "1"
+EXPERIMENTAL_SOURCES = {
+    "conv_roll.hip": ["-ffp-contract=off"],   # same rounding rule for its lazy BatchNorm+ReLU staging
+}
+EXPERIMENTAL_USERS = ("conv_mfma.hip", "conv_wgrad.hip")     # translation units that test the macro
+
+
+def active_sources() -> dict:
+    if not EXPERIMENTAL:
+        return dict(SOURCES)
+    out = {k: (v + ["-DIM2IM_BUILD_EXPERIMENTAL=1"] if k in EXPERIMENTAL_USERS else v) for k, v in SOURCES.items()}
+    out.update({k: v + ["-DIM2IM_BUILD_EXPERIMENTAL=1"] for k, v in EXPERIMENTAL_SOURCES.items()})
+    return out
 
 
 def _hipcc() -> str:
@@ -54,7 +72,8 @@ def _deps_mtime() -> float:
 
 def _compile(src: str, flags, force: bool, hdr_t: float) -> str:
     path = os.path.join(CSRC, src)
-    obj = os.path.join(OBJ, src + ".o")
+    tag = ".exp" if EXPERIMENTAL and (src in EXPERIMENTAL_USERS or src in EXPERIMENTAL_SOURCES) else ""
+    obj = os.path.join(OBJ, src + tag + ".o")
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), hdr_t):
         return obj
     cmd = [_hipcc(), f"--offload-arch={ARCH}", *COMMON, *flags, "-c", path, "-o", obj]
@@ -72,15 +91,22 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     hdr_t = _deps_mtime()
-    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
-        objs = list(ex.map(lambda kv: _compile(kv[0], kv[1], force, hdr_t), SOURCES.items()))
-    if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+    sources = active_sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(sources))) as ex:
+        objs = list(ex.map(lambda kv: _compile(kv[0], kv[1], force, hdr_t), sources.items()))
+    # the library remembers which object set it was linked from (a default build after an experimental one must relink)
+    stamp = LIB + ".objs"
+    want = "\n".join(sorted(os.path.basename(o) for o in objs))
+    have = open(stamp).read() if os.path.exists(stamp) else None
+    if force or not os.path.exists(LIB) or have != want or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        with open(stamp, "w") as f:
+            f.write(want)
         if verbose:
-            print(f"[im2im_uq_amd.build] linked {LIB}")
+            print(f"[im2im_uq_amd.build] linked {LIB}" + (" (with the experimental kernels)" if EXPERIMENTAL else ""))
     elif verbose:
         print(f"[im2im_uq_amd.build] up to date: {LIB}")
     return LIB

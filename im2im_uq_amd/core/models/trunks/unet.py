@@ -47,9 +47,15 @@ class UNet(nn.Module):
         if not self.training and not torch.is_grad_enabled():
             # inference: the last block hands OutConv's 1x1 to its own conv epilogue when it can (nn_ops.conv_bn_relu_eval tail=)
             # -- unless OutConv carries its own compute dtype or anyone listens on it (forward hooks: feature extraction)
+            # [r6] ... nor on the last Up block or anything inside it (fused, its conv writes OutConv's result, not its own 64-channel
+            # activation), nor through a global module forward hook
             out, conv = self.out, self.out.conv
-            hooked = any(getattr(m, a, None) for m in (out, conv) for a in ("_forward_hooks", "_forward_pre_hooks"))
-            fuse = not hooked and _cdt(out) == _cdt(getattr(self, f"up{getattr(self, 'depth', 4)}").conv)
+            last = getattr(self, f"up{getattr(self, 'depth', 4)}")
+            import torch.nn.modules.module as _mm
+            hooked = bool(_mm._global_forward_hooks) or bool(_mm._global_forward_pre_hooks) or any(
+                getattr(m, a, None) for m in (out, conv, *last.modules()) for a in ("_forward_hooks", "_forward_pre_hooks"))
+            last_conv = getattr(last, "conv", None)
+            fuse = not hooked and last_conv is not None and _cdt(out) == _cdt(last_conv)
             h = self.features(x, tail=conv if fuse else None)
             return h if getattr(h, "_im2im_tail_done", False) else self.out(h)
         return self.out(self.features(x))

@@ -9,6 +9,7 @@ from torch.utils.data import TensorDataset
 
 from .. import _pkg  # noqa: F401
 from ... import hip_ops
+from ...prefetch import to_device
 from ..calibration.calibrate_model import (collect_outputs, fraction_missed_loss, gather_rows, get_rcps_loss_fn,
                                            get_rcps_losses_from_outputs, get_rcps_metrics_from_outputs, lambda_grid, _dist)
 from ..models.add_uncertainty import sets_form
@@ -125,7 +126,7 @@ def eval_net(net, loader, device):
         net.to(device=device)
         val_loss = torch.zeros((), dtype=torch.float64, device=device)
         num_val = 0
-        for batch in loader:
+        for batch in to_device(loader, device):              # [r6] uploads overlap the previous batch's kernels (im2im_uq_amd/prefetch.py)
             labels = batch[-1].to(device=device)
             x = [batch[i].to(device=device, dtype=torch.float32) for i in range(len(batch) - 1)]
             labels_pred = net(*x)

@@ -19,6 +19,7 @@ from torch.utils.data import DataLoader
 from .. import _pkg  # noqa: F401
 from ... import nn_ops
 from ...compat import load_reference_checkpoint
+from ...prefetch import to_device
 from ._wandb import wandb
 from .eval import eval_net, get_images
 
@@ -632,7 +633,10 @@ def train_net(net, train_dataset, val_dataset, device, epochs, batch_size, lr, l
             batches = _sliced()
         else:
             batches = ((b, None) for b in train_loader)
-        for batch, global_n in batches:
+        # [r6] host batches reach HBM through the two-deep pinned prefetcher (im2im_uq_amd/prefetch.py): batch k+1 is fetched, staged and
+        # uploaded on a copy stream while the kernels of batch k run -- same batches, same order, same values as the in-line
+        # `.to(device)` of the reference (:147-149), which stalls the GPU for every collation and pageable copy
+        for batch, global_n in to_device(batches, device):
             if batch is None:                                # this rank's share of a short last batch is empty: it still joins the exchange
                 sync.zero_grad(); sync.finish(); optimizer.step()
                 global_step += 1

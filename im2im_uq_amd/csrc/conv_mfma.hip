@@ -806,9 +806,11 @@ int dispatch_conv(const ConvArgs& a_in, hipStream_t stream, bool per_image = fal
   } else {
     a.ksplit = 1;
   }
+#ifdef IM2IM_BUILD_EXPERIMENTAL
   if constexpr (sizeof(T) == 2) {
-    if (conv_roll64_eligible(a, t, TAPS, per_image)) return launch_conv_roll64(a, stream);      // [r5] conv_roll.hip
+    if (conv_roll64_eligible(a, t, TAPS, per_image)) return launch_conv_roll64(a, stream);      // [r5] conv_roll.hip (build.py EXPERIMENTAL)
   }
+#endif
   if (t.tb == 1) {
     if (t.bn == 128) return launch_conv<T, 1, 16, 16, 128, 2, 2, TAPS>(a, stream);
     if (t.bn == 64 && t.th == 32) return launch_conv<T, 1, 32, 16, 64, 4, 1, TAPS>(a, stream);

@@ -29,6 +29,7 @@
 // from conv_igemm_kernel's in the last bits (fp32 sums in another order), not in what they are.
 #include "conv_common.h"
 #include <type_traits>
+#include <mutex>
 #ifndef IM2IM_CROLL_PIN
 #define IM2IM_CROLL_PIN 1
 #endif
@@ -432,11 +433,22 @@ int launch_roll_epi(const ConvArgs& a, int nitems, int grid, size_t smem, hipStr
   const bool lazy = a.in_ss != nullptr || a.in_ss_hi != nullptr;
   auto k1 = conv_roll64_kernel<EPI, true>;
   auto k0 = conv_roll64_kernel<EPI, false>;
-  static size_t attr_set = 0;
-  if (smem > attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = smem;
+  // the dynamic-LDS limit is a per-device function attribute: remembered per device, set under a lock, and a refusal (a part with
+  // less LDS than gfx950's 160 KB) is an error code for THIS launch, not a later launch failure
+  static std::mutex mu;
+  static size_t attr_set[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail_invalid("conv_roll64: device index");
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (smem > attr_set[dev]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail_invalid("conv_roll64: the device refuses the kernel's dynamic LDS size");
+      }
+      attr_set[dev] = smem;
+    }
   }
   if (lazy) hipLaunchKernelGGL(k1, dim3((unsigned)grid), dim3(256), smem, stream, a, nitems);
   else hipLaunchKernelGGL(k0, dim3((unsigned)grid), dim3(256), smem, stream, a, nitems);
@@ -452,6 +464,16 @@ void set_conv_roll(int v) { g_conv_roll = v; }
 // does this launch go to conv_roll64_kernel?  (bf16, 3x3, the 32 x 16 x 64 tile with nothing hanging over the image, no split-K,
 // no fused BatchNorm-backward sums / max-pool / 1x1 tail in the epilogue, one (scale, shift) pair per channel)
 bool conv_roll64_eligible(const ConvArgs& a, const TileChoice& t, int taps, bool per_image) {
+  if (g_conv_roll == 0) return false;
+  {   // two workgroups per CU at 2 x 38 KB + coefficients: only parts with gfx950's LDS take it; the others keep conv_igemm_kernel
+    static int lds_ok = -1;
+    if (lds_ok < 0) {
+      int dev = 0, lds = 0;
+      lds_ok = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess &&
+                (size_t)lds >= (size_t)2 * R_UNIT_B + (size_t)2 * 512 * sizeof(float)) ? 1 : 0;
+    }
+    if (!lds_ok) return false;
+  }
   if (g_conv_roll == 3 && (a.in_ss || a.in_ss_hi || a.stats || a.scale)) return false;      // 3 = the data-gradients only
   return g_conv_roll != 0 && taps == 9 && !per_image && t.tb == 1 && t.th == R_TH && t.tw == R_TW && t.bn == R_BN && a.H % R_TH == 0 &&
          a.W % R_TW == 0 && a.Ci % 32 == 0 && a.Ci <= 512 && a.Co % R_BN == 0 && a.ksplit <= 1 && a.bn_partial == nullptr &&

@@ -1670,7 +1670,12 @@ extern "C" int im2im_set_option(const char* key, int32_t value) {
   if (std::string(key) == "pool_bwd_full") { im2im::set_pool_bwd_full(value); return IM2IM_OK; }
   if (std::string(key) == "pool_bwd_blocks") { im2im::set_pool_bwd_blocks(value); return IM2IM_OK; }
   if (std::string(key) == "bn_apply_keep_mb") { im2im::set_bn_apply_keep_mb(value); return IM2IM_OK; }
+#ifdef IM2IM_BUILD_EXPERIMENTAL
   if (std::string(key) == "conv_roll") { im2im::set_conv_roll(value); return IM2IM_OK; }
+#else
+  if (std::string(key) == "conv_roll")       // conv_roll.hip is only in libraries built with IM2IM_BUILD_EXPERIMENTAL=1: 0 = already the case
+    return value == 0 ? IM2IM_OK : im2im::fail_invalid("conv_roll: this library was built without the experimental kernels (IM2IM_BUILD_EXPERIMENTAL=1)");
+#endif
   return im2im::fail_invalid("unknown option");
 }
 

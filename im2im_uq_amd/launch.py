@@ -82,20 +82,39 @@ def init_distributed(expected_world: int | None = None):
     if dist.get_world_size() != world:
         raise SystemExit(f"process group has {dist.get_world_size()} ranks, expected {world}")
     verify_world(dist, rank, world, dev, backend)
+    # the short timeout above is for the rendezvous and the world check only.  Training has rank-0-only phases (a checkpoint on a slow
+    # filesystem, validation images, a wandb upload) during which the other ranks wait in a collective: those get the backends' usual
+    # patience back (nccl's default is 10 min, gloo's 30; IM2IM_COLLECTIVE_TIMEOUT_S overrides)
+    try:
+        from torch.distributed.distributed_c10d import _set_pg_timeout
+        _set_pg_timeout(datetime.timedelta(seconds=int(os.environ.get("IM2IM_COLLECTIVE_TIMEOUT_S", "1800"))))
+    except Exception:  # noqa: BLE001  (a torch without the hook keeps the rendezvous timeout)
+        pass
     return dist, rank, world, dev, backend
 
 
 def device_identity(dev, rank: int) -> dict:
-    """what tells two ranks' GPUs apart: index, name, uuid, PCI bus id (+ the pid that holds it)"""
+    """what tells two ranks' GPUs apart: host, index, name, uuid, PCI bus id (+ the pid that holds it).  `uuid` / `pci_bus_id` are None
+    when this torch build does not expose them (then only the host and the local index are left to go by)."""
     import torch
     props = torch.cuda.get_device_properties(dev)
-    return {"rank": rank, "local_device_index": dev.index, "name": props.name, "uuid": str(getattr(props, "uuid", "")) or None,
-            "pci_bus_id": ("%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))),
+    uuid = str(getattr(props, "uuid", "") or "") or None
+    pci = None
+    if all(hasattr(props, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        pci = "%04x:%02x:%02x" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+    return {"rank": rank, "host": socket.gethostname(), "local_device_index": dev.index, "name": props.name, "uuid": uuid, "pci_bus_id": pci,
             "pid": os.getpid()}
 
 
+def identifiable(ranks) -> bool:
+    """True when every rank reported a hardware identity (a uuid or a PCI address); without one, two GPUs cannot be told apart beyond
+    (host, local index) and the distinct-device check says nothing."""
+    return all(r.get("uuid") or r.get("pci_bus_id") for r in ranks)
+
+
 def distinct_devices(ranks) -> int:
-    return len({(r["uuid"], r["pci_bus_id"], r["local_device_index"]) for r in ranks})
+    """devices behind the ranks, counted PER HOST: two nodes with the same topology hold different GPUs at the same PCI address"""
+    return len({(r.get("host"), r.get("uuid"), r.get("pci_bus_id"), r["local_device_index"]) for r in ranks})
 
 
 def verify_world(dist, rank: int, world: int, dev, backend: str):
@@ -113,7 +132,7 @@ def verify_world(dist, rank: int, world: int, dev, backend: str):
     if n != world:
         raise SystemExit(f"[rank {rank}] the {backend} communicator summed {n} ranks, expected {world}")
     nd = distinct_devices(ranks)
-    if backend == "nccl" and nd != world:
+    if backend == "nccl" and nd != world and identifiable(ranks):
         raise SystemExit(f"[rank {rank}] {world} RCCL ranks sit on {nd} distinct device(s): "
                          + ", ".join(f"rank {r['rank']} -> {r['pci_bus_id']}" for r in ranks))
     return ranks

@@ -70,4 +70,5 @@ def test_every_source_file_is_built():
     import os
     from im2im_uq_amd import build
     on_disk = sorted(f for f in os.listdir(build.CSRC) if f.endswith((".hip", ".cpp")) and not f.startswith("_"))
-    assert on_disk == sorted(build.SOURCES)
+    assert on_disk == sorted(list(build.SOURCES) + list(build.EXPERIMENTAL_SOURCES))      # [r6] conv_roll.hip: IM2IM_BUILD_EXPERIMENTAL=1 only
+    assert not set(build.SOURCES) & set(build.EXPERIMENTAL_SOURCES)

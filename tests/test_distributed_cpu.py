@@ -316,3 +316,9 @@ def test_distinct_devices_counts_physical_devices_not_ranks():
     assert launch.distinct_devices([a, b]) == 2
     assert launch.distinct_devices([a, dict(a, rank=1, pid=2)]) == 1
     assert launch.distinct_devices([a, b, dict(b, rank=2, pid=3), dict(a, rank=3, pid=4)]) == 2
+    # [r6] two nodes of the same topology are different devices at the same PCI address; a torch build that exposes neither
+    # a uuid nor PCI ids cannot tell GPUs apart, and verify_world then does not refuse the world on that count
+    n0, n1 = dict(a, host="node0"), dict(a, host="node1", rank=1)
+    assert launch.distinct_devices([n0, n1]) == 2 and launch.identifiable([n0, n1])
+    blind = [dict(a, uuid=None, pci_bus_id=None, host="node0"), dict(a, uuid=None, pci_bus_id=None, host="node1", rank=1)]
+    assert not launch.identifiable(blind)

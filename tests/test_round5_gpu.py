@@ -354,6 +354,24 @@ def test_eval_fused_outconv_respects_hooks_and_a_dtype_override_on_outconv():
         assert not getattr(feat, "_im2im_tail_done", False) and feat.dtype == torch.float32
         model.baseModel.out.compute_dtype = None
         assert torch.equal(model(x), ref)
+        # [r6] a hook on the LAST Up block (or a module inside it) must see that block's own 64-channel activation, and a
+        # global module forward hook must see every module's real output: both switch the fused tail off
+        seen = []
+        h = model.baseModel.up2.register_forward_hook(lambda m, i, o: seen.append(tuple(o.shape)))
+        out = model(x)
+        h.remove()
+        assert seen == [(2, 64, 64, 64)] and torch.equal(out, ref)
+        seen = []
+        h = model.baseModel.up2.conv.register_forward_hook(lambda m, i, o: seen.append(tuple(o.shape)))
+        out = model(x)
+        h.remove()
+        assert seen == [(2, 64, 64, 64)] and torch.equal(out, ref)
+        shapes = {}
+        h = torch.nn.modules.module.register_module_forward_hook(lambda m, i, o: shapes.__setitem__(type(m).__name__, tuple(getattr(o, "shape", ()))))
+        out = model(x)
+        h.remove()
+        assert shapes.get("Up") == (2, 64, 64, 64) and shapes.get("OutConv") == (2, 32, 64, 64) and torch.equal(out, ref)
+        assert getattr(model.baseModel(x), "_im2im_tail_done", False)             # nobody listening any more: fused again
 
 
 # ------------------------------------------------------------------------------------------------ conv_roll64_kernel (csrc/conv_roll.hip)
@@ -376,8 +394,14 @@ def test_conv_roll64_kernel_vs_cpu_and_vs_conv_igemm(case):
     (count exact, mean / M2 to 1e-5 after merging), forward with statistics, the folded eval epilogue and the plain
     data-gradient form."""
     import torch.nn.functional as F
-    from im2im_uq_amd import hip_ops, nn_ops
+    from im2im_uq_amd import _lib, hip_ops, nn_ops
     from test_kernels_gpu import merged_moments
+    try:                                                  # [r6] the kernel is only in libraries built with IM2IM_BUILD_EXPERIMENTAL=1
+        hip_ops.set_option("conv_roll", 1)
+    except _lib.Im2ImError:
+        pytest.skip("library built without the experimental kernels (IM2IM_BUILD_EXPERIMENTAL=1 python -m im2im_uq_amd.build)")
+    finally:
+        hip_ops.set_option("conv_roll", 0)
     b, h, w, ci, co, split, lazy = case
     BF = torch.bfloat16
     g = torch.Generator().manual_seed(7)

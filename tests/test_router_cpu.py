@@ -97,3 +97,19 @@ def test_wnet_state_dict_matches_the_reference(tmp_path):
     want = torch.load(out)
     got = {k: tuple(v.shape) for k, v in WNet(2, 1).state_dict().items()}
     assert list(got.items()) == list(want.items())
+
+
+def test_prefetcher_is_a_pass_through_without_a_gpu_device():
+    """[r6] im2im_uq_amd/prefetch.py: on a non-CUDA device (and with IM2IM_PREFETCH=0) the wrapper yields the loader's own batches"""
+    import torch
+    from torch.utils.data import DataLoader, TensorDataset
+    from im2im_uq_amd.prefetch import DevicePrefetcher, _map_tensors
+    ds = TensorDataset(torch.arange(10.0).view(10, 1), torch.arange(10))
+    loader = DataLoader(ds, batch_size=4)
+    got = list(DevicePrefetcher(loader, "cpu"))
+    want = list(loader)
+    assert len(got) == 3 and all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(got, want))
+    assert len(DevicePrefetcher(loader, "cpu")) == 3
+    nested = ([torch.ones(2), {"k": torch.zeros(1)}], 78, None)
+    out = _map_tensors(nested, lambda t: t + 1)
+    assert out[1] == 78 and out[2] is None and float(out[0][0][0]) == 2.0 and float(out[0][1]["k"][0]) == 1.0
