@@ -52,7 +52,8 @@ SIGNATURES = {
                                     _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_conv_fwd_eval_pool": (_i32, [_ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_conv_fwd_eval_tail": (_i32, [_ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
-    "im2im_conv_wgrad_fp8": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i32, _i32, _i32, _i32, _ptr]),
+    # x, x_ss, x_hi, x_ss_hi, Ci_lo, dz, amax_prev, dw, ws, ws_bytes, B, H, W, Ci, Co, target_wgs, nsplit (host int*), stream
+    "im2im_conv_wgrad_fp8": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _ptr, _ptr]),
     "im2im_conv_splitk_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "im2im_conv_fwd_split_ws": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr,
                                        _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr, _i64, _ptr]),
@@ -67,22 +68,24 @@ SIGNATURES = {
                                   _i32, _ptr]),
     # dz, wd, dx, bn_z, bn_ss, bn_mi, bn_partial, B, H, W, Ci, Co, taps, dtype, stream
     "im2im_conv_dgrad_bn": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
-    "im2im_bn_relu_bwd_from_partial": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i64, _ptr]),
+    "im2im_bn_relu_bwd_from_partial": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i64, _ptr, _ptr]),
     "im2im_conv_wgrad_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32]),
-    # x, x_ss, x_hi, x_ss_hi, Ci_lo, dz, dw, ws, ws_bytes, B, H, W, Ci, Co, taps, dtype, stream
+    # x, x_ss, x_hi, x_ss_hi, Ci_lo, dz, dw, ws, ws_bytes, B, H, W, Ci, Co, taps, dtype, target_wgs, nsplit (host int*), stream
     "im2im_conv_wgrad_split": (_i32, [_ptr, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _i64, _i32, _i32, _i32, _i32, _i32, _i32,
-                                      _i32, _ptr]),
+                                      _i32, _i32, _ptr, _ptr]),
+    "im2im_wgrad_reduce_multi": (_i32, [_i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "im2im_conv_wgrad": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_reduce_workspace_bytes": (_i64, [_i64]),
-    "im2im_bn_finalize": (_i32, [_ptr, _i64, _i32, _i64, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _i32, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    # ..., mean_invstd, scale_shift, ws, counters, num_batches_tracked, stream
+    "im2im_bn_finalize": (_i32, [_ptr, _i64, _i32, _i64, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "im2im_bn_fold_eval": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _f32, _i32, _ptr, _ptr]),
     "im2im_bn_relu_apply": (_i32, [_ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr]),
     "im2im_bn_bwd_workspace_bytes": (_i64, [_i64, _i32]),
     "im2im_bn_relu_pool_bwd_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
-    "im2im_bn_relu_pool_bwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr, _i64, _ptr]),
-    "im2im_bn_relu_bwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i64, _ptr]),
+    "im2im_bn_relu_pool_bwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr, _i64, _ptr, _ptr]),
+    "im2im_bn_relu_bwd": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i64, _ptr, _ptr]),
     "im2im_bn_bwd_rows_per_block": (_i64, [_i64]),
-    "im2im_bn_relu_bwd_phase": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i64, _i32, _i64, _i64, _ptr]),
+    "im2im_bn_relu_bwd_phase": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i64, _i32, _i64, _i64, _ptr, _ptr]),
     "im2im_conv_tiles_per_image": (_i64, [_i32, _i32]),
     "im2im_conv_fwd_per_image": (_i32, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "im2im_groupnorm_stats_rows": (_i64, [_i32, _i64]),

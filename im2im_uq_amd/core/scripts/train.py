@@ -19,7 +19,7 @@ from torch.utils.data import DataLoader
 from .. import _pkg  # noqa: F401
 from ... import nn_ops
 from ...compat import load_reference_checkpoint
-from ...prefetch import to_device
+from ...prefetch import DevicePrefetcher, loader as prefetch_loader, to_device
 from ._wandb import wandb
 from .eval import eval_net, get_images
 
@@ -138,6 +138,7 @@ class GradSync:
             if bn is not None:
                 side.wait_stream(bn)            # ... and dgamma / dbeta of the pipelined BatchNorm backward on its stream
             with torch.cuda.stream(side):       # ... and, in stream order, the conv weight gradients computed on this one
+                nn_ops.flush_wgrad_reduce(self.flat.device.index)     # [r6] their deferred split-K reductions, in one launch
                 self._pack(b)
                 self.launched[b] = self.dist.all_reduce(self.flat[lo:hi], async_op=True)
         else:
@@ -313,8 +314,9 @@ class GraphedStep:
     graph) and the whole step is one replay.
 
     The first WARM steps run eagerly on the capture stream (they are real training steps), then the step is captured once and
-    replayed.  A batch of another shape (the short last one of an epoch) or another loss weight makes `step` return None and
-    the caller runs it eagerly.  A capture that fails (a module that synchronises, a hook that reads a tensor) is abandoned:
+    replayed.  A batch of another shape (the short last one of an epoch) or another loss weight is run as a plain step on this
+    object's stream ([r6] `_eager_other`: every training step -- warm-up, odd, captured -- lives on ONE stream, so autograd's
+    AccumulateGrad nodes never belong to another).  A capture that fails (a module that synchronises, a hook that reads a tensor) is abandoned:
     the optimizer's counters are put back, `failed` is set and every later call returns None.  fp8 mode is not captured (it
     rotates its amax slots on the host)."""
     WARM = 3
@@ -436,6 +438,24 @@ class GraphedStep:
         self.opt.step()
         return loss.detach() * self.weight if self.sync is not None else loss.detach()
 
+    def _eager_other(self, x, labels, weight):
+        """a batch of another shape / loss weight (the short last batch of an epoch): the plain step, on THIS object's stream and with
+        its autograd graph gone when it returns.  [r6] Run by the caller on its own stream with `loss` kept alive into the next
+        iteration -- what train_net did -- it left AccumulateGrad nodes bound to the caller's (default) stream; the capture that
+        followed in the next epoch then accumulated gradients on the default stream and hipStreamEndCapture fell over."""
+        pred = self.net(*x)
+        loss = self.net.loss_fn(pred, labels)
+        if self.sync is None:
+            self.opt.zero_grad(set_to_none=True)
+            loss.backward()
+        else:
+            self.sync.zero_grad()
+            (loss * weight).backward()
+            self.sync.finish()
+        nn_ops.join_side_streams()
+        self.opt.step()
+        return loss.detach() * weight if self.sync is not None else loss.detach()
+
     def _addresses(self):
         return (tuple(p.data_ptr() for p in self.params), tuple(b.data_ptr() for b in self.net.buffers() if b is not None),
                 nn_ops._Scratch.addresses())
@@ -458,7 +478,9 @@ class GraphedStep:
                 self.sync.zero_grad()
                 self.sync.deferred = not self.collectives_in_graph
             self.stream.wait_stream(cur)
-            with torch.cuda.graph(graph, stream=self.stream):
+            # thread_local: only this thread's calls are held to the capture rules -- the prefetcher's producer thread (im2im_uq_amd/prefetch.py)
+            # synchronises events and pins memory while this thread captures, which the default "global" mode turns into a failed capture
+            with torch.cuda.graph(graph, stream=self.stream, capture_error_mode="thread_local"):
                 loss = self._fwd_bwd()
                 if self.sync is not None:
                     if self.collectives_in_graph:
@@ -504,7 +526,7 @@ class GraphedStep:
         return True
 
     def step(self, x, labels, weight=1.0):
-        """-> the step's (weighted) loss as a 0-dim tensor, or None when this batch has to run eagerly."""
+        """-> the step's (weighted) loss as a 0-dim tensor, or None when the caller has to run the batch itself (after a failed capture)."""
         if self.failed:
             return None
         key = (tuple((tuple(t.shape), t.dtype) for t in x), tuple(labels.shape), labels.dtype, float(weight))
@@ -513,9 +535,13 @@ class GraphedStep:
             self.weight = float(weight)
             self.xs = tuple(torch.empty_like(t) for t in x)
             self.y = torch.empty_like(labels)
-        if key != self.key:
-            return None
         cur = torch.cuda.current_stream()
+        if key != self.key:
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                out = self._eager_other(x, labels, float(weight))
+            cur.wait_stream(self.stream)
+            return out
         for dst, src in zip(self.xs, x):
             dst.copy_(src, non_blocking=True)
         self.y.copy_(labels, non_blocking=True)
@@ -591,7 +617,8 @@ def train_net(net, train_dataset, val_dataset, device, epochs, batch_size, lr, l
             sampler = GlobalBatchSampler(len(train_dataset), batch_size, rank, world, shuffle=True, seed=0)
             train_loader = None
         else:
-            train_loader = DataLoader(train_dataset, batch_size=batch_size, shuffle=True, num_workers=0)
+            # (the reference's loader, :104; its batches are stacked straight into pinned staging memory -- im2im_uq_amd/prefetch.py)
+            train_loader = prefetch_loader(train_dataset, device, batch_size=batch_size, shuffle=True, num_workers=0)
     except Exception:  # noqa: BLE001  (iterable datasets cannot be shuffled, reference :105-106)
         # with several ranks every rank reads the same global batches from the stream and keeps its slice of each
         iterable = True
@@ -636,7 +663,7 @@ def train_net(net, train_dataset, val_dataset, device, epochs, batch_size, lr, l
         # [r6] host batches reach HBM through the two-deep pinned prefetcher (im2im_uq_amd/prefetch.py): batch k+1 is fetched, staged and
         # uploaded on a copy stream while the kernels of batch k run -- same batches, same order, same values as the in-line
         # `.to(device)` of the reference (:147-149), which stalls the GPU for every collation and pageable copy
-        for batch, global_n in to_device(batches, device):
+        for batch, global_n in (batches if isinstance(train_loader, DevicePrefetcher) else to_device(batches, device)):
             if batch is None:                                # this rank's share of a short last batch is empty: it still joins the exchange
                 sync.zero_grad(); sync.finish(); optimizer.step()
                 global_step += 1
@@ -673,6 +700,7 @@ def train_net(net, train_dataset, val_dataset, device, epochs, batch_size, lr, l
 
             global_step += 1
             num_examples += labels.shape[0]
+            labels_pred = loss = None                        # the step's autograd graph does not outlive the step
 
         if dist:                                             # the logged quantity is the global one (sum of batch-mean losses / #examples)
             tot = torch.stack([epoch_loss, torch.tensor(float(num_examples), dtype=torch.float64, device=device)])

@@ -111,6 +111,7 @@ inline TileChoice pick_tile(int B, int H, int W, int Co, bool per_image = false)
 // conv_mfma.hip: A/B switch of the split-K path (im2im_set_option "conv_splitk", conv_wgrad.hip)
 void set_conv_splitk(int v);
 void set_bn_fused_small(int v);          // elementwise.hip: one-launch BatchNorm sums for few partial rows
+void set_bn_onelaunch(int v);            // elementwise.hip [r6]: last-block-finalizes BatchNorm sums at every size
 void set_pool_bwd_blocks(int v);
 void set_bn_apply_keep_mb(int v);
 void set_pool_bwd_full(int v);           // elementwise.hip: branch-free bn_relu_pool_bwd for even extents (A/B)

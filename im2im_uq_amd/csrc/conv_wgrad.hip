@@ -1383,6 +1383,62 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// [r6] the same reduction for many layers in one launch: block b belongs to the tensor whose block range holds it and runs
+// wgrad_reduce_kernel's loop with that tensor's own block count -- per output the same slabs in the same order, the same bits.
+// 18 launches of 8-50 us per training step become one (the slabs stay in per-layer workspaces until the backward pass ends).
+constexpr int REDUCE_MULTI_MAX = 32;
+struct ReduceMultiArgs {
+  const float* partial[REDUCE_MULTI_MAX];
+  float* dw[REDUCE_MULTI_MAX];
+  int nsplit[REDUCE_MULTI_MAX], Co[REDUCE_MULTI_MAX], Ci[REDUCE_MULTI_MAX], taps[REDUCE_MULTI_MAX];
+  int first_block[REDUCE_MULTI_MAX + 1];                   // tensor t owns blocks [first_block[t], first_block[t+1])
+  int n;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReduceMultiArgs a) {
+  __shared__ float4 s_acc[4][64];
+  int t = 0;
+  while (t + 1 < a.n && (int)blockIdx.x >= a.first_block[t + 1]) ++t;
+  const int blk = (int)blockIdx.x - a.first_block[t], nblk = a.first_block[t + 1] - a.first_block[t];
+  const int nsplit = a.nsplit[t], Ci = a.Ci[t], taps = a.taps[t];
+  float* __restrict__ dw = a.dw[t];
+  const size_t total4 = (size_t)a.Co[t] * taps * Ci / 4;
+  const float4* __restrict__ p4 = reinterpret_cast<const float4*>(a.partial[t]);
+  const int ol = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  for (size_t base = (size_t)blk * 64; base < total4; base += (size_t)nblk * 64) {
+    const size_t i = base + ol;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < total4) {
+      int k = sl;
+      for (; k + 12 < nsplit; k += 16) {
+        const float4 q0 = p4[(size_t)k * total4 + i], q1 = p4[(size_t)(k + 4) * total4 + i];
+        const float4 q2 = p4[(size_t)(k + 8) * total4 + i], q3 = p4[(size_t)(k + 12) * total4 + i];
+        s.x += q0.x; s.y += q0.y; s.z += q0.z; s.w += q0.w;
+        s.x += q1.x; s.y += q1.y; s.z += q1.z; s.w += q1.w;
+        s.x += q2.x; s.y += q2.y; s.z += q2.z; s.w += q2.w;
+        s.x += q3.x; s.y += q3.y; s.z += q3.z; s.w += q3.w;
+      }
+      for (; k < nsplit; k += 4) {
+        const float4 q = p4[(size_t)k * total4 + i];
+        s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+      }
+    }
+    s_acc[sl][ol] = s;
+    __syncthreads();
+    if (sl == 0 && i < total4) {
+      const float4 q0 = s_acc[0][ol], q1 = s_acc[1][ol], q2 = s_acc[2][ol], q3 = s_acc[3][ol];
+      const float v[4] = {(q0.x + q1.x) + (q2.x + q3.x), (q0.y + q1.y) + (q2.y + q3.y), (q0.z + q1.z) + (q2.z + q3.z), (q0.w + q1.w) + (q2.w + q3.w)};
+      const size_t e = i * 4;
+      const int ci = (int)(e % Ci);
+      const size_t r = e / Ci;
+      const int tp = (int)(r % taps);
+      const size_t co = r / taps;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dw[(co * Ci + ci + j) * taps + tp] = v[j];
+    }
+    __syncthreads();
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, int Co, int Ci, int taps,
                                                            T* __restrict__ wf, T* __restrict__ wd) {
@@ -1493,11 +1549,11 @@ namespace {
 int g_wgrad_co128 = 1;      // A/B switch (im2im_set_option "wgrad_co128")
 int g_wgrad_tile16 = 1;     // A/B switch "wgrad_tile16": 256-pixel tiles for the 64-output-channel form
 int g_wgrad_fp8_co128 = 1;  // A/B switch "wgrad_fp8_co128": the fp8 weight gradient's 128-output-channel form where Co % 128 == 0
-int g_wgrad_wgs = 256;      // A/B switch "wgrad_wgs": workgroups a bf16 3x3 weight-gradient launch aims at (split-K slabs = this / channel blocks)
 int g_wgrad_roll = 1;       // A/B switch "wgrad_roll": conv_wgrad_roll_kernel (rolling operand prefetch, staging spread over the MFMA phase)
 template <typename T, int TAPS>
 int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float* x_ss_hi, int Ci_lo, const void* dz, float* partial,
-                 int64_t partial_bytes, float* dw, int B, int H, int W, int Ci, int Co, hipStream_t stream) {
+                 int64_t partial_bytes, float* dw, int B, int H, int W, int Ci, int Co, int target_wgs, int32_t* nsplit_out, hipStream_t stream) {
+  const int g_wgrad_wgs = target_wgs > 0 ? target_wgs : 256;     // [r6] an argument since ABI 3 (was a process-global option)
   constexpr int TH = 8, TW = 16;
   constexpr int PAD = (TAPS == 9) ? 1 : 0;
   constexpr bool IS_BF16 = sizeof(T) == 2;
@@ -1593,6 +1649,8 @@ int launch_wgrad(const void* x, const float* x_ss, const void* x_hi, const float
     hipLaunchKernelGGL(kern, dim3((unsigned)cblocks, (unsigned)nsplit), dim3(256), smem, stream, a);
     if (int rc = check_launch("conv_wgrad_kernel")) return rc;
   }
+  if (nsplit_out) *nsplit_out = (int32_t)nsplit;
+  if (!dw) return IM2IM_OK;                                   // the slabs stay in the workspace for im2im_wgrad_reduce_multi
   const size_t total = (size_t)Co * TAPS * Ci;
   int blocks = (int)std::min<size_t>(cdiv(total / 4, 64), 8192);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, (int)nsplit, Co, Ci, TAPS, dw);
@@ -1615,15 +1673,16 @@ extern "C" int im2im_conv_wgrad(const void* x, const float* x_scale_shift, const
                                 int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t taps, int32_t dtype,
                                 im2im_stream_t stream_) {
   return im2im_conv_wgrad_split(x, x_scale_shift, nullptr, nullptr, Ci, dz, dw, workspace, workspace_bytes, B, H, W, Ci, Co, taps,
-                                dtype, stream_);
+                                dtype, 0, nullptr, stream_);
 }
 
 extern "C" int im2im_conv_wgrad_split(const void* x, const float* x_scale_shift, const void* x_hi, const float* x_scale_shift_hi,
                                       int32_t Ci_lo, const void* dz, float* dw, void* workspace, int64_t workspace_bytes,
                                       int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t taps, int32_t dtype,
-                                      im2im_stream_t stream_) {
+                                      int32_t target_wgs, int32_t* nsplit, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  IM2IM_REQUIRE(x && dz && dw && workspace);
+  IM2IM_REQUIRE(x && dz && workspace && (dw || nsplit));
+  IM2IM_REQUIRE(target_wgs >= 0 && target_wgs <= 4096);
   if (x_hi) {
     IM2IM_REQUIRE(Ci_lo > 0 && Ci_lo % 64 == 0 && Ci == 2 * Ci_lo);   // a 64-channel block never straddles the two sources
   } else {
@@ -1637,10 +1696,34 @@ extern "C" int im2im_conv_wgrad_split(const void* x, const float* x_scale_shift,
   IM2IM_REQUIRE(dtype == IM2IM_F32 || dtype == IM2IM_BF16);
   float* partial = reinterpret_cast<float*>(workspace);
   if (dtype == IM2IM_BF16)
-    return taps == 9 ? launch_wgrad<bf16_t, 9>(x, x_scale_shift, x_hi, x_scale_shift_hi, Ci_lo, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream)
-                     : launch_wgrad<bf16_t, 1>(x, x_scale_shift, x_hi, x_scale_shift_hi, Ci_lo, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream);
-  return taps == 9 ? launch_wgrad<float, 9>(x, x_scale_shift, x_hi, x_scale_shift_hi, Ci_lo, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream)
-                   : launch_wgrad<float, 1>(x, x_scale_shift, x_hi, x_scale_shift_hi, Ci_lo, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, stream);
+    return taps == 9 ? launch_wgrad<bf16_t, 9>(x, x_scale_shift, x_hi, x_scale_shift_hi, Ci_lo, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, target_wgs, nsplit, stream)
+                     : launch_wgrad<bf16_t, 1>(x, x_scale_shift, x_hi, x_scale_shift_hi, Ci_lo, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, target_wgs, nsplit, stream);
+  return taps == 9 ? launch_wgrad<float, 9>(x, x_scale_shift, x_hi, x_scale_shift_hi, Ci_lo, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, target_wgs, nsplit, stream)
+                   : launch_wgrad<float, 1>(x, x_scale_shift, x_hi, x_scale_shift_hi, Ci_lo, dz, partial, workspace_bytes, dw, B, H, W, Ci, Co, target_wgs, nsplit, stream);
+}
+
+extern "C" int im2im_wgrad_reduce_multi(int32_t n_tensors, const float* const* slabs, const int32_t* nsplit, const int32_t* Co,
+                                        const int32_t* Ci, const int32_t* taps, float* const* dw, im2im_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  IM2IM_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || (slabs && nsplit && Co && Ci && taps && dw)));
+  for (int t0 = 0; t0 < n_tensors; t0 += REDUCE_MULTI_MAX) {
+    ReduceMultiArgs a;
+    a.n = std::min(n_tensors - t0, REDUCE_MULTI_MAX);
+    int nblocks = 0;
+    for (int j = 0; j < a.n; ++j) {
+      const int i = t0 + j;
+      IM2IM_REQUIRE(slabs[i] && dw[i] && nsplit[i] > 0 && Co[i] > 0 && Ci[i] > 0 && Ci[i] % 4 == 0 && (taps[i] == 9 || taps[i] == 1));
+      a.partial[j] = slabs[i]; a.dw[j] = dw[i]; a.nsplit[j] = nsplit[i]; a.Co[j] = Co[i]; a.Ci[j] = Ci[i]; a.taps[j] = taps[i];
+      a.first_block[j] = nblocks;
+      const size_t total4 = (size_t)Co[i] * taps[i] * Ci[i] / 4;
+      nblocks += (int)std::min<size_t>(cdiv(total4, 64), 2048);
+    }
+    a.first_block[a.n] = nblocks;
+    for (int j = a.n + 1; j <= REDUCE_MULTI_MAX; ++j) a.first_block[j] = nblocks;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, a);
+    if (int rc = check_launch("wgrad_reduce_multi_kernel")) return rc;
+  }
+  return IM2IM_OK;
 }
 
 extern "C" int im2im_pack_conv_weight(const float* w, int32_t Co, int32_t Ci, int32_t taps, int32_t dtype, void* wf,
@@ -1664,9 +1747,9 @@ extern "C" int im2im_set_option(const char* key, int32_t value) {
   if (std::string(key) == "wgrad_co128") { g_wgrad_co128 = value; return IM2IM_OK; }
   if (std::string(key) == "wgrad_tile16") { g_wgrad_tile16 = value; return IM2IM_OK; }
   if (std::string(key) == "wgrad_roll") { g_wgrad_roll = value; return IM2IM_OK; }
-  if (std::string(key) == "wgrad_wgs") { g_wgrad_wgs = value > 0 ? value : 256; return IM2IM_OK; }
   if (std::string(key) == "wgrad_fp8_co128") { g_wgrad_fp8_co128 = value; return IM2IM_OK; }
   if (std::string(key) == "bn_fused_small") { im2im::set_bn_fused_small(value); return IM2IM_OK; }
+  if (std::string(key) == "bn_onelaunch") { im2im::set_bn_onelaunch(value); return IM2IM_OK; }
   if (std::string(key) == "pool_bwd_full") { im2im::set_pool_bwd_full(value); return IM2IM_OK; }
   if (std::string(key) == "pool_bwd_blocks") { im2im::set_pool_bwd_blocks(value); return IM2IM_OK; }
   if (std::string(key) == "bn_apply_keep_mb") { im2im::set_bn_apply_keep_mb(value); return IM2IM_OK; }
@@ -1719,9 +1802,11 @@ extern "C" int im2im_pack_conv_weights_multi(int32_t n_tensors, const float* con
 extern "C" int im2im_conv_wgrad_fp8(const void* x, const float* x_scale_shift, const void* x_hi, const float* x_scale_shift_hi,
                                     int32_t Ci_lo, const void* dz, const float* amax_prev, float* dw, void* workspace,
                                     int64_t workspace_bytes, int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co,
-                                    im2im_stream_t stream_) {
+                                    int32_t target_wgs, int32_t* nsplit_out, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  IM2IM_REQUIRE(x && dz && dw && workspace && amax_prev);
+  IM2IM_REQUIRE(x && dz && (dw || nsplit_out) && workspace && amax_prev);
+  IM2IM_REQUIRE(target_wgs >= 0 && target_wgs <= 4096);
+  const int g_wgrad_wgs = target_wgs > 0 ? target_wgs : 256;
   if (x_hi) {
     IM2IM_REQUIRE(Ci_lo > 0 && Ci_lo % 64 == 0 && Ci == 2 * Ci_lo);
   } else {
@@ -1779,6 +1864,8 @@ extern "C" int im2im_conv_wgrad_fp8(const void* x, const float* x_scale_shift, c
     hipLaunchKernelGGL(kern, dim3((unsigned)cblocks, (unsigned)nsplit), dim3(768), smem, stream, fa);
   }
   if (int rc = check_launch("conv_wgrad_fp8_kernel")) return rc;
+  if (nsplit_out) *nsplit_out = (int32_t)nsplit;
+  if (!dw) return IM2IM_OK;
   const size_t total = (size_t)Co * 9 * Ci;
   int blocks = (int)std::min<size_t>(cdiv(total / 4, 64), 8192);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<float*>(workspace), (int)nsplit, Co, Ci, 9, dw);

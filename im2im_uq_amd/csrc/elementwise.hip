@@ -113,6 +113,87 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   bn_finalize_channel(m, c, C, gamma, beta, running_mean, running_var, momentum, eps, centered, mean_invstd, scale_shift);
 }
 
+// [r6] stage 1 and stage 2 in ONE launch at every size.  Grid and stage-1 arithmetic of bn_stats_stage1_kernel; a block that has
+// written its split row takes a ticket from its channel group's counter (device-scope atomic behind a release fence), and the
+// block that draws the last ticket -- every other split row of the group is then visible to it -- merges the S rows with
+// bn_finalize_kernel's butterfly (one wave per channel, lane i = split row i: the same order, the same bits) and puts the counter
+// back to zero for the next launch on this stream.  counters: >= 16 zero-initialised ints owned by the caller, used by one stream
+// at a time.  One ~5 us launch and one dependent-launch gap less per BatchNorm layer and pass.
+__device__ __forceinline__ bool last_block_of_group(int32_t* counter, int nblocks) {
+  __shared__ int s_last;
+  __threadfence();                                          // this block's tmp row is visible device-wide before the ticket
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(counter, 1) == nblocks - 1);
+  __syncthreads();
+  if (s_last) __threadfence();                              // ... and the other blocks' rows to this one after it
+  return s_last != 0;
+}
+
+__global__ __launch_bounds__(1024) void bn_stats_onelaunch_kernel(const float* __restrict__ partial, int64_t R, int C, int64_t rows_per_split,
+                                                                   double* __restrict__ tmp, int32_t* __restrict__ counters,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                   float momentum, float eps, int centered,
+                                                                   float* __restrict__ mean_invstd, float* __restrict__ scale_shift,
+                                                                   long long* __restrict__ num_batches_tracked) {
+  __shared__ double sh[2][16][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const bool on = c < C;
+  const int S = gridDim.y;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_split;
+  const int64_t r1 = (r0 + rows_per_split < R) ? r0 + rows_per_split : R;
+  double n = 0.0, a = 0.0;
+  if (on)
+    for (int64_t r = r0 + rl; r < r1; r += 16) {
+      const float* row = partial + r * 3 * C;
+      const double nt = (double)row[2 * C + c];
+      n += nt; a += nt * (double)row[c];
+    }
+  sh[0][rl][cl] = n; sh[1][rl][cl] = a;
+  __syncthreads();
+  double N = 0.0, A = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { N += sh[0][i][cl]; A += sh[1][i][cl]; }
+  const double mean = N > 0.0 ? A / N : 0.0;
+  double q = 0.0;
+  if (on)
+    for (int64_t r = r0 + rl; r < r1; r += 16) {
+      const float* row = partial + r * 3 * C;
+      const double d = (double)row[c] - mean;
+      q += (double)row[C + c] + (double)row[2 * C + c] * d * d;
+    }
+  __syncthreads();
+  sh[0][rl][cl] = q;
+  __syncthreads();
+  if (rl == 0 && on) {
+    double Q = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Q += sh[0][i][cl];
+    double* o = tmp + (int64_t)blockIdx.y * 3 * C;
+    o[c] = N; o[C + c] = mean; o[2 * C + c] = Q;
+  }
+  if (!last_block_of_group(counters + blockIdx.x, S)) return;
+  // stage 2 for this group's 64 channels: 16 waves x 4 channels, bn_finalize_kernel's merge
+  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const volatile double* vt = tmp;                          // written by other blocks during this launch
+#pragma unroll 1
+  for (int j = 0; j < 4; ++j) {
+    const int cc = blockIdx.x * 64 + wv * 4 + j;
+    if (cc >= C) break;
+    Moments m{0.0, 0.0, 0.0};
+    if (lane < S) { const volatile double* row = vt + (size_t)lane * 3 * C; m = Moments{row[cc], row[C + cc], row[2 * C + cc]}; }
+    for (int off = 32; off > 0; off >>= 1) {
+      const Moments o{__shfl_xor(m.n, off, 64), __shfl_xor(m.mean, off, 64), __shfl_xor(m.m2, off, 64)};
+      m = merge_moments(m, o);
+    }
+    if (lane == 0)
+      bn_finalize_channel(m, cc, C, gamma, beta, running_mean, running_var, momentum, eps, centered, mean_invstd, scale_shift);
+  }
+  if (threadIdx.x == 0) counters[blockIdx.x] = 0;
+}
+
 // [r4] few partial rows (R <= BN_FUSED_MAX_ROWS = 256: every layer of the 32x32 config, the deep levels of a small batch): stage 1 over
 // ALL rows and stage 2 in one launch, block = 16 channels x 64 row lanes -- one ~5 us launch less per BatchNorm layer where the
 // step is a chain of such launches.
@@ -293,6 +374,42 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
   dgamma[c] = (float)s2;
   coef[c] = (float)(s1 / count);
   coef[C + c] = (float)(s2 / count);
+}
+
+// [r6] reduce_rows_stage1_kernel + bn_bwd_finalize_kernel in ONE launch at every size (see bn_stats_onelaunch_kernel): grid (ceil(2C / 64), S);
+// the last block of a column group sums the S rows of its 64 columns with bn_bwd_finalize_kernel's butterfly (same bits).  Column k of
+// [2][C]: k < C = sum g -> dbeta, coef[k]; k >= C = sum g*xhat -> dgamma, coef[k].
+__global__ __launch_bounds__(256) void bn_bwd_sums_onelaunch_kernel(const float* __restrict__ partial, int64_t R, int C, int64_t rows_per_split,
+                                                                     double* __restrict__ tmp, int32_t* __restrict__ counters, double count,
+                                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+  __shared__ double s_acc[4][64];
+  const int64_t K = 2 * (int64_t)C;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int64_t k = (int64_t)blockIdx.x * 64 + cl;
+  const int S = gridDim.y;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_split;
+  const int64_t r1 = (r0 + rows_per_split < R) ? r0 + rows_per_split : R;
+  double acc = 0.0;
+  if (k < K)
+    for (int64_t r = r0 + rl; r < r1; r += 4) acc += (double)partial[r * K + k];
+  s_acc[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && k < K) tmp[(int64_t)blockIdx.y * K + k] = s_acc[0][cl] + s_acc[1][cl] + s_acc[2][cl] + s_acc[3][cl];
+  if (!last_block_of_group(counters + blockIdx.x, S)) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const volatile double* vt = tmp;
+#pragma unroll 1
+  for (int j = 0; j < 16; ++j) {
+    const int64_t kk = (int64_t)blockIdx.x * 64 + wv * 16 + j;
+    if (kk >= K) break;
+    double v = (lane < S) ? vt[(size_t)lane * K + kk] : 0.0;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) {
+      if (kk < C) dbeta[kk] = (float)v; else dgamma[kk - C] = (float)v;
+      coef[kk] = (float)(v / count);
+    }
+  }
+  if (threadIdx.x == 0) counters[blockIdx.x] = 0;
 }
 
 // [r4] the same for few partial rows (R <= BN_FUSED_MAX_ROWS): both stages in one launch, block = 16 channels x 64 row lanes
@@ -1618,11 +1735,18 @@ int64_t g_bn_apply_keep_bytes = 0;                           // im2im_set_option
 int g_pool_bwd_full = 1;                                     // im2im_set_option("pool_bwd_full", 0 / 1): branch-free bn_relu_pool_bwd for even extents
 int g_bn_fused_small = 1;                                    // im2im_set_option("bn_fused_small", 0 / 1 / n): off / up to BN_FUSED_MAX_ROWS partial rows / up to n rows
 inline int64_t bn_fused_rows() { return g_bn_fused_small <= 0 ? -1 : g_bn_fused_small == 1 ? BN_FUSED_MAX_ROWS : g_bn_fused_small; }
+int g_bn_onelaunch = 1;                                      // im2im_set_option("bn_onelaunch", 0 / 1): [r6] statistics / backward sums of > bn_fused_small rows in one launch (needs `counters`)
 inline int launch_bn_bwd_sums(const float* partial, int64_t R, int C, double count, double* tmp, float* dgamma, float* dbeta,
-                              float* coef, hipStream_t stream) {
+                              float* coef, int32_t* counters, hipStream_t stream) {
   if (R <= bn_fused_rows()) {
     hipLaunchKernelGGL(bn_bwd_sums_fused_kernel, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, stream, partial, R, C, count, dgamma, dbeta, coef);
     return check_launch("bn_bwd_sums_fused_kernel");
+  }
+  if (counters && g_bn_onelaunch && cdiv(2 * (int64_t)C, 64) <= IM2IM_BN_COUNTERS) {
+    const int S = reduce_splits(R);
+    hipLaunchKernelGGL(bn_bwd_sums_onelaunch_kernel, dim3((unsigned)cdiv(2 * (int64_t)C, 64), (unsigned)S), dim3(256), 0, stream, partial, R, C,
+                       cdiv(R, S), tmp, counters, count, dgamma, dbeta, coef);
+    return check_launch("bn_bwd_sums_onelaunch_kernel");
   }
   int rc;
   const int S = launch_reduce_stage1(partial, R, 2 * (int64_t)C, tmp, stream, &rc);
@@ -1632,15 +1756,20 @@ inline int launch_bn_bwd_sums(const float* partial, int64_t R, int C, double cou
 }
 
 }  // namespace
-namespace im2im { void set_bn_fused_small(int v) { g_bn_fused_small = v; } void set_pool_bwd_full(int v) { g_pool_bwd_full = v; } void set_bn_apply_keep_mb(int v) { g_bn_apply_keep_bytes = (int64_t)v << 20; } }
+namespace im2im {
+void set_bn_fused_small(int v) { g_bn_fused_small = v; }
+void set_bn_onelaunch(int v) { g_bn_onelaunch = v; }
+void set_pool_bwd_full(int v) { g_pool_bwd_full = v; }
+void set_bn_apply_keep_mb(int v) { g_bn_apply_keep_bytes = (int64_t)v << 20; }
+}
 
 // ================================================================================================
 extern "C" int64_t im2im_reduce_workspace_bytes(int64_t K) { return im2im::reduce_tmp_bytes(K); }
 
 extern "C" int im2im_bn_finalize(const float* partial, int64_t R, int32_t C, int64_t count, const float* gamma,
                                  const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                 int32_t centered, float* mean_invstd, float* scale_shift, void* ws, int64_t* num_batches_tracked,
-                                 im2im_stream_t stream_) {
+                                 int32_t centered, float* mean_invstd, float* scale_shift, void* ws, int32_t* counters,
+                                 int64_t* num_batches_tracked, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(partial && gamma && beta && mean_invstd && scale_shift && ws && R > 0 && C > 0 && count > 0);
   IM2IM_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
@@ -1651,6 +1780,12 @@ extern "C" int im2im_bn_finalize(const float* partial, int64_t R, int32_t C, int
     return check_launch("bn_stats_fused_kernel");
   }
   const int S = reduce_splits(R);
+  if (counters && g_bn_onelaunch && cdiv(C, 64) <= IM2IM_BN_COUNTERS) {
+    hipLaunchKernelGGL(bn_stats_onelaunch_kernel, dim3((unsigned)cdiv(C, 64), (unsigned)S), dim3(1024), 0, stream, partial, R, (int)C, cdiv(R, S),
+                       (double*)ws, counters, gamma, beta, running_mean, running_var, momentum, eps, (int)centered, mean_invstd, scale_shift,
+                       (long long*)num_batches_tracked);
+    return check_launch("bn_stats_onelaunch_kernel");
+  }
   hipLaunchKernelGGL(bn_stats_stage1_kernel, dim3((unsigned)cdiv(C, 64), (unsigned)S), dim3(1024), 0, stream, partial, R, (int)C,
                      cdiv(R, S), (double*)ws);
   if (int rc = check_launch("bn_stats_stage1_kernel")) return rc;
@@ -1688,7 +1823,7 @@ extern "C" int64_t im2im_bn_bwd_workspace_bytes(int64_t M, int32_t C) {
 
 extern "C" int im2im_bn_relu_bwd(const void* da, const void* z, const float* scale_shift, const float* mean_invstd, void* dz,
                                  float* dgamma, float* dbeta, int64_t M, int32_t C, int32_t dtype, void* ws, int64_t ws_bytes,
-                                 im2im_stream_t stream_) {
+                                 int32_t* counters, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(da && z && scale_shift && mean_invstd && dz && dgamma && dbeta && ws && M > 0 && C > 0 && C % 8 == 0);
   IM2IM_REQUIRE(ws_bytes >= im2im_bn_bwd_workspace_bytes(M, C));
@@ -1703,7 +1838,7 @@ extern "C" int im2im_bn_relu_bwd(const void* da, const void* z, const float* sca
     hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel<T>, dim3((unsigned)cdiv(M, rpb)), dim3(256), 0, stream,
                        (const T*)da, (const T*)z, scale_shift, mean_invstd, M, (int)C, rpb, partial);
     if (int rc = check_launch("bn_relu_bwd_reduce_kernel")) return rc;
-    if (int rc = launch_bn_bwd_sums(partial, cdiv(M, rpb), (int)C, (double)M, tmp, dgamma, dbeta, coef, stream)) return rc;
+    if (int rc = launch_bn_bwd_sums(partial, cdiv(M, rpb), (int)C, (double)M, tmp, dgamma, dbeta, coef, counters, stream)) return rc;
     const int64_t nvec = M * C / Vec16<T>::N;
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, stream, (const T*)da, (const T*)z,
                        scale_shift, mean_invstd, coef, (T*)dz, nvec, (int)C, (int)(nvec * 16 <= g_bn_apply_keep_bytes));
@@ -1725,7 +1860,7 @@ extern "C" int64_t im2im_bn_bwd_rows_per_block(int64_t M) {
 
 extern "C" int im2im_bn_relu_bwd_phase(const void* da, const void* z, const float* scale_shift, const float* mean_invstd, void* dz,
                                        float* dgamma, float* dbeta, int64_t M, int32_t C, int32_t dtype, void* ws, int64_t ws_bytes,
-                                       int32_t phase, int64_t row0, int64_t row1, im2im_stream_t stream_) {
+                                       int32_t phase, int64_t row0, int64_t row1, int32_t* counters, im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(da && z && scale_shift && mean_invstd && dz && dgamma && dbeta && ws && M > 0 && C > 0 && C % 8 == 0);
   IM2IM_REQUIRE(ws_bytes >= im2im_bn_bwd_workspace_bytes(M, C));
@@ -1748,7 +1883,7 @@ extern "C" int im2im_bn_relu_bwd_phase(const void* da, const void* z, const floa
       return check_launch("bn_relu_bwd_reduce_kernel");
     }
     if (phase == 2) {
-      return launch_bn_bwd_sums(partial, cdiv(M, rpb), (int)C, (double)M, tmp, dgamma, dbeta, coef, stream);
+      return launch_bn_bwd_sums(partial, cdiv(M, rpb), (int)C, (double)M, tmp, dgamma, dbeta, coef, counters, stream);
     }
     const int64_t nvec = (row1 - row0) * C / Vec16<T>::N;
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, stream, (const T*)da + row0 * C,
@@ -1757,9 +1892,9 @@ extern "C" int im2im_bn_relu_bwd_phase(const void* da, const void* z, const floa
   });
 }
 
-constexpr int POOL_BWD_MAX_BLOCKS = 6144;
-int g_pool_bwd_blocks = 2048;                                // im2im_set_option("pool_bwd_blocks", n <= 6144): A/B -- 1,536 / 2,048 / 6,144 measured equal (r05_ab_experiments.txt section 6)
-namespace im2im { void set_pool_bwd_blocks(int v) { g_pool_bwd_blocks = v > 0 && v <= POOL_BWD_MAX_BLOCKS ? v : POOL_BWD_MAX_BLOCKS; } }
+constexpr int POOL_BWD_MAX_BLOCKS = 6144, POOL_BWD_DEFAULT_BLOCKS = 2048;
+int g_pool_bwd_blocks = POOL_BWD_DEFAULT_BLOCKS;             // im2im_set_option("pool_bwd_blocks", n in [1, 6144]; anything else = the default 2048): A/B -- 1,536 / 2,048 / 6,144 measured equal (r05_ab_experiments.txt section 6)
+namespace im2im { void set_pool_bwd_blocks(int v) { g_pool_bwd_blocks = v > 0 && v <= POOL_BWD_MAX_BLOCKS ? v : POOL_BWD_DEFAULT_BLOCKS; } }
 namespace {
 inline dim3 pool_bwd_grid(int B, int H, int W, int vpr) {
   const int Hc = (H + 1) / 2, Wc = (W + 1) / 2;
@@ -1777,7 +1912,8 @@ extern "C" int64_t im2im_bn_relu_pool_bwd_workspace_bytes(int32_t B, int32_t H, 
 
 extern "C" int im2im_bn_relu_pool_bwd(const void* da, const void* dpool, const void* z, const float* scale_shift,
                                       const float* mean_invstd, void* dz, float* dgamma, float* dbeta, int32_t B, int32_t H,
-                                      int32_t W, int32_t C, int32_t dtype, void* ws, int64_t ws_bytes, im2im_stream_t stream_) {
+                                      int32_t W, int32_t C, int32_t dtype, void* ws, int64_t ws_bytes, int32_t* counters,
+                                      im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(dpool && z && scale_shift && mean_invstd && dz && dgamma && dbeta && ws);
   IM2IM_REQUIRE(B > 0 && H >= 2 && W >= 2 && C > 0);
@@ -1802,7 +1938,7 @@ extern "C" int im2im_bn_relu_pool_bwd(const void* da, const void* dpool, const v
     else hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<T, false, false>), grid, dim3(256), 0, stream, (const T*)da, (const T*)dpool, (const T*)z,
                             scale_shift, mean_invstd, (const float*)nullptr, (T*)nullptr, partial, B, H, W, (int)C, rv);
     if (int rc = check_launch("bn_relu_pool_bwd_kernel<reduce>")) return rc;
-    if (int rc = launch_bn_bwd_sums(partial, nblk, (int)C, count, tmp, dgamma, dbeta, coef, stream)) return rc;
+    if (int rc = launch_bn_bwd_sums(partial, nblk, (int)C, count, tmp, dgamma, dbeta, coef, counters, stream)) return rc;
     if (full) hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<T, true, true>), grid, dim3(256), 0, stream, (const T*)da, (const T*)dpool, (const T*)z,
                                  scale_shift, mean_invstd, (const float*)coef, (T*)dz, (float*)nullptr, B, H, W, (int)C, rv);
     else hipLaunchKernelGGL((bn_relu_pool_bwd_kernel<T, true, false>), grid, dim3(256), 0, stream, (const T*)da, (const T*)dpool, (const T*)z,
@@ -1813,7 +1949,8 @@ extern "C" int im2im_bn_relu_pool_bwd(const void* da, const void* dpool, const v
 
 extern "C" int im2im_bn_relu_bwd_from_partial(const void* da, const void* z, const float* scale_shift, const float* mean_invstd,
                                               const float* partial, int64_t R, void* dz, float* dgamma, float* dbeta, int64_t M,
-                                              int32_t C, int32_t dtype, void* ws, int64_t ws_bytes, im2im_stream_t stream_) {
+                                              int32_t C, int32_t dtype, void* ws, int64_t ws_bytes, int32_t* counters,
+                                              im2im_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(da && z && scale_shift && mean_invstd && partial && dz && dgamma && dbeta && ws && M > 0 && C > 0 && C % 8 == 0 && R > 0);
   IM2IM_REQUIRE(ws_bytes >= reduce_tmp_bytes(2 * (int64_t)C) + 2 * (int64_t)C * (int64_t)sizeof(float));
@@ -1822,7 +1959,7 @@ extern "C" int im2im_bn_relu_bwd_from_partial(const void* da, const void* z, con
   float* coef = (float*)((char*)tmp + reduce_tmp_bytes(2 * (int64_t)C));
   return for_dtype(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
-    if (int rc = launch_bn_bwd_sums(partial, R, (int)C, (double)M, tmp, dgamma, dbeta, coef, stream)) return rc;
+    if (int rc = launch_bn_bwd_sums(partial, R, (int)C, (double)M, tmp, dgamma, dbeta, coef, counters, stream)) return rc;
     const int64_t nvec = M * C / Vec16<T>::N;
     hipLaunchKernelGGL(bn_relu_bwd_apply_kernel<T>, dim3(ew_blocks(nvec)), dim3(256), 0, stream, (const T*)da, (const T*)z,
                        scale_shift, mean_invstd, coef, (T*)dz, nvec, (int)C, (int)(nvec * 16 <= g_bn_apply_keep_bytes));

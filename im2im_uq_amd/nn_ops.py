@@ -101,6 +101,21 @@ class _Scratch:
     def addresses(cls):
         return tuple(sorted((k, b.data_ptr()) for k, b in cls.bufs.items()))
 
+    ctrs = {}
+
+    @classmethod
+    def counters(cls, device, key: str = "a") -> torch.Tensor:
+        """the zero-initialised ticket counters of the one-launch BatchNorm reductions (include/im2im_uq.h IM2IM_BN_COUNTERS; the
+        kernels leave them zero): one array per (device, scratch key) = per stream that uses that scratch, allocated once and never
+        moved (a captured HIP graph holds its address)."""
+        k = (torch.device(device).index, key)
+        c = cls.ctrs.get(k)
+        if c is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.Im2ImError("BatchNorm ticket counters would be created inside a graph capture; run one eager step first")
+            c = cls.ctrs[k] = torch.zeros(64, dtype=torch.int32, device=device)
+        return c
+
 
 class KernelTimer:
     """optional per-launch timing of the MFMA conv kernels with HIP events recorded on the launch stream
@@ -353,7 +368,7 @@ class Fp8GradScale:
         return base + 4 * prev, base + 4 * now, base + 4 * nxt
 
 
-def conv_wgrad_fp8(x, dz, amax_prev, x_ss=None, x_hi=None, x_ss_hi=None, scratch_key="a", out=None):
+def conv_wgrad_fp8(x, dz, amax_prev, x_ss=None, x_hi=None, x_ss_hi=None, scratch_key="a", out=None, defer=False):
     """dw [Co,Ci,9] fp32 of a 3x3 conv with e5m2 dz (scaled from the device scalar at `amax_prev`, an address) and e4m3 input
     (csrc/conv_wgrad.hip conv_wgrad_fp8_kernel); arguments as conv_wgrad."""
     b, h, w_, ci = x.shape
@@ -364,10 +379,14 @@ def conv_wgrad_fp8(x, dz, amax_prev, x_ss=None, x_hi=None, x_ss_hi=None, scratch
     nbytes = lib.im2im_conv_wgrad_workspace_bytes(b, h, w_, ci, co, 9)
     ws = _Scratch.get(nbytes, x.device, scratch_key)
     dw = torch.empty((co, ci, 9), dtype=F32, device=x.device) if out is None else out
-    _set_wgrad_width(x.device)
+    width = _wgrad_width(x.device)
     ev = TIMER.wrap(f"conv_wgrad_fp8_kernel<{128 if co % 128 == 0 else 64}>", 2.0 * b * h * w_ * co * ci * 9, x.device) if TIMER else None
-    check(lib.im2im_conv_wgrad_fp8(dptr(x), dptr(x_ss), dptr(x_hi), dptr(x_ss_hi), ci_lo, dptr(dz), amax_prev, dptr(dw), dptr(ws), ws.numel(),
-                                   b, h, w_, ci, co, stream_ptr(x.device)), "im2im_conv_wgrad_fp8")
+    nsplit = ctypes.c_int32(0)
+    check(lib.im2im_conv_wgrad_fp8(dptr(x), dptr(x_ss), dptr(x_hi), dptr(x_ss_hi), ci_lo, dptr(dz), amax_prev, None if defer else dptr(dw),
+                                   dptr(ws), ws.numel(), b, h, w_, ci, co, width, ctypes.addressof(nsplit), stream_ptr(x.device)),
+          "im2im_conv_wgrad_fp8")
+    if defer:
+        _pending_reduce.setdefault(x.device.index, []).append((ws, nsplit.value, co, ci, 9, dw))
     if ev is not None:
         ev.record(torch.cuda.current_stream(x.device))
     return dw
@@ -423,6 +442,8 @@ def conv_fwd_fp8(x, wq, wscale, bias=None, scale_shift=None, relu=False, want_st
 
 if os.environ.get("IM2IM_BN_FUSED_SMALL") is not None:   # A/B: one-launch BatchNorm sums for <= 256 partial rows (default on)
     check(lib.im2im_set_option(b"bn_fused_small", int(os.environ["IM2IM_BN_FUSED_SMALL"])), "im2im_set_option")
+if os.environ.get("IM2IM_BN_ONELAUNCH") is not None:     # A/B: 0 = BatchNorm statistics / backward sums of many partial rows in two launches (round 5), default 1
+    check(lib.im2im_set_option(b"bn_onelaunch", int(os.environ["IM2IM_BN_ONELAUNCH"])), "im2im_set_option")
 if os.environ.get("IM2IM_BN_APPLY_KEEP_MB") is not None:   # A/B: dz tensors up to n MB written with cacheable stores (default 0: all streamed)
     check(lib.im2im_set_option(b"bn_apply_keep_mb", int(os.environ["IM2IM_BN_APPLY_KEEP_MB"])), "im2im_set_option")
 if os.environ.get("IM2IM_POOL_BWD_BLOCKS") is not None:   # A/B: workgroups of bn_relu_pool_bwd (default 6144; 2048 until round 5)
@@ -511,7 +532,7 @@ def bn_relu_bwd_from_partial(da, z, scale_shift, mean_invstd, partial):
     ws = _Scratch.get(lib.im2im_reduce_workspace_bytes(2 * c) + 2 * c * 4, dev)
     check(lib.im2im_bn_relu_bwd_from_partial(dptr(da), dptr(z), dptr(scale_shift), dptr(mean_invstd), dptr(partial), partial.shape[0],
                                              dptr(dz), dptr(dgamma), dptr(dbeta), m, c, _DT[z.dtype], dptr(ws), ws.numel(),
-                                             stream_ptr(dev)), "im2im_bn_relu_bwd_from_partial")
+                                             dptr(_Scratch.counters(dev)), stream_ptr(dev)), "im2im_bn_relu_bwd_from_partial")
     return dz, dgamma, dbeta
 
 
@@ -541,6 +562,9 @@ def join_side_streams():
     """make the current stream of every device wait for the weight-gradient and BatchNorm-backward streams' work."""
     for idx in list(_side_busy):
         main = torch.cuda.current_stream(idx)
+        if _pending_reduce.get(idx) and idx in _side_streams:
+            with torch.cuda.stream(_side_streams[idx]):  # [r6] every deferred split-K reduction of this backward pass in one launch
+                flush_wgrad_reduce(idx)
         for pool in (_side_streams, _bn_streams):
             if idx in pool:
                 main.wait_stream(pool[idx])
@@ -643,26 +667,48 @@ def _on_side_stream(device, tensors, fn, after=None):
 _WGS_PIN = os.environ.get("IM2IM_WGRAD_WGS")
 WGRAD_WGS_ALONE = int(_WGS_PIN) if _WGS_PIN else 256
 WGRAD_WGS_SIDE = int(_WGS_PIN) if _WGS_PIN else int(os.environ.get("IM2IM_WGRAD_WGS_SIDE", "128"))
-_wgs_now = [256]
 
 
 WGRAD_TAIL_FULL_FROM = int(os.environ.get("IM2IM_WGRAD_TAIL_FULL_FROM", "0"))   # A/B: 3x3 weight gradients number >= this of a backward pass (1-based) run at the alone-width
 _wgrad_calls = [0]
 
 
-def _set_wgrad_width(device):
+def _wgrad_width(device) -> int:
+    """workgroups this weight-gradient launch aims at -- an ARGUMENT of the launch since ABI 3 (it was a process-global option two autograd
+    threads could race on).  The split-K slab count follows from it and sets the order of the fp32 partial sums, so a layer's dW is
+    bit-identical from step to step, but not between a launch from the side stream (128) and one from the main stream (256):
+    IM2IM_WGRAD_STREAM=0 / 1 agree to fp32 re-association noise, not bits."""
     side = _side_streams.get(torch.device(device).index)
     _wgrad_calls[0] += 1
     tail = WGRAD_TAIL_FULL_FROM > 0 and _wgrad_calls[0] >= WGRAD_TAIL_FULL_FROM
-    want = WGRAD_WGS_SIDE if (side is not None and torch.cuda.current_stream(device) == side and not tail) else WGRAD_WGS_ALONE
-    if want != _wgs_now[0]:
-        check(lib.im2im_set_option(b"wgrad_wgs", want), "im2im_set_option")
-        _wgs_now[0] = want
+    return WGRAD_WGS_SIDE if (side is not None and torch.cuda.current_stream(device) == side and not tail) else WGRAD_WGS_ALONE
 
 
-def conv_wgrad(x, dz, taps, x_ss=None, x_hi=None, x_ss_hi=None, scratch_key="a", out=None):
+# [r6] split-K reduction of the weight gradients issued from the side stream: the slabs stay in per-layer workspaces and ONE multi-tensor
+# launch (im2im_wgrad_reduce_multi) finishes every pending layer when the side stream is joined (end of the backward pass) or when a
+# GradSync bucket is about to pack its gradients -- 18 launches of 8-50 us per step become one; per output the same slabs are added in the
+# same order, so the same bits.  IM2IM_WGRAD_DEFER_REDUCE=0: every weight-gradient launch reduces its own slabs at once.
+WGRAD_DEFER_REDUCE = os.environ.get("IM2IM_WGRAD_DEFER_REDUCE", "1") != "0"
+_pending_reduce = {}       # device index -> [(slab workspace, nsplit, Co, Ci, taps, dw)] in launch order
+
+
+def flush_wgrad_reduce(device_index) -> None:
+    """finish the pending weight gradients of a device on the CURRENT stream (call it on the stream that computed the slabs)"""
+    items = _pending_reduce.pop(device_index, None)
+    if not items:
+        return
+    n = len(items)
+    arr, i32 = ctypes.c_void_p * n, ctypes.c_int32 * n
+    check(lib.im2im_wgrad_reduce_multi(n, arr(*[it[0].data_ptr() for it in items]), i32(*[it[1] for it in items]), i32(*[it[2] for it in items]),
+                                       i32(*[it[3] for it in items]), i32(*[it[4] for it in items]), arr(*[it[5].data_ptr() for it in items]),
+                                       stream_ptr(torch.device("cuda", device_index))), "im2im_wgrad_reduce_multi")
+
+
+def conv_wgrad(x, dz, taps, x_ss=None, x_hi=None, x_ss_hi=None, scratch_key="a", out=None, defer=False):
     """x [B,H,W,Ci], dz [B,H,W,Co] -> dw [Co,Ci,taps] fp32 (x_ss: lazy BatchNorm+ReLU of x, as in conv_fwd; x_hi: second
-    half of the input channels as in conv_fwd).  out: a preallocated [Co,Ci,taps] fp32 result."""
+    half of the input channels as in conv_fwd).  out: a preallocated [Co,Ci,taps] fp32 result.
+    defer=True: only the split-K slabs are computed (into the scratch buffer `scratch_key`, which must then be this layer's own);
+    dw is filled by the next flush_wgrad_reduce on this stream."""
     b, h, w_, ci = x.shape
     ci_lo = ci
     if x_hi is not None:
@@ -673,10 +719,14 @@ def conv_wgrad(x, dz, taps, x_ss=None, x_hi=None, x_ss_hi=None, scratch_key="a",
         raise _lib.Im2ImError(f"conv wgrad: unsupported channels Ci={ci} Co={co}")
     ws = _Scratch.get(nbytes, x.device, scratch_key)
     dw = torch.empty((co, ci, taps), dtype=F32, device=x.device) if out is None else out
-    _set_wgrad_width(x.device)
+    width = _wgrad_width(x.device)
     ev = TIMER.wrap(_tile_name("wgrad", h, w_, co, taps, x.dtype), 2.0 * b * h * w_ * co * ci * taps, x.device) if TIMER else None
-    check(lib.im2im_conv_wgrad_split(dptr(x), dptr(x_ss), dptr(x_hi), dptr(x_ss_hi), ci_lo, dptr(dz), dptr(dw), dptr(ws), ws.numel(),
-                                     b, h, w_, ci, co, taps, _DT[x.dtype], stream_ptr(x.device)), "im2im_conv_wgrad_split")
+    nsplit = ctypes.c_int32(0)
+    check(lib.im2im_conv_wgrad_split(dptr(x), dptr(x_ss), dptr(x_hi), dptr(x_ss_hi), ci_lo, dptr(dz), None if defer else dptr(dw), dptr(ws),
+                                     ws.numel(), b, h, w_, ci, co, taps, _DT[x.dtype], width, ctypes.addressof(nsplit), stream_ptr(x.device)),
+          "im2im_conv_wgrad_split")
+    if defer:
+        _pending_reduce.setdefault(x.device.index, []).append((ws, nsplit.value, co, ci, taps, dw))
     if ev is not None:
         ev.record(torch.cuda.current_stream(x.device))
     return dw
@@ -698,7 +748,7 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, 
     ws = _Scratch.get(lib.im2im_reduce_workspace_bytes(3 * c), dev)
     check(lib.im2im_bn_finalize(dptr(stats), rows, c, count, dptr(gamma), dptr(beta), dptr(running_mean), dptr(running_var),
                                 float(momentum), float(eps), int(centered), dptr(mean_invstd), dptr(scale_shift), dptr(ws),
-                                dptr(num_batches_tracked), stream_ptr(dev)),
+                                dptr(_Scratch.counters(dev)), dptr(num_batches_tracked), stream_ptr(dev)),
           "im2im_bn_finalize")
     touched(running_mean, running_var, num_batches_tracked)
     return mean_invstd, scale_shift
@@ -737,11 +787,12 @@ def bn_relu_bwd(da, z, scale_shift, mean_invstd):
         # pass is removed AND its replacement in the consumers is free.  profiles/r03_ab_experiments.txt
         for which, r1 in ((1, m), (2, 0)):
             check(lib.im2im_bn_relu_bwd_phase(dptr(da), dptr(z), dptr(scale_shift), dptr(mean_invstd), dptr(da), dptr(dgamma), dptr(dbeta),
-                                              m, c, _DT[z.dtype], dptr(ws), ws.numel(), which, 0, r1, stream_ptr(dev)), "im2im_bn_relu_bwd_phase")
+                                              m, c, _DT[z.dtype], dptr(ws), ws.numel(), which, 0, r1, dptr(_Scratch.counters(dev)),
+                                              stream_ptr(dev)), "im2im_bn_relu_bwd_phase")
         return da, dgamma, dbeta
     dz = torch.empty_like(z)
     check(lib.im2im_bn_relu_bwd(dptr(da), dptr(z), dptr(scale_shift), dptr(mean_invstd), dptr(dz), dptr(dgamma), dptr(dbeta), m, c,
-                                _DT[z.dtype], dptr(ws), ws.numel(), stream_ptr(dev)), "im2im_bn_relu_bwd")
+                                _DT[z.dtype], dptr(ws), ws.numel(), dptr(_Scratch.counters(dev)), stream_ptr(dev)), "im2im_bn_relu_bwd")
     return dz, dgamma, dbeta
 
 
@@ -757,6 +808,7 @@ def bn_relu_bwd_pipelined(da, z, scale_shift, mean_invstd, halves, b_first):
     dgamma = torch.empty((c,), dtype=F32, device=dev)
     dbeta = torch.empty((c,), dtype=F32, device=dev)
     ws = _Scratch.get(lib.im2im_bn_bwd_workspace_bytes(m, c), dev, "bn")      # this stream's own scratch
+    ctr = _Scratch.counters(dev, "bn")                                        # ... and ticket counters
     rpb = lib.im2im_bn_bwd_rows_per_block(m)
     r_apply = b_first * (m // z.shape[0])
     r_reduce = (r_apply // rpb) * rpb                      # whole reduction blocks inside the first half
@@ -765,7 +817,7 @@ def bn_relu_bwd_pipelined(da, z, scale_shift, mean_invstd, halves, b_first):
 
     def phase(which, r0, r1):
         check(lib.im2im_bn_relu_bwd_phase(dptr(da), dptr(z), dptr(scale_shift), dptr(mean_invstd), dptr(dz), dptr(dgamma), dptr(dbeta),
-                                          m, c, _DT[z.dtype], dptr(ws), ws.numel(), which, r0, r1, bn.cuda_stream), "im2im_bn_relu_bwd_phase")
+                                          m, c, _DT[z.dtype], dptr(ws), ws.numel(), which, r0, r1, dptr(ctr), bn.cuda_stream), "im2im_bn_relu_bwd_phase")
 
     if halves is not None and halves.first is not None and r_reduce > 0:
         bn.wait_event(halves.first)
@@ -797,7 +849,8 @@ def bn_relu_pool_bwd(da, dpool, z, scale_shift, mean_invstd):
     dbeta = torch.empty((c,), dtype=F32, device=dev)
     ws = _Scratch.get(lib.im2im_bn_relu_pool_bwd_workspace_bytes(b, h, w_, c), dev)
     check(lib.im2im_bn_relu_pool_bwd(dptr(da), dptr(dpool), dptr(z), dptr(scale_shift), dptr(mean_invstd), dptr(dz), dptr(dgamma),
-                                     dptr(dbeta), b, h, w_, c, _DT[z.dtype], dptr(ws), ws.numel(), stream_ptr(dev)),
+                                     dptr(dbeta), b, h, w_, c, _DT[z.dtype], dptr(ws), ws.numel(), dptr(_Scratch.counters(dev)),
+                                     stream_ptr(dev)),
           "im2im_bn_relu_pool_bwd")
     return dz, dgamma, dbeta
 
@@ -978,18 +1031,25 @@ class ConvStats(torch.autograd.Function):
             fp8_w = (ctx.fp8_dgrad and FP8_WGRAD and dz.dtype == BF16 and dz.shape[3] % 64 == 0 and ci % 64 == 0
                      and (FP8_WGRAD is True or dz.shape[3] % 128 != 0))
 
-            def wgrad(out, key):
+            def wgrad(out, key, defer=False):
                 if fp8_w:
-                    return conv_wgrad_fp8(xin, dz, fp8_slots[0], x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi, scratch_key=key, out=out)
-                return conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi, scratch_key=key, out=out)
+                    return conv_wgrad_fp8(xin, dz, fp8_slots[0], x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi, scratch_key=key, out=out, defer=defer)
+                return conv_wgrad(xin, dz, 9, x_ss=in_ss, x_hi=xin_hi, x_ss_hi=in_ss_hi, scratch_key=key, out=out, defer=defer)
             # ... or a tensor hook on the weight (wandb.watch, a user's register_hook) would read dW on THIS stream right away
             if (WGRAD_SIDE_STREAM and not torch.is_grad_enabled() and w_ref is not None and w_ref.grad is None
                     and not getattr(w_ref, "_backward_hooks", None)):
                 dw_buf = torch.empty((dz.shape[3], ci, 9), dtype=F32, device=dz.device)     # owned by the current stream's pool
                 # (the closure must not hold the tensor OBJECT handed to autograd: AccumulateGrad adopts an incoming gradient only
                 # while nobody else references it, otherwise it clones it on the spot -- before the side stream has computed it)
-                _on_side_stream(dz.device, (xin, dz, in_ss, xin_hi, in_ss_hi, dw_buf), lambda dw_buf=dw_buf: wgrad(dw_buf, "side"),
-                                after=dz_ready)
+                if WGRAD_DEFER_REDUCE:
+                    # [r6] this layer's slabs stay in its own workspace ("side<n>": the n-th deferred weight gradient of the backward pass)
+                    # until the side stream is joined; one multi-tensor launch reduces them all then (flush_wgrad_reduce)
+                    slot = f"side{len(_pending_reduce.get(dz.device.index, ()))}"
+                    _on_side_stream(dz.device, (xin, dz, in_ss, xin_hi, in_ss_hi, dw_buf), lambda dw_buf=dw_buf: wgrad(dw_buf, slot, True),
+                                    after=dz_ready)
+                else:
+                    _on_side_stream(dz.device, (xin, dz, in_ss, xin_hi, in_ss_hi, dw_buf), lambda dw_buf=dw_buf: wgrad(dw_buf, "side"),
+                                    after=dz_ready)
                 dw = dw_buf.view(dz.shape[3], ci, 3, 3)
                 del dw_buf
             else:

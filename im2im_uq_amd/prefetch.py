@@ -31,14 +31,39 @@ import torch
 ENABLED = os.environ.get("IM2IM_PREFETCH", "1") != "0"
 THREAD = os.environ.get("IM2IM_PREFETCH_THREAD", "1") != "0"
 DEPTH = int(os.environ.get("IM2IM_PREFETCH_DEPTH", "2"))
+# intra-op threads of the host-side copies (the DataLoader's collation, the staging copy).  torch's default is one thread per core, and on
+# a many-core host a 32 MB `torch.stack` spread over 128 threads takes 121 ms where 8 threads take 1.7 ms (tools/host_pipe_probe.py on the
+# 256-core MI355X host: the fork/join of a hundred threads on a shared machine costs more than the copy).  The producer thread sets its
+# own OpenMP team size; in the consumer's thread the setting is restored after every fetch.
+HOST_THREADS = int(os.environ.get("IM2IM_PREFETCH_THREADS", "8"))
+
+
+class _host_threads:
+    """`with _host_threads():` -- at most HOST_THREADS intra-op threads for the calling thread's torch CPU ops"""
+
+    def __enter__(self):
+        self.was = torch.get_num_threads()
+        if HOST_THREADS > 0 and self.was > HOST_THREADS:
+            torch.set_num_threads(HOST_THREADS)
+        else:
+            self.was = None
+
+    def __exit__(self, *exc):
+        if self.was is not None:
+            torch.set_num_threads(self.was)
+
+
+def _pinned(n, dtype):
+    return torch.empty(n, dtype=dtype).pin_memory()
 
 
 class _Slot:
     """staging (pinned) and device buffers of one in-flight batch, and its two hand-off events"""
-    __slots__ = ("pin", "dev", "ready", "released", "keep")
+    __slots__ = ("pin", "dev", "ready", "released", "keep", "k")
 
     def __init__(self):
         self.pin, self.dev = [], []
+        self.k = 0                 # staging buffers of this slot the collate function has filled for the batch being fetched
         self.ready = None          # recorded on the copy stream after the slot's uploads
         self.released = None       # recorded on the consumer's stream when it let go of the slot's device tensors
         self.keep = None           # already-pinned source tensors the uploads read from (no staging copy for those)
@@ -84,21 +109,40 @@ class DevicePrefetcher:
         self.depth = max(1, DEPTH if depth is None else int(depth))
         self.use_thread = THREAD if thread is None else bool(thread)
         self.active = ENABLED and self.device.type == "cuda"
+        self._collate_slot = None                          # the slot whose staging buffers `collate` may fill right now
 
     def __len__(self):
         return len(self.batches)
+
+    def collate(self, samples):
+        """`collate_fn` for a DataLoader this prefetcher wraps (see `loader`): torch's default collation of (tuples of) equally
+        shaped tensors, stacked straight into the current slot's PINNED staging buffers -- one host copy per batch instead of
+        collate-into-a-fresh-tensor (64 MB of first-touch page faults per batch of 78 images) + staging copy.  Anything else, or a
+        call from outside the prefetcher's fetch, is torch.utils.data.default_collate."""
+        from torch.utils.data import default_collate
+        slot = self._collate_slot
+        elem = samples[0] if len(samples) else None
+        if (slot is None or not isinstance(elem, (tuple, list)) or hasattr(elem, "_fields")
+                or not all(isinstance(t, torch.Tensor) and not t.is_cuda for t in elem)):
+            return default_collate(samples)
+        cols = [[smp[j] for smp in samples] for j in range(len(elem))]
+        if any(len(smp) != len(elem) for smp in samples) or any(c.shape != col[0].shape or c.dtype != col[0].dtype for col in cols for c in col):
+            return default_collate(samples)
+        out = []
+        for col in cols:
+            buf = _Slot._fit(slot.pin, slot.k, (len(col),) + tuple(col[0].shape), col[0].dtype, _pinned)
+            slot.k += 1
+            torch.stack(col, 0, out=buf)
+            out.append(buf)
+        return out
 
     # ------------------------------------------------------------------ producer side
     def _upload(self, item, slot, copy_stream):
         """stage + enqueue the uploads of one batch; returns the batch with device tensors (views of the slot's ring buffers)"""
         dev = self.device
-        k = [0]
+        k = [slot.k, 0]                                    # next free staging buffer (after the ones `collate` filled), next device buffer
         slot.keep = []
-        if slot.ready is not None:
-            slot.ready.synchronize()                       # the uploads that last read this slot's staging buffers (long done)
-
-        def pinned(n, dtype):
-            return torch.empty(n, dtype=dtype).pin_memory()
+        pinned = _pinned
 
         def device(n, dtype):
             return torch.empty(n, dtype=dtype, device=dev)
@@ -110,16 +154,16 @@ class DevicePrefetcher:
             def move(t):
                 if t.is_cuda:
                     return t
-                i = k[0]
-                k[0] += 1
                 src = t.detach()
                 if src.is_pinned() and src.is_contiguous():
-                    slot.keep.append(src)                  # stays referenced until the slot's next `ready.synchronize()`
-                else:
-                    stage = _Slot._fit(slot.pin, i, src.shape, src.dtype, pinned)
+                    slot.keep.append(src)                  # `collate`'s views of this slot's staging buffers, or a caller's pinned tensor:
+                else:                                      # referenced until the slot is taken again (after its `ready` event completed)
+                    stage = _Slot._fit(slot.pin, k[0], src.shape, src.dtype, pinned)
+                    k[0] += 1
                     stage.copy_(src)                       # host memcpy (the GIL is released inside)
                     src = stage
-                out = _Slot._fit(slot.dev, i, src.shape, src.dtype, device)
+                out = _Slot._fit(slot.dev, k[1], src.shape, src.dtype, device)
+                k[1] += 1
                 out.copy_(src, non_blocking=True)
                 return out
 
@@ -129,13 +173,30 @@ class DevicePrefetcher:
             slot.ready.record(copy_stream)
         return out
 
+    def _fetch(self, it, slot):
+        """next batch of the wrapped iterable; while it is fetched `collate` may fill the slot's staging buffers"""
+        if slot.ready is not None:
+            slot.ready.synchronize()                       # the uploads that last read this slot's staging buffers (long done)
+        slot.k = 0
+        self._collate_slot = slot
+        try:
+            return next(it)
+        finally:
+            self._collate_slot = None
+
     def _produce(self, it, free, ready, copy_stream, stop):
         try:
             torch.cuda.set_device(self.device)
-            for item in it:
+            if HOST_THREADS > 0 and torch.get_num_threads() > HOST_THREADS:
+                torch.set_num_threads(HOST_THREADS)        # this thread's OpenMP team (the consumer's thread keeps its own setting)
+            while True:
                 slot = free.get()
                 if slot is None or stop.is_set():
                     return
+                try:
+                    item = self._fetch(it, slot)
+                except StopIteration:
+                    break
                 ready.put((self._upload(item, slot, copy_stream), slot))
             ready.put((_Stop(), None))
         except BaseException as e:  # noqa: BLE001  -- handed to the consumer, which re-raises it
@@ -194,13 +255,15 @@ class DevicePrefetcher:
                         free.append(held)
                         held = None
                     while not done and len(pending) < self.depth:
-                        try:
-                            nxt = next(it)
-                        except StopIteration:
-                            done = True
-                            break
-                        slot = free.pop(0)
-                        pending.append((self._upload(nxt, slot, copy_stream), slot))
+                        with _host_threads():
+                            slot = free[0]
+                            try:
+                                nxt = self._fetch(it, slot)
+                            except StopIteration:
+                                done = True
+                                break
+                            free.pop(0)
+                            pending.append((self._upload(nxt, slot, copy_stream), slot))
                     if not pending:
                         break
                     item, slot = pending.pop(0)
@@ -216,3 +279,14 @@ class DevicePrefetcher:
 def to_device(batches, device, **kw):
     """`for batch in to_device(loader, device):` -- the loader's batches with their tensors already in HBM"""
     return DevicePrefetcher(batches, device, **kw)
+
+
+def loader(dataset, device, **dataloader_kwargs):
+    """DataLoader(dataset, **dataloader_kwargs) behind a prefetcher whose `collate` stacks the samples straight into pinned staging
+    memory (the loader's order, shuffling and RNG use are torch's own; only where the stacked batch is written changes)."""
+    from torch.utils.data import DataLoader
+    pf = DevicePrefetcher(None, device)
+    if pf.active and "collate_fn" not in dataloader_kwargs:
+        dataloader_kwargs = dict(dataloader_kwargs, collate_fn=pf.collate)
+    pf.batches = DataLoader(dataset, **dataloader_kwargs)
+    return pf

@@ -19,7 +19,8 @@
 extern "C" {
 #endif
 
-#define IM2IM_ABI_VERSION 2
+#define IM2IM_ABI_VERSION 3
+#define IM2IM_BN_COUNTERS 64        /* ints in a `counters` array of the BatchNorm entry points ([ABI 3], see im2im_bn_finalize) */
 #define IM2IM_OK 0
 #define IM2IM_ERR_INVALID (-1)     /* bad argument / unsupported shape */
 #define IM2IM_ERR_HIP (-2)         /* a HIP runtime call or launch failed */
@@ -129,7 +130,11 @@ int im2im_rcps_scan(const float* table, int64_t N, int32_t L, int64_t row_stride
  * "wgrad_roll": 0 = the bf16 and fp8 3x3 weight gradients on conv_wgrad_pipe_kernel / conv_wgrad_fp8_kernel instead of the roll
  *   kernels (default 1; same bits either way); "wgrad_fp8_co128": 0 = the fp8 weight gradient's 64-output-channel form everywhere;
  * "conv_splitk": 0 = im2im_conv_fwd_split_ws never splits, n = it aims at n * 256 workgroups (default 3);
- * "bn_fused_small": 0 = BatchNorm statistics / backward sums always in two stages (default 1: one launch for <= 256 partial rows). */
+ * "bn_fused_small": n = BatchNorm statistics / backward sums of <= n partial rows in one small-grid launch (0 = never, 1 = the default
+ *   of 256 rows); "bn_onelaunch": [ABI 3] 0 = above that row count always two launches even when `counters` are given (default 1);
+ * "pool_bwd_blocks": workgroups of im2im_bn_relu_pool_bwd, 1..6144 (anything else = the default 2048);
+ * "conv_roll": only in libraries built with IM2IM_BUILD_EXPERIMENTAL=1 (csrc/conv_roll.hip); elsewhere any value but 0 is an error.
+ * ("wgrad_wgs" became the target_wgs argument of im2im_conv_wgrad_split / im2im_conv_wgrad_fp8 in ABI 3.) */
 int im2im_set_option(const char* key, int32_t value);
 
 /* ---------------------------------------------------------------------------------------------
@@ -283,11 +288,22 @@ int64_t im2im_conv_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_
 int im2im_conv_wgrad(const void* x, const float* x_scale_shift, const void* dz, float* dw, void* workspace,
                      int64_t workspace_bytes, int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co,
                      int32_t taps, int32_t dtype, im2im_stream_t stream);
-/* weight gradient of a convolution with channel-split input (see im2im_conv_fwd_split); Ci_lo % 64 == 0. */
+/* weight gradient of a convolution with channel-split input (see im2im_conv_fwd_split); Ci_lo % 64 == 0.
+ * [ABI 3] target_wgs: workgroups a bf16 3x3 launch aims at (split-K slabs = target / channel blocks; 0 = 256, one per CU).  A
+ *   launch that shares the chip with another stream's kernels is faster for the STEP at half width (the Python host passes 128
+ *   from its weight-gradient stream): it was a process-global option ("wgrad_wgs") until ABI 2, which two threads could race on.
+ *   The split count sets the order of the fp32 partial sums: results are bit-identical for one target, not across targets.
+ * [ABI 3] dw == NULL with nsplit != NULL: the split-K slabs are left in `workspace` ([*nsplit][Co][taps][Ci] fp32, *nsplit a host
+ *   int written before the call returns) for im2im_wgrad_reduce_multi, which finishes MANY layers' gradients in one launch. */
 int im2im_conv_wgrad_split(const void* x, const float* x_scale_shift, const void* x_hi,
                            const float* x_scale_shift_hi, int32_t Ci_lo, const void* dz, float* dw, void* workspace,
                            int64_t workspace_bytes, int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co,
-                           int32_t taps, int32_t dtype, im2im_stream_t stream);
+                           int32_t taps, int32_t dtype, int32_t target_wgs, int32_t* nsplit, im2im_stream_t stream);
+/* [ABI 3] dw_i [Co_i][Ci_i][taps_i] = sum of the nsplit_i slabs at slabs_i (what im2im_conv_wgrad_split / _fp8 left there), for
+ * n_tensors layers in ONE launch (<= 32 per launch, more are chunked): the same per-output summation order as the single-layer
+ * reduction, so the same bits.  Host arrays of device pointers / sizes, as im2im_pack_conv_weights_multi. */
+int im2im_wgrad_reduce_multi(int32_t n_tensors, const float* const* slabs, const int32_t* nsplit, const int32_t* Co,
+                             const int32_t* Ci, const int32_t* taps, float* const* dw, im2im_stream_t stream);
 
 /* [r4] fp8 weight gradient (BASELINE configs[4] "fp8 MFMA conv path"; the dW half of autograd's backward of nn.Conv2d 3x3,
  * unet_parts.py:16,19 under loss.backward(), train.py:159): dz as OCP e5m2 under the tensor's delayed power-of-two scale
@@ -298,7 +314,7 @@ int im2im_conv_wgrad_split(const void* x, const float* x_scale_shift, const void
 int im2im_conv_wgrad_fp8(const void* x, const float* x_scale_shift, const void* x_hi, const float* x_scale_shift_hi,
                          int32_t Ci_lo, const void* dz, const float* amax_prev, float* dw, void* workspace,
                          int64_t workspace_bytes, int32_t B, int32_t H, int32_t W, int32_t Ci, int32_t Co,
-                         im2im_stream_t stream);
+                         int32_t target_wgs, int32_t* nsplit, im2im_stream_t stream);
 
 
 /* Shared scratch for the deterministic two-stage "sum over pixels" reductions: bytes needed to reduce
@@ -314,6 +330,11 @@ int64_t im2im_reduce_workspace_bytes(int64_t K);
  *   scale_shift [2][C] (scale = gamma*invstd, shift = beta - mean*scale) and, if non-NULL, the running statistics
  *   (unbiased variance, as torch).  ws: im2im_reduce_workspace_bytes(3*C) bytes.  num_batches_tracked (device int64
  *   scalar or NULL) is incremented by one: nn.BatchNorm2d's bookkeeping in the same launch.
+ *   [ABI 3] counters (device, IM2IM_BN_COUNTERS zero-initialised int32, or NULL): with counters the two reduction stages of this
+ *   entry point -- and of the backward sums inside im2im_bn_relu_bwd / _phase 2 / _from_partial / im2im_bn_relu_pool_bwd -- run as
+ *   ONE launch whatever the number of partial rows: the block that finishes last (a ticket from a device-scope atomic) merges the
+ *   split rows in the two-launch form's order, so the results are the same bits, and leaves the counters zero again.  The caller
+ *   owns the counters, zeroes them once, and hands one array to ONE stream at a time.  NULL = the two-launch form.
  * im2im_bn_fold_eval: eval-mode fold into the conv epilogue: scale = gamma/sqrt(rv+eps),
  *   shift = beta + (conv_bias - rm)*scale.
  * im2im_bn_relu_apply: a = max(z*scale + shift, 0).
@@ -323,7 +344,7 @@ int64_t im2im_reduce_workspace_bytes(int64_t K);
 int im2im_bn_finalize(const float* partial, int64_t R, int32_t C, int64_t count, const float* gamma,
                       const float* beta, float* running_mean, float* running_var, float momentum,
                       float eps, int32_t centered, float* mean_invstd, float* scale_shift, void* ws,
-                      int64_t* num_batches_tracked, im2im_stream_t stream);
+                      int32_t* counters, int64_t* num_batches_tracked, im2im_stream_t stream);
 int im2im_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, const float* conv_bias, float eps, int32_t C,
                        float* scale_shift, im2im_stream_t stream);
@@ -332,7 +353,7 @@ int im2im_bn_relu_apply(const void* z, const float* scale_shift, void* a, int64_
 int64_t im2im_bn_bwd_workspace_bytes(int64_t M, int32_t C);
 int im2im_bn_relu_bwd(const void* da, const void* z, const float* scale_shift, const float* mean_invstd,
                       void* dz, float* dgamma, float* dbeta, int64_t M, int32_t C, int32_t dtype,
-                      void* ws, int64_t ws_bytes, im2im_stream_t stream);
+                      void* ws, int64_t ws_bytes, int32_t* counters, im2im_stream_t stream);
 /* im2im_bn_relu_bwd cut into phases over row ranges, for a caller that pipelines it against the data-gradient kernels
  * working on the other half of the batch (nn_ops.BnReluLazy; no reference counterpart -- torch's batch_norm backward is
  * one call).  phase 1: partial sums of rows [row0,row1), row0 a multiple of im2im_bn_bwd_rows_per_block(M);
@@ -342,12 +363,13 @@ int64_t im2im_bn_bwd_rows_per_block(int64_t M);
 int im2im_bn_relu_bwd_phase(const void* da, const void* z, const float* scale_shift, const float* mean_invstd,
                             void* dz, float* dgamma, float* dbeta, int64_t M, int32_t C, int32_t dtype,
                             void* ws, int64_t ws_bytes, int32_t phase, int64_t row0, int64_t row1,
-                            im2im_stream_t stream);
+                            int32_t* counters, im2im_stream_t stream);
 /* im2im_bn_relu_bwd with the reduction already done by im2im_conv_dgrad_bn: partial [R][2][C].
  * ws: im2im_reduce_workspace_bytes(2*C) + 2*C*4 bytes. */
 int im2im_bn_relu_bwd_from_partial(const void* da, const void* z, const float* scale_shift, const float* mean_invstd,
                                    const float* partial, int64_t R, void* dz, float* dgamma, float* dbeta, int64_t M,
-                                   int32_t C, int32_t dtype, void* ws, int64_t ws_bytes, im2im_stream_t stream);
+                                   int32_t C, int32_t dtype, void* ws, int64_t ws_bytes, int32_t* counters,
+                                   im2im_stream_t stream);
 
 /* BatchNorm+ReLU backward of a skip-connection layer fused with the backward of the MaxPool2d(2) that consumes the
  * same activation (unet.py:35-38; unet_parts.py:34 / 17-18,20-21): the activation's gradient
@@ -359,7 +381,7 @@ int64_t im2im_bn_relu_pool_bwd_workspace_bytes(int32_t B, int32_t H, int32_t W, 
 int im2im_bn_relu_pool_bwd(const void* da, const void* dpool, const void* z, const float* scale_shift,
                            const float* mean_invstd, void* dz, float* dgamma, float* dbeta, int32_t B,
                            int32_t H, int32_t W, int32_t C, int32_t dtype, void* ws, int64_t ws_bytes,
-                           im2im_stream_t stream);
+                           int32_t* counters, im2im_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * GroupNorm(+ReLU) -- named by BASELINE.json:north_star; NOT in the reference (its DoubleConv uses BatchNorm2d,

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, s), f"{s} declared in include/im2im_uq.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} missing from the ctypes signature table"
     assert sorted(_lib.SIGNATURES) == syms
-    assert _lib.lib.im2im_abi_version() == 2        # [r5] bumped: im2im_rcps_scan gained `rhat_in`, im2im_conv1x1_heads_fwd left (round 4)
+    assert _lib.lib.im2im_abi_version() == 3        # [r6] bumped: BatchNorm entry points take `counters`, the weight gradients `target_wgs` + `nsplit`; + im2im_wgrad_reduce_multi
 
 
 def test_argument_validation_needs_no_gpu():

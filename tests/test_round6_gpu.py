@@ -256,7 +256,18 @@ def test_eight_ranks_run_the_references_split_of_batch_78_and_of_the_3474_image_
     from im2im_uq_amd.core.calibration.calibrate_model import calibrate_model
     from im2im_uq_amd.core.scripts.eval import eval_set_metrics, get_loss_table
     from im2im_uq_amd.core.scripts.train import GlobalBatchSampler
-    mp.spawn(_worker8, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
+    # Eight processes time-sharing ONE GPU (production is one process per GPU) now and then lose a rank to a queue abort of the
+    # runtime -- HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION in a random rank at a random point, in about one run of three on the test boxes,
+    # equally with the prefetcher, the one-launch BatchNorm sums and the deferred weight-gradient reduction switched off (the
+    # two-rank tests of rounds 2-5 never showed it).  A run that loses a rank that way proves nothing either way and is repeated.
+    for attempt in range(4):
+        try:
+            mp.spawn(_worker8, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
+            break
+        except mp.ProcessExitedException as e:
+            if attempt == 3 or getattr(e, "signal_name", None) != "SIGABRT":
+                raise
+            time.sleep(2.0)
     g = [torch.load(tmp_path / f"grad_{r}.pt", weights_only=False) for r in range(8)]
     shares = [r["share"] for r in g]
     assert [hi - lo for lo, hi in shares] == [10, 10, 10, 10, 10, 10, 9, 9]                  # the reference's DataParallel scatter of 78
@@ -316,9 +327,12 @@ def test_bench_gpus_8_over_gloo_on_one_gpu():
     env["IM2IM_DIST_BACKEND"] = "gloo"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--size", "64",
            "--calib-images", "16", "--no-roofline", "--no-cpu-baseline"]
-    t0 = time.time()
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
-    dt = time.time() - t0
+    for attempt in range(3):                                 # (a rank lost to the shared-GPU queue abort described above: run again)
+        t0 = time.time()
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+        dt = time.time() - t0
+        if r.returncode == 0 or "ILLEGAL_INSTRUCTION" not in r.stderr:
+            break
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
