@@ -1735,7 +1735,12 @@ int64_t g_bn_apply_keep_bytes = 0;                           // im2im_set_option
 int g_pool_bwd_full = 1;                                     // im2im_set_option("pool_bwd_full", 0 / 1): branch-free bn_relu_pool_bwd for even extents
 int g_bn_fused_small = 1;                                    // im2im_set_option("bn_fused_small", 0 / 1 / n): off / up to BN_FUSED_MAX_ROWS partial rows / up to n rows
 inline int64_t bn_fused_rows() { return g_bn_fused_small <= 0 ? -1 : g_bn_fused_small == 1 ? BN_FUSED_MAX_ROWS : g_bn_fused_small; }
-int g_bn_onelaunch = 1;                                      // im2im_set_option("bn_onelaunch", 0 / 1): [r6] statistics / backward sums of > bn_fused_small rows in one launch (needs `counters`)
+// im2im_set_option("bn_onelaunch", 0 / 1): [r6] statistics / backward sums of > bn_fused_small rows in ONE launch (needs `counters`).  DEFAULT OFF:
+// measured slower than the two launches it replaces -- batch 78: 39.7 vs 38.3 ms per step, batch 10: 7.07 vs 6.42 (three alternating
+// rounds on one box, profiles/r06_ab_experiments.txt section 1).  The ticket needs a device-scope release / acquire, which on this
+// eight-XCD part writes back and invalidates the XCD's whole L2 (buffer_wbl2 / buffer_inv sc1) in every one of the ~64 blocks of each
+// of the 34 launches: the conv kernels around them (and the weight gradients running beside them) lose their L2 contents.
+int g_bn_onelaunch = 0;
 inline int launch_bn_bwd_sums(const float* partial, int64_t R, int C, double count, double* tmp, float* dgamma, float* dbeta,
                               float* coef, int32_t* counters, hipStream_t stream) {
   if (R <= bn_fused_rows()) {

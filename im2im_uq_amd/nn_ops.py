@@ -442,7 +442,7 @@ def conv_fwd_fp8(x, wq, wscale, bias=None, scale_shift=None, relu=False, want_st
 
 if os.environ.get("IM2IM_BN_FUSED_SMALL") is not None:   # A/B: one-launch BatchNorm sums for <= 256 partial rows (default on)
     check(lib.im2im_set_option(b"bn_fused_small", int(os.environ["IM2IM_BN_FUSED_SMALL"])), "im2im_set_option")
-if os.environ.get("IM2IM_BN_ONELAUNCH") is not None:     # A/B: 0 = BatchNorm statistics / backward sums of many partial rows in two launches (round 5), default 1
+if os.environ.get("IM2IM_BN_ONELAUNCH") is not None:     # A/B: 1 = BatchNorm statistics / backward sums of many partial rows in ONE launch (default 0: two, measured faster)
     check(lib.im2im_set_option(b"bn_onelaunch", int(os.environ["IM2IM_BN_ONELAUNCH"])), "im2im_set_option")
 if os.environ.get("IM2IM_BN_APPLY_KEEP_MB") is not None:   # A/B: dz tensors up to n MB written with cacheable stores (default 0: all streamed)
     check(lib.im2im_set_option(b"bn_apply_keep_mb", int(os.environ["IM2IM_BN_APPLY_KEEP_MB"])), "im2im_set_option")
@@ -687,8 +687,10 @@ def _wgrad_width(device) -> int:
 # [r6] split-K reduction of the weight gradients issued from the side stream: the slabs stay in per-layer workspaces and ONE multi-tensor
 # launch (im2im_wgrad_reduce_multi) finishes every pending layer when the side stream is joined (end of the backward pass) or when a
 # GradSync bucket is about to pack its gradients -- 18 launches of 8-50 us per step become one; per output the same slabs are added in the
-# same order, so the same bits.  IM2IM_WGRAD_DEFER_REDUCE=0: every weight-gradient launch reduces its own slabs at once.
-WGRAD_DEFER_REDUCE = os.environ.get("IM2IM_WGRAD_DEFER_REDUCE", "1") != "0"
+# same order, so the same bits.  DEFAULT OFF (IM2IM_WGRAD_DEFER_REDUCE=1 enables): measured neutral at batch 78 (38.27 vs 38.28 ms) and
+# 0.05 ms slower at batch 10 (6.46 vs 6.42) -- the 18 small launches sit on the side stream in the shadow of the main stream's kernels, and
+# one late launch that reads every layer's slabs from HBM loses what the per-layer reductions found in L2 (profiles/r06_ab_experiments.txt 1).
+WGRAD_DEFER_REDUCE = os.environ.get("IM2IM_WGRAD_DEFER_REDUCE", "0") != "0"
 _pending_reduce = {}       # device index -> [(slab workspace, nsplit, Co, Ci, taps, dw)] in launch order
 
 

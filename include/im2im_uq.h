@@ -131,7 +131,8 @@ int im2im_rcps_scan(const float* table, int64_t N, int32_t L, int64_t row_stride
  *   kernels (default 1; same bits either way); "wgrad_fp8_co128": 0 = the fp8 weight gradient's 64-output-channel form everywhere;
  * "conv_splitk": 0 = im2im_conv_fwd_split_ws never splits, n = it aims at n * 256 workgroups (default 3);
  * "bn_fused_small": n = BatchNorm statistics / backward sums of <= n partial rows in one small-grid launch (0 = never, 1 = the default
- *   of 256 rows); "bn_onelaunch": [ABI 3] 0 = above that row count always two launches even when `counters` are given (default 1);
+ *   of 256 rows); "bn_onelaunch": [ABI 3] 1 = above that row count ONE launch when `counters` are given (default 0: the device-scope fence the ticket
+ *   needs flushes the XCD's L2 in every block and the step is 3-10 % slower with it, profiles/r06_ab_experiments.txt);
  * "pool_bwd_blocks": workgroups of im2im_bn_relu_pool_bwd, 1..6144 (anything else = the default 2048);
  * "conv_roll": only in libraries built with IM2IM_BUILD_EXPERIMENTAL=1 (csrc/conv_roll.hip); elsewhere any value but 0 is an error.
  * ("wgrad_wgs" became the target_wgs argument of im2im_conv_wgrad_split / im2im_conv_wgrad_fp8 in ABI 3.) */
@@ -334,7 +335,8 @@ int64_t im2im_reduce_workspace_bytes(int64_t K);
  *   entry point -- and of the backward sums inside im2im_bn_relu_bwd / _phase 2 / _from_partial / im2im_bn_relu_pool_bwd -- run as
  *   ONE launch whatever the number of partial rows: the block that finishes last (a ticket from a device-scope atomic) merges the
  *   split rows in the two-launch form's order, so the results are the same bits, and leaves the counters zero again.  The caller
- *   owns the counters, zeroes them once, and hands one array to ONE stream at a time.  NULL = the two-launch form.
+ *   owns the counters, zeroes them once, and hands one array to ONE stream at a time.  NULL = the two-launch form.  The one-launch
+ *   form is additionally gated by im2im_set_option("bn_onelaunch", 1) -- off by default, it measured slower (see there).
  * im2im_bn_fold_eval: eval-mode fold into the conv epilogue: scale = gamma/sqrt(rv+eps),
  *   shift = beta + (conv_bias - rm)*scale.
  * im2im_bn_relu_apply: a = max(z*scale + shift, 0).
