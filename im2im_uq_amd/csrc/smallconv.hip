@@ -1004,6 +1004,153 @@ __global__ __launch_bounds__(256) void smallconv_wgrad_mfma_kernel(SWArgs a) {
   }
 }
 
+// [r6] the bf16 / 32-channel form of the kernel above (the quantile heads' weight gradient: 3 planes x 32 channels, 0.365 ms at batch 78
+// against 0.12 ms of traffic) rebuilt around two findings from its instruction stream:
+//   * the small side's hi and lo bf16 halves ride in ONE MFMA: the LDS row of a halo pixel holds 16 slots (hi in 0-7, lo in 8-15), so
+//     columns 0-7 of the B fragment are the hi planes and 8-15 the lo planes; hi and lo products accumulate in separate accumulator
+//     columns and are added once at the end -- half the matrix instructions;
+//   * a wave owns half of the tile's rows (8 k-steps) and five (four) of the nine taps: 40 / 32 MFMAs per wave and tile instead of the
+//     taps alone (3/2/2/2 per wave with two MFMAs each: the first wave did 96 of the tile's 288, and every workgroup's first wave sits
+//     on the same SIMD); 80 accumulators, three workgroups per CU.  An A fragment feeds five MFMAs.
+// The two row halves are summed through LDS in a fixed order when the persistent workgroup has walked its tiles.
+constexpr size_t wgrad_rows_smem() { return (size_t)TS * TS * (32 * 2 + 16) + (size_t)HS * HS * 32 + 128; }
+template <int MODE>      // 0: wave = (row half, tap group of 5 / 4), 80 accumulators; 1: wave = taps {w, w + 4, w + 8} over all rows, 48 accumulators
+__global__ __launch_bounds__(256, MODE == 0 ? 2 : 3) void smallconv_wgrad_mfma_rows_kernel(SWArgs a) {
+  using T = bf16_t;
+  constexpr int CL = 32, N = 8;
+  constexpr int PL = CL * 2 + 16;                      // L tile pixel pitch
+  constexpr int L_BYTES = TS * TS * PL;
+  constexpr int PD = 32;                               // S tile: [halo px][8 hi slots | 8 lo slots]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsL = smem;
+  char* ldsD = smem + L_BYTES;
+  float* ldsR = reinterpret_cast<float*>(smem);        // final reduction scratch (after the loop)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int q = lane & 15;
+  const int tr_col_b = (((lane >> 4) & 1) * 16 + (q & 3) * 4) * 2;
+  const int tr_row = q >> 2;
+  constexpr int NTP = MODE == 0 ? 5 : 3;               // taps of a wave.  MODE 0: tap group tg owns taps [5 tg, 5 tg + 5) of the nine
+  const int rp = MODE == 0 ? (wave & 1) : 0, tg = MODE == 0 ? (wave >> 1) : wave;   // MODE 0: wave = (row half rp, tap group tg)
+  constexpr int ROWS = MODE == 0 ? TS / 2 : TS;        // k-steps of a wave per tile
+  f32x16 acc[NTP];
+#pragma unroll
+  for (int i = 0; i < NTP; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  constexpr int PPR = CL / N;
+  constexpr int L_ROUNDS = (TS * TS * PPR + 255) / 256;
+  constexpr int S_ROUNDS = (HS * HS * 8 + 255) / 256;
+  uint4 rl[L_ROUNDS];
+  float rs[S_ROUNDS], bs[S_ROUNDS];
+#pragma unroll
+  for (int i = 0; i < S_ROUNDS; ++i) bs[i] = 0.f;
+  const int ntiles = a.B * a.tilesY * a.tilesX;
+  auto gload = [&](int tile) {
+    int t = tile;
+    const int tx_id = t % a.tilesX; t /= a.tilesX;
+    const int ty_id = t % a.tilesY;
+    const int b = t / a.tilesY;
+    const int y0 = ty_id * TS, x0 = tx_id * TS;
+    const float* Sb = a.S + (size_t)b * a.CS * a.H * a.W;
+    const T* Lb = reinterpret_cast<const T*>(a.L) + (size_t)b * a.H * a.W * CL;
+#pragma unroll
+    for (int i = 0; i < L_ROUNDS; ++i) {
+      const int p = i * 256 + tid;
+      const int px = p / PPR, part = p % PPR;
+      const int yy = y0 + px / TS, xx = x0 + px % TS;
+      rl[i] = make_uint4(0, 0, 0, 0);
+      if (px < TS * TS && yy < a.H && xx < a.W) rl[i] = *reinterpret_cast<const uint4*>(Lb + ((size_t)yy * a.W + xx) * CL + part * N);
+    }
+#pragma unroll
+    for (int i = 0; i < S_ROUNDS; ++i) {
+      const int e = i * 256 + tid;
+      const int slot = e / (HS * HS), px = e % (HS * HS);
+      const int yy = y0 + px / HS - 1, xx = x0 + px % HS - 1;
+      rs[i] = 0.f;
+      if (slot < a.CS && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) rs[i] = Sb[((size_t)slot * a.H + yy) * a.W + xx];
+    }
+  };
+  // LDS byte offsets of this wave's taps relative to a tile row's first halo pixel (wave-uniform scalars)
+  int tap_off[NTP];
+#pragma unroll
+  for (int i = 0; i < NTP; ++i) { const int tp = MODE == 0 ? tg * NTP + i : tg + 4 * i; tap_off[i] = ((tp / 3) * HS + (tp % 3)) * PD; }
+  const int ntaps = MODE == 0 ? (tg == 0 ? NTP : 9 - NTP) : (tg == 0 ? 3 : 2);
+  const int a_off = (half * 8 + tr_row) * PL + tr_col_b, d_off = (half * 8 + tr_row) * PD + tr_col_b;
+  if ((int)blockIdx.x < ntiles) gload(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();                                   // the previous tile's readers are done
+#pragma unroll
+    for (int i = 0; i < L_ROUNDS; ++i) {
+      const int p = i * 256 + tid;
+      const int px = p / PPR, part = p % PPR;
+      if (px < TS * TS) *reinterpret_cast<uint4*>(ldsL + px * PL + part * 16) = rl[i];
+    }
+#pragma unroll
+    for (int i = 0; i < S_ROUNDS; ++i) {
+      const int e = i * 256 + tid;
+      const int slot = e / (HS * HS), px = e % (HS * HS);
+      if (slot < 8) {
+        const bf16_t hi = (bf16_t)rs[i];
+        *reinterpret_cast<bf16_t*>(ldsD + px * PD + slot * 2) = hi;
+        *reinterpret_cast<bf16_t*>(ldsD + px * PD + 16 + slot * 2) = (bf16_t)(rs[i] - (float)hi);
+        const int hy = px / HS, hx = px % HS;
+        if (hy >= 1 && hy <= TS && hx >= 1 && hx <= TS) bs[i] += rs[i];     // tile interior (zero beyond the image)
+      }
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) gload(tile + gridDim.x);
+#pragma unroll 2
+    for (int r8 = 0; r8 < ROWS; ++r8) {                 // k-step = tile row ty: the A fragment feeds this wave's taps
+      const int ty = rp * ROWS + r8;
+      const char* p0 = ldsL + ty * TS * PL + a_off;
+      const short8 fa = WgFrag::load(p0, p0 + 4 * PL);
+      const char* drow = ldsD + ty * HS * PD + d_off;
+#pragma unroll
+      for (int i = 0; i < NTP; ++i)
+        if (i < ntaps) {
+          const short8 fb = WgFrag::load(drow + tap_off[i], drow + tap_off[i] + 4 * PD);
+          acc[i] = SmallFrag<bf16_t>::mfma(fa, fb, acc[i]);
+        }
+    }
+  }
+  // hi + lo columns, then the two row halves' sums (rp = 0 first) through LDS:  red[(s*9 + tap)*CL + l]
+  __syncthreads();
+  const int K = a.CS * 9 * CL + a.CS;
+  float* out = a.partial + (size_t)blockIdx.x * K;
+#pragma unroll 1
+  for (int w = 0; w < (MODE == 0 ? 2 : 1); ++w) {
+    if (rp == w) {
+#pragma unroll
+      for (int i = 0; i < NTP; ++i) {
+        const int tp = MODE == 0 ? tg * NTP + i : tg + 4 * i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[i][r] + __shfl_down(acc[i][r], 8, 64);      // column s (hi) + column 8 + s (lo)
+          if (i < ntaps && l31 < a.CS) {
+            const int l = (r & 3) + 8 * (r >> 2) + 4 * half;
+            float* dst = ldsR + ((size_t)l31 * 9 + tp) * CL + l;
+            *dst = (w == 0) ? v : *dst + v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < a.CS * 9 * CL; i += 256) out[i] = ldsR[i];
+  __syncthreads();
+  // plane sums: element e = i*256 + tid belongs to slot e / (HS*HS); summed per slot in a fixed order
+#pragma unroll
+  for (int i = 0; i < S_ROUNDS; ++i) ldsR[i * 256 + tid] = bs[i];
+  __syncthreads();
+  if (tid < a.CS) {
+    float v = 0.f;
+    for (int e = tid * HS * HS; e < (tid + 1) * HS * HS; ++e) v += ldsR[e];
+    out[(size_t)a.CS * 9 * CL + tid] = v;
+  }
+}
+
 // tmp[S][K] -> dw with index map, dbias tail
 //   l_major != 0: dw[(l*CS + s)*9 + tap]        (first conv: weight [co=l][ci=s][tap])
 //   l_major == 0: dw[(s*CL + l)*9 + (8 - tap)]  (heads: weight [co=s][ci=l][tap], correlation flipped)
@@ -1113,7 +1260,11 @@ extern "C" int im2im_smallconv_wgrad(const float* S, const void* L, float* dw, f
   hipStream_t stream = (hipStream_t)stream_;
   IM2IM_REQUIRE(S && L && dw && ws && B > 0 && H > 0 && W > 0 && CS >= 1 && CS <= CS_MAX);
   IM2IM_REQUIRE(ws_bytes >= im2im_smallconv_wgrad_workspace_bytes(B, H, W, CS, CL));
-  const int64_t nblk = std::min<int64_t>(im2im_smallconv_tiles(B, H, W), 2048);   // persistent blocks, one partial row each
+  // persistent blocks, one partial row each.  [r6] the heads' kernel (smallconv_wgrad_mfma_rows_kernel: 3 workgroups per CU by registers)
+  // gets exactly one resident round of them (IM2IM_SWG_BLOCKS overrides: A/B)
+  static const int swg_blocks = [] { const char* e = getenv("IM2IM_SWG_BLOCKS"); return e ? atoi(e) : 768; }();
+  const bool rows_kernel = CS >= 3 && dtype == IM2IM_BF16 && CL == 32 && !(valu_mask() & (4 | 32));
+  const int64_t nblk = std::min<int64_t>(im2im_smallconv_tiles(B, H, W), rows_kernel ? std::max(1, std::min(swg_blocks, 2048)) : 2048);
   const int64_t K = (int64_t)CS * 9 * CL + CS;
   float* partial = (float*)ws;
   double* tmp = (double*)((char*)ws + nblk * K * sizeof(float));
@@ -1121,7 +1272,14 @@ extern "C" int im2im_smallconv_wgrad(const float* S, const void* L, float* dw, f
   return for_dtype_cl(dtype, CL, [&](auto* tag, auto cl) {
     using T = std::remove_pointer_t<decltype(tag)>;
     constexpr int CLv = decltype(cl)::value;
-    if (CS >= 3 && !(valu_mask() & 4)) {               // matrix cores pay from 3 planes up (CS = 1: 0.83 vs 0.48 ms, the VALU kernel wins)
+    if (rows_kernel && std::is_same<T, bf16_t>::value && CLv == 32) {
+      // [r6] the heads' weight gradient: rows split over the waves, hi + lo halves in one MFMA (IM2IM_SMALLCONV_VALU bit 32 = the round-2 kernel)
+      constexpr size_t smem = wgrad_rows_smem();
+      static_assert(smem >= (size_t)((HS * HS * 8 + 255) / 256) * 256 * sizeof(float) && smem >= (size_t)CS_MAX * 9 * 32 * sizeof(float), "reduction scratch fits");
+      if (valu_mask() & 64) hipLaunchKernelGGL(smallconv_wgrad_mfma_rows_kernel<0>, dim3((unsigned)nblk), dim3(256), smem, stream, a);
+      else hipLaunchKernelGGL(smallconv_wgrad_mfma_rows_kernel<1>, dim3((unsigned)nblk), dim3(256), smem, stream, a);
+    }
+    else if (CS >= 3 && !(valu_mask() & 4)) {          // matrix cores pay from 3 planes up (CS = 1: 0.83 vs 0.48 ms, the VALU kernel wins)
       constexpr size_t smem = wgrad_mfma_smem<T, CLv>();
       static_assert(smem >= (size_t)((HS * HS * 8 + 255) / 256) * 256 * sizeof(float), "bias scratch fits");
       auto kern = smallconv_wgrad_mfma_kernel<T, CLv>;
