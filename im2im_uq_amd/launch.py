@@ -85,12 +85,18 @@ def init_distributed(expected_world: int | None = None):
     # the short timeout above is for the rendezvous and the world check only.  Training has rank-0-only phases (a checkpoint on a slow
     # filesystem, validation images, a wandb upload) during which the other ranks wait in a collective: those get the backends' usual
     # patience back (nccl's default is 10 min, gloo's 30; IM2IM_COLLECTIVE_TIMEOUT_S overrides)
+    relax_collective_timeout()
+    return dist, rank, world, dev, backend
+
+
+def relax_collective_timeout() -> bool:
+    """the default process group's collective timeout -> IM2IM_COLLECTIVE_TIMEOUT_S (default 30 min); False when this torch cannot"""
     try:
         from torch.distributed.distributed_c10d import _set_pg_timeout
         _set_pg_timeout(datetime.timedelta(seconds=int(os.environ.get("IM2IM_COLLECTIVE_TIMEOUT_S", "1800"))))
+        return True
     except Exception:  # noqa: BLE001  (a torch without the hook keeps the rendezvous timeout)
-        pass
-    return dist, rank, world, dev, backend
+        return False
 
 
 def device_identity(dev, rank: int) -> dict:

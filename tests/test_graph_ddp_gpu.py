@@ -108,6 +108,8 @@ def _worker_rccl(rank, world, port, tmpdir):
         from im2im_uq_amd import launch                     # [r5] the start-up check of `bench.py --gpus N`, on RCCL: identities gathered,
         ids = launch.verify_world(dist, rank, world, torch.device(DEV), "nccl")      # ranks counted by an all-reduce, devices distinct
         assert len(ids) == 1 and ids[0]["local_device_index"] == 0 and launch.distinct_devices(ids) == 1
+        assert launch.relax_collective_timeout()           # [r6] what init_distributed does after the world check: works on the RCCL group
+        dist.all_reduce(t)                                 # ... and collectives go on working after it
         torch.cuda.synchronize()
         ver = ".".join(str(v) for v in torch.cuda.nccl.version())
         torch.save({"le": le, "ls": ls, "lg": lg, "se": se, "ss": ss, "sg": sg, "rccl": ver, "sum": float(t.sum()),
@@ -125,7 +127,7 @@ def test_one_rank_rccl_eager_and_captured_collectives(tmp_path):
     assert torch.equal(d["le"], d["ls"]) and torch.equal(d["le"], d["lg"])
     for k in d["se"]:
         assert torch.equal(d["se"][k], d["ss"][k]) and torch.equal(d["se"][k], d["sg"][k]), k
-    assert d["sum"] == float(1 << 20) and d["steps"] == [9]
+    assert d["sum"] == float(1 << 20) and d["steps"] == [9]            # (one rank: the all-reduce leaves the ones as they are)
     print("RCCL", d["rccl"])
 
 
