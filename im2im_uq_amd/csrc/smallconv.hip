@@ -1004,15 +1004,16 @@ __global__ __launch_bounds__(256) void smallconv_wgrad_mfma_kernel(SWArgs a) {
   }
 }
 
-// [r6] the bf16 / 32-channel form of the kernel above (the quantile heads' weight gradient: 3 planes x 32 channels, 0.365 ms at batch 78
-// against 0.12 ms of traffic) rebuilt around two findings from its instruction stream:
+// [r6] the bf16 / 32-channel form of the kernel above (the quantile heads' weight gradient: 3 planes x 32 channels, 0.397 ms at batch 78
+// against 0.12 ms of traffic):
 //   * the small side's hi and lo bf16 halves ride in ONE MFMA: the LDS row of a halo pixel holds 16 slots (hi in 0-7, lo in 8-15), so
 //     columns 0-7 of the B fragment are the hi planes and 8-15 the lo planes; hi and lo products accumulate in separate accumulator
-//     columns and are added once at the end -- half the matrix instructions;
-//   * a wave owns half of the tile's rows (8 k-steps) and five (four) of the nine taps: 40 / 32 MFMAs per wave and tile instead of the
-//     taps alone (3/2/2/2 per wave with two MFMAs each: the first wave did 96 of the tile's 288, and every workgroup's first wave sits
-//     on the same SIMD); 80 accumulators, three workgroups per CU.  An A fragment feeds five MFMAs.
-// The two row halves are summed through LDS in a fixed order when the persistent workgroup has walked its tiles.
+//     columns and are added once at the end -- half the matrix instructions of the kernel above;
+//   * the host launches exactly one resident round of persistent workgroups (768 = 3 per CU by registers) instead of 2,048.
+// MODE 1 (default): a wave owns the taps {w, w + 4, w + 8} over all 16 rows, as above (48 accumulators, 3 workgroups per CU): 0.293 ms at
+// batch 78, 0.058 at batch 10.  MODE 0 (IM2IM_SMALLCONV_VALU bit 64): a wave owns half of the tile's rows and five (four) of the nine
+// taps -- balanced MFMA counts (40 / 32 per wave instead of 48 / 32 / 32 / 32), but 80 accumulators leave two workgroups per CU and the two
+// row halves have to be summed through LDS: 0.327 / 0.115 ms.  The matrix instructions were not the limit (profiles/r06_ab_experiments.txt 4).
 constexpr size_t wgrad_rows_smem() { return (size_t)TS * TS * (32 * 2 + 16) + (size_t)HS * HS * 32 + 128; }
 template <int MODE>      // 0: wave = (row half, tap group of 5 / 4), 80 accumulators; 1: wave = taps {w, w + 4, w + 8} over all rows, 48 accumulators
 __global__ __launch_bounds__(256, MODE == 0 ? 2 : 3) void smallconv_wgrad_mfma_rows_kernel(SWArgs a) {
