@@ -398,7 +398,9 @@ __global__ __launch_bounds__(256) void smallconv_l2s_mfma_kernel(L2SArgs a) {
   int aoff[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) aoff[j] = (4 * wave + 2 * j + l31 / TS) * HROWB + (l31 % TS) * PF;
-  const int boff = (l31 & 7) * PW;
+  // [r6] bf16: B-fragment columns 0-7 are the hi rows of the weights and columns 8-15 the lo rows (rows 8-15 of ldsW): hi and lo products
+  // come out of ONE MFMA in separate accumulator columns and are added in the epilogue (was: two MFMAs per k-step and row tile)
+  const int boff = (IS_BF16 ? (l31 & 15) : (l31 & 7)) * PW;
   if ((int)blockIdx.x < ntiles) gload(blockIdx.x);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int t = tile;
@@ -431,21 +433,19 @@ __global__ __launch_bounds__(256) void smallconv_l2s_mfma_kernel(L2SArgs a) {
         for (int j = 0; j < 2; ++j) {
           const auto fa = SmallFrag<T>::load(ldsF + aoff[j] + toff + koff);
           acc[j] = SmallFrag<T>::mfma(fa, fb, acc[j]);
-          if constexpr (IS_BF16) {
-            const auto fl = SmallFrag<T>::load(ldsW + 8 * PW + boff + tap * CL * SZ + koff);
-            acc[j] = SmallFrag<T>::mfma(fa, fl, acc[j]);
-          }
         }
       }
     }
-    if (l31 < a.CS) {
-      const float bv = a.bias ? a.bias[l31] : 0.f;
+    {
+      const float bv = (a.bias && l31 < a.CS) ? a.bias[l31] : 0.f;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int m = (q & 3) + 8 * (q >> 2) + 4 * half;              // pixel within the 32-pixel row tile
-          ldsO[l31 * 256 + (4 * wave + 2 * j) * TS + m] = acc[j][q] + bv;
+          float v = acc[j][q];
+          if constexpr (IS_BF16) v += __shfl_down(acc[j][q], 8, 64);    // plane s: hi column s + lo column 8 + s
+          if (l31 < a.CS) ldsO[l31 * 256 + (4 * wave + 2 * j) * TS + m] = v + bv;
         }
     }
     __syncthreads();                                    // results staged; every wave is done reading the halo tile
@@ -1245,7 +1245,8 @@ extern "C" int im2im_smallconv_l2s_fwd(const void* in, const float* w, const flo
     }
     const int64_t ntiles = (int64_t)B * a.tilesY * a.tilesX;
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / smem));
-    hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(ntiles, 256 * per_cu)), dim3(256), smem, stream, a);
+    static const int l2s_blocks = [] { const char* e = getenv("IM2IM_L2S_BLOCKS"); return e ? atoi(e) : 0; }();     // A/B: persistent workgroups
+    hipLaunchKernelGGL(kern, dim3((unsigned)std::min<int64_t>(ntiles, l2s_blocks > 0 ? l2s_blocks : 256 * per_cu)), dim3(256), smem, stream, a);
     return check_launch("smallconv_l2s_mfma_kernel");
   });
 }
