@@ -191,7 +191,9 @@ def test_fp8_training_tracks_fp32_training_then_calibrates_alike():
     # absolute bounds: the bf16 test's (10 % / 12 % / 20 % / 15 %) widened for e4m3 / e5m2 operands
     assert d8["loss"] < 0.20
     assert d8["mid"] < 0.16 and d8["lo"] < 0.25 and d8["hi"] < 0.20
-    assert 0.70 < size["fp8"] / size["fp32"] < 1.45
+    # [r6] relative to the yardstick (see tests/test_train_parity_gpu.py: two fp32 runs alone can sit at a ratio of 0.75), plus a sanity range
+    assert abs(np.log(size["fp8"] / size["fp32"])) <= 2.5 * abs(np.log(size["fp32'"] / size["fp32"])) + np.log(1.3), size
+    assert 0.5 < size["fp8"] / size["fp32"] < 2.0
     # and relative to the yardstick: no further from fp32 than 2.5x what a second fp32 run is, plus a margin
     assert d8["loss"] <= 2.5 * dself["loss"] + 0.10
     assert d8["lhat"] <= 2.5 * dself["lhat"] + 4.0
