@@ -843,7 +843,7 @@ def main():
 
     # ---------------------------------------------------------------- calibration leg
     want_host = default_run and world == 1
-    calib = calib_leg(wl, max(1, args.steps // 5), calib_images=args.calib_images, host_images=16 * conf["batch"] if want_host else 0)
+    calib = calib_leg(wl, max(1, args.steps // 5), calib_images=args.calib_images, host_images=(args.calib_images or conf["calib_total"]) if want_host else 0)
     wl.release()
     _phase("calibration leg done")
     host_ds = None
