@@ -22,6 +22,11 @@ in HBM.
     batch of 78/8 (what 8-GPU strong scaling runs); `fastmri_pipeline`: the k-space -> image transform.
   * `strong` (N > 1): the reference's GLOBAL batch of 78 split over the ranks (10,10,10,10,10,10,9,9 on 8), beside the
     weak-scaling `value` (78 per GPU).
+  * `host_dataset` (N = 1 default run) [r6]: `train_net` and `calibrate_model` themselves on a pageable HOST TensorDataset -- the
+    reference's data contract (train.py:147-149, calibrate_model.py:118-123) -- with the pinned prefetcher and with the reference's
+    in-line uploads, beside the HBM-resident figures; `value` itself stays HBM-resident as SURVEY 8(d) prescribes.
+  * the scalars the north-star targets hang on are repeated at the top level and at the end of the line (`batch10_ms_per_step`,
+    `temca1024_imgs_per_s`, `bsbcm512_fp8_over_bf16`, `calib_imgs_per_s`, `calib_forward_frac`, `host_*`).
 `--scaling weak` (default) keeps per-GPU work fixed as N grows; `--scaling strong` makes the split batch the headline.
 One JSON line is printed by rank 0.
 """
