@@ -297,6 +297,19 @@ def run_validation(net, val_loader, val_dataset, device, global_step, epoch, con
     net.train()
 
 
+_graph_streams = {}
+
+
+def _graph_stream():
+    """the stream every GraphedStep of this process runs and captures on.  torch hands out side streams from a pool of 32 per device,
+    round-robin: a sweep that builds a GraphedStep per run would eventually get the hardware queue of the weight-gradient stream."""
+    idx = torch.cuda.current_device()
+    st = _graph_streams.get(idx)
+    if st is None:
+        st = _graph_streams[idx] = torch.cuda.Stream(device=idx)
+    return st
+
+
 class GraphedStep:
     """One training step of a fixed batch shape as ONE HIP graph (the launch-bound regime: a 32x32 depth-2 step is ~150 kernel
     launches of a few microseconds each, 2.9 ms of host enqueue for 1.2 ms of GPU work; replaying the captured graph costs the
@@ -324,7 +337,7 @@ class GraphedStep:
     def __init__(self, net, optimizer, sync=None):
         self.net, self.opt, self.sync = net, optimizer, sync
         self.params = [p for p in net.parameters() if p.requires_grad]
-        self.stream = torch.cuda.Stream()
+        self.stream = _graph_stream()                      # ONE per device and process (torch's stream pool wraps around after 32)
         self.graph = None
         self.key = None
         self.done = 0

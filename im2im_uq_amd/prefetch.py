@@ -53,6 +53,22 @@ class _host_threads:
             torch.set_num_threads(self.was)
 
 
+_copy_streams = {}
+
+
+def _copy_stream(device):
+    """ONE copy stream per device for the life of the process.  torch hands out side streams from a pool of 32 per device, round-robin:
+    a stream created per loader (one per epoch, one per validation pass) would, after a few dozen epochs, be the SAME hardware queue as
+    the weight-gradient stream or as GraphedStep's capture stream -- uploads would queue behind kernels, or be recorded into a capture."""
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    st = _copy_streams.get(idx)
+    if st is None:
+        st = _copy_streams[idx] = torch.cuda.Stream(device=idx)
+    return st
+
+
 def _pinned(n, dtype):
     return torch.empty(n, dtype=dtype).pin_memory()
 
@@ -208,7 +224,7 @@ class DevicePrefetcher:
             yield from self.batches
             return
         dev = self.device
-        copy_stream = torch.cuda.Stream(device=dev)
+        copy_stream = _copy_stream(dev)
         slots = [_Slot() for _ in range(self.depth + 2)]
         held = None
         it = iter(self.batches)                            # in the consumer's thread: a DataLoader draws its base seed here
