@@ -38,6 +38,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # as im2im_uq_amd/__init__.py does (this script imports torch first): kernel arguments in device memory
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
