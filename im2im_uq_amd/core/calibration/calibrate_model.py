@@ -24,7 +24,7 @@ from torch.utils.data import DataLoader, Subset, TensorDataset
 
 from .. import _pkg  # noqa: F401
 from ... import hip_ops
-from ...prefetch import loader as prefetch_loader
+from ...prefetch import loader as prefetch_loader, sequential_slices, to_device
 from ..models.add_uncertainty import calibration_repr, sets_form
 from .bounds import HB_mu_plus  # noqa: F401  (re-exported: the reference's module exposes it here too)
 
@@ -242,7 +242,9 @@ def collect_outputs(model, dataset, config, device, shard=True):
     else:
         # [r6] a host dataset: the reference's loader (:118) behind the two-deep pinned prefetcher -- batch k+1 is collated, staged and
         # uploaded on a copy stream while batch k's forward runs (im2im_uq_amd/prefetch.py)
-        loader = prefetch_loader(dataset, device, num_workers=0, batch_size=config['batch_size'])
+        # (a plain host TensorDataset walked in order: the loader's batches are contiguous row ranges -- sliced, not collated)
+        seq = sequential_slices(dataset, config['batch_size'])
+        loader = to_device(seq, device) if seq is not None else prefetch_loader(dataset, device, num_workers=0, batch_size=config['batch_size'])
     for batch in loader:
         out = calibration_repr(model, model(batch[0].to(device=device, dtype=torch.float32)))
         if outputs is None:

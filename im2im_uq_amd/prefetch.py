@@ -297,6 +297,24 @@ def to_device(batches, device, **kw):
     return DevicePrefetcher(batches, device, **kw)
 
 
+def sequential_slices(dataset, batch_size):
+    """the batches `DataLoader(dataset, batch_size=batch_size, shuffle=False)` would yield, as views -- for a plain host TensorDataset
+    (or a Subset of one over a contiguous range): batch k IS rows [k*bs, (k+1)*bs) of every tensor, so the 2 x 78 per-sample index
+    operations and the stack of the default collation shrink to one slice per tensor (and one copy into the pinned ring).  None for
+    anything else (a Dataset subclass may override __getitem__)."""
+    from torch.utils.data import Subset, TensorDataset
+    lo, hi = 0, None
+    ds = dataset
+    if type(ds) is Subset and isinstance(ds.indices, range) and ds.indices.step == 1:
+        lo, hi, ds = ds.indices.start, ds.indices.stop, ds.dataset
+    if type(ds) is not TensorDataset or not ds.tensors or any(t.is_cuda for t in ds.tensors):
+        return None
+    n = ds.tensors[0].shape[0]
+    hi = n if hi is None else min(hi, n)
+    bs = int(batch_size)
+    return ([t[s:min(s + bs, hi)] for t in ds.tensors] for s in range(lo, hi, bs))
+
+
 def loader(dataset, device, **dataloader_kwargs):
     """DataLoader(dataset, **dataloader_kwargs) behind a prefetcher whose `collate` stacks the samples straight into pinned staging
     memory (the loader's order, shuffling and RNG use are torch's own; only where the stacked batch is written changes)."""

@@ -113,3 +113,22 @@ def test_prefetcher_is_a_pass_through_without_a_gpu_device():
     nested = ([torch.ones(2), {"k": torch.zeros(1)}], 78, None)
     out = _map_tensors(nested, lambda t: t + 1)
     assert out[1] == 78 and out[2] is None and float(out[0][0][0]) == 2.0 and float(out[0][1]["k"][0]) == 1.0
+
+
+def test_sequential_slices_are_the_unshuffled_loaders_batches():
+    """[r6] prefetch.sequential_slices: for a plain host TensorDataset (or a Subset of one over a contiguous range) the views it yields are
+    exactly DataLoader(shuffle=False)'s batches (incl. the short last one); anything else is left to the DataLoader"""
+    import torch
+    from torch.utils.data import DataLoader, Subset, TensorDataset
+    from im2im_uq_amd.prefetch import sequential_slices
+    x, y = torch.arange(23.0).view(23, 1), torch.arange(23)
+    ds = TensorDataset(x, y)
+    for d in (ds, Subset(ds, range(5, 19)), Subset(ds, range(0, 23))):
+        a, b = list(sequential_slices(d, 4)), list(DataLoader(d, batch_size=4))
+        assert len(a) == len(b) and all(torch.equal(p[0], q[0]) and torch.equal(p[1], q[1]) for p, q in zip(a, b))
+    assert sequential_slices(Subset(ds, [1, 2, 5]), 4) is None and sequential_slices(Subset(ds, range(0, 23, 2)), 4) is None
+
+    class Mine(TensorDataset):
+        def __getitem__(self, i):
+            return tuple(t[i] * 2 for t in self.tensors)
+    assert sequential_slices(Mine(x, y), 4) is None
