@@ -716,18 +716,38 @@ __global__ __launch_bounds__(256) void smallconv_wgrad_kernel(SWArgs a) {
 // window values of the small side are shared by VL * 9 fused multiply-adds (the one-channel form issues 4 LDS reads and
 // 19 VALU operations per 9 MACs: 0.48 ms for a 1 GB read).  Lanes sharing a channel group sit 16 apart in a wave: their
 // sums meet by xor-shuffles, the four waves through LDS, in a fixed order.  Partial rows as smallconv_wgrad_kernel.
-template <typename T, int CL, int CSB, int VL>
+// FM [r6]: how the multiply-adds are issued.  The compiler pairs them into v_pk_fma_f32 and, for a small-side value that sits in the HIGH
+// register of an aligned pair, selects it for the low lane with op_sel:[0,1,0].  That form returned wrong low-lane sums (the even channels,
+// about one pixel's products off, a different result on every launch) whenever OTHER PROCESSES kept the GPU busy -- never in a process that
+// had the GPU to itself, and not on every box: 35 % of the two-rank runs of tests/test_graph_ddp_gpu.py on one, 100 % of the launches beside
+// two processes running training steps.  Bisected in place with explicit instruction forms (tools/debug_victim2.sh,
+// profiles/r06_multiprocess_determinism.txt; 200 launches each beside two such processes):
+//   0  compiler's choice (op_sel:[0,1,0] and op_sel_hi:[1,0,1] mixed)            200 / 200 launches differ
+//   1  scalar v_fmac_f32                                                            0 / 200     <- what runs (DEFAULT)
+//   2  even columns v_pk_fma_f32 op_sel_hi:[1,0,1], odd columns scalar              0 / 200
+//   3  even columns scalar, odd columns v_pk_fma_f32 op_sel:[0,1,0]               200 / 200
+//   4  both packed forms, explicit                                                200 / 200
+//   5  small side stored twice in LDS, v_pk_fma_f32 without modifiers               0 / 200
+// The register prefetch and the shuffles were excluded the same way.  Alone on the GPU the forms cost 0.296 (0) / 0.311 (1) / 0.316 (2) /
+// 0.323 ms (5) at batch 78: the sums are not what limits the kernel, so the plain scalar form is the one kept.  Forms 2..5 need LF (the
+// wide side as fp32 pairs in LDS; a bf16 tile is widened when it is written to LDS).  IM2IM_SWG_DBG=<form> selects one (CS = 1, CL = 64).
+template <typename T, int CL, int CSB, int VL, bool LF = false, int FM = 1>
 __global__ __launch_bounds__(256) void smallconv_wgrad_vec_kernel(SWArgs a) {
   constexpr int N = Vec16<T>::N;
   constexpr int LG = CL / VL;                       // lanes per tile row
   constexpr int G = 256 / LG;                       // tile rows in flight
   constexpr int RPG = TS / G;
   static_assert(LG == 16 && G == 16 && RPG == 1, "one tile row per 16-lane group");
-  __shared__ __attribute__((aligned(16))) T s_L[TS * TS][CL];
-  __shared__ float s_S[CSB][HS][HS + 1];
+  using LT = std::conditional_t<LF, float, T>;
+  __shared__ __attribute__((aligned(16))) LT s_L[TS * TS][CL];
+  constexpr int SW = FM == 5 ? 2 * (HS + 1) : (FM >= 2 ? HS + 2 : HS + 1);      // row pitch of the small side's halo tile (floats)
+  constexpr int SD = FM == 5 ? 2 : 1;               // FM 5: every value twice, (v, v)
+  static_assert(FM < 2 || LF, "explicit packed forms read the wide side as fp32 pairs");
+  __shared__ __attribute__((aligned(16))) float s_S[CSB][HS][SW];
   __shared__ float s_red[4][CSB * 9 + 1][CL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = tid % LG, ty = tid / LG;           // channel group, tile row
+  using f2 = float __attribute__((ext_vector_type(2)));
   float acc[CSB][9][VL];
   float bsum[CSB];
 #pragma unroll
@@ -770,33 +790,84 @@ __global__ __launch_bounds__(256) void smallconv_wgrad_vec_kernel(SWArgs a) {
       const int sidx = i / (HS * HS), r = i % (HS * HS);
       const int hy = r / HS, hx = r % HS;
       const int yy = y0 + hy - 1, xx = x0 + hx - 1;
-      s_S[sidx][hy][hx] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? Sb[((size_t)sidx * a.H + yy) * a.W + xx] : 0.f;
+      const float sv = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? Sb[((size_t)sidx * a.H + yy) * a.W + xx] : 0.f;
+      s_S[sidx][hy][hx * SD] = sv;
+      if constexpr (SD == 2) s_S[sidx][hy][hx * 2 + 1] = sv;
     }
 #pragma unroll
     for (int i = 0; i < L_ROUNDS; ++i) {
       const int p = i * 256 + tid;
-      *reinterpret_cast<uint4*>(&s_L[p / PPR][(p % PPR) * N]) = rl[i];
+      if constexpr (std::is_same<LT, T>::value) *reinterpret_cast<uint4*>(&s_L[p / PPR][(p % PPR) * N]) = rl[i];
+      else {
+        float f[N];
+        Vec16<T>::load(reinterpret_cast<const T*>(&rl[i]), f);
+#pragma unroll
+        for (int k = 0; k < N; k += 4) *reinterpret_cast<float4*>(&s_L[p / PPR][(p % PPR) * N + k]) = make_float4(f[k], f[k + 1], f[k + 2], f[k + 3]);
+      }
     }
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) gload_L(tile + (int)gridDim.x);   // the next tile's wide side is in flight during the sums
 #pragma unroll
     for (int s = 0; s < CSB; ++s) {
       if (s < a.CS) {
-        float w[3][3];
+        if constexpr (FM < 2) {
+          float w[3][3];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) { w[dy][1] = s_S[s][ty + dy][0]; w[dy][2] = s_S[s][ty + dy][1]; }
+          for (int dy = 0; dy < 3; ++dy) { w[dy][1] = s_S[s][ty + dy][0]; w[dy][2] = s_S[s][ty + dy][1]; }
 #pragma unroll
-        for (int tx = 0; tx < TS; ++tx) {
+          for (int tx = 0; tx < TS; ++tx) {
 #pragma unroll
-          for (int dy = 0; dy < 3; ++dy) { w[dy][0] = w[dy][1]; w[dy][1] = w[dy][2]; w[dy][2] = s_S[s][ty + dy][tx + 2]; }
-          float lv[VL];
+            for (int dy = 0; dy < 3; ++dy) { w[dy][0] = w[dy][1]; w[dy][1] = w[dy][2]; w[dy][2] = s_S[s][ty + dy][tx + 2]; }
+            float lv[VL];
 #pragma unroll
-          for (int k = 0; k < VL; ++k) lv[k] = to_float(s_L[ty * TS + tx][lq * VL + k]);
+            for (int k = 0; k < VL; ++k) lv[k] = to_float(s_L[ty * TS + tx][lq * VL + k]);
 #pragma unroll
-          for (int tp = 0; tp < 9; ++tp)
+            for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-            for (int k = 0; k < VL; ++k) acc[s][tp][k] = __builtin_fmaf(lv[k], w[tp / 3][tp % 3], acc[s][tp][k]);
-          bsum[s] += w[1][1];
+              for (int k = 0; k < VL; ++k) {
+                if constexpr (FM == 1) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[s][tp][k]) : "v"(lv[k]), "v"(w[tp / 3][tp % 3]));
+                else acc[s][tp][k] = __builtin_fmaf(lv[k], w[tp / 3][tp % 3], acc[s][tp][k]);
+              }
+            bsum[s] += w[1][1];
+          }
+        } else {
+          // the halo rows as aligned register pairs: FM 2..4 pr[dy][j] = (S[2j], S[2j+1]); FM 5 pr[dy][x] = (S[x], S[x])
+          constexpr int NP = FM == 5 ? HS : HS / 2;
+          f2 pr[3][NP];
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int j = 0; j < NP; ++j) pr[dy][j] = *reinterpret_cast<const f2*>(&s_S[s][ty + dy][2 * j]);
+#pragma unroll
+          for (int tx = 0; tx < TS; ++tx) {
+            f2 lv2[VL / 2];
+#pragma unroll
+            for (int kp = 0; kp < VL / 2; ++kp) lv2[kp] = *reinterpret_cast<const f2*>(&s_L[ty * TS + tx][lq * VL + 2 * kp]);
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+              const int x = tx + tp % 3;                                  // column of the halo row (compile-time after unrolling)
+              const bool hi = FM != 5 && (x & 1);
+              const f2 wp = FM == 5 ? pr[tp / 3][x] : pr[tp / 3][x / 2];
+              const bool packed = FM == 4 || FM == 5 || (FM == 2 && !hi) || (FM == 3 && hi);
+#pragma unroll
+              for (int kp = 0; kp < VL / 2; ++kp) {
+                f2 av = {acc[s][tp][2 * kp], acc[s][tp][2 * kp + 1]};
+                if (packed) {
+                  if (FM == 5) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(av) : "v"(lv2[kp]), "v"(wp));
+                  else if (hi) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(av) : "v"(lv2[kp]), "v"(wp));
+                  else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(av) : "v"(lv2[kp]), "v"(wp));
+                } else {
+                  const float wv = hi ? wp.y : wp.x;
+                  float a0 = av.x, a1 = av.y;
+                  asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a0) : "v"(lv2[kp].x), "v"(wv));
+                  asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a1) : "v"(lv2[kp].y), "v"(wv));
+                  av.x = a0; av.y = a1;
+                }
+                acc[s][tp][2 * kp] = av.x; acc[s][tp][2 * kp + 1] = av.y;
+              }
+            }
+            bsum[s] += FM == 5 ? pr[1][tx + 1].x : (((tx + 1) & 1) ? pr[1][(tx + 1) / 2].y : pr[1][(tx + 1) / 2].x);
+          }
         }
       }
     }
@@ -1176,6 +1247,11 @@ inline int valu_mask() {
   return m;
 }
 
+inline int swg_form() {      // IM2IM_SWG_DBG=<0..5>: multiply-add form of smallconv_wgrad_vec_kernel (CS = 1, CL = 64); unset: the default
+  static const int m = [] { const char* e = getenv("IM2IM_SWG_DBG"); return e ? atoi(e) : -1; }();
+  return m;
+}
+
 template <typename F> int for_dtype_cl(int dtype, int CL, F f) {
   if (dtype == IM2IM_BF16 && CL == 64) return f((bf16_t*)nullptr, std::integral_constant<int, 64>{});
   if (dtype == IM2IM_BF16 && CL == 32) return f((bf16_t*)nullptr, std::integral_constant<int, 32>{});
@@ -1290,6 +1366,16 @@ extern "C" int im2im_smallconv_wgrad(const float* S, const void* L, float* dw, f
         if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; }
       }
       hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, stream, a);
+    }
+    else if (CS == 1 && CLv == 64 && swg_form() >= 0 && !(valu_mask() & 8)) {      // the record of the bisect (tools/debug_victim2.sh)
+#define IM2IM_SWG_CASE(F) if (swg_form() == F) hipLaunchKernelGGL((smallconv_wgrad_vec_kernel<T, 64, 1, 4, true, F>), dim3((unsigned)nblk), dim3(256), 0, stream, a); else
+      IM2IM_SWG_CASE(0) IM2IM_SWG_CASE(1) IM2IM_SWG_CASE(2) IM2IM_SWG_CASE(3) IM2IM_SWG_CASE(4) IM2IM_SWG_CASE(5)
+      return fail_invalid("IM2IM_SWG_DBG: forms 0..5");
+#undef IM2IM_SWG_CASE
+    }
+    else if (CS <= 2 && !(valu_mask() & 8) && (valu_mask() & 128)) {      // A/B: the wide side widened to fp32 when it is written to LDS
+      if (CS == 1) hipLaunchKernelGGL((smallconv_wgrad_vec_kernel<T, CLv, 1, CLv / 16, true>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((smallconv_wgrad_vec_kernel<T, CLv, 2, CLv / 16, true>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
     }
     else if (CS == 1 && !(valu_mask() & 8)) hipLaunchKernelGGL((smallconv_wgrad_vec_kernel<T, CLv, 1, CLv / 16>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
     else if (CS == 2 && !(valu_mask() & 8)) hipLaunchKernelGGL((smallconv_wgrad_vec_kernel<T, CLv, 2, CLv / 16>), dim3((unsigned)nblk), dim3(256), 0, stream, a);

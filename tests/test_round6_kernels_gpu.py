@@ -144,3 +144,35 @@ def test_train_step_with_deferred_reduce_and_one_launch_sums_is_bit_identical_to
         assert torch.equal(ref[1][k], new[1][k]), k
     for k in ref[2]:
         assert torch.equal(ref[2][k], new[2][k]), k
+
+
+def test_first_conv_weight_gradient_keeps_its_bits_beside_another_process():
+    """[r6] smallconv_wgrad_vec_kernel with the compiler's v_pk_fma_f32 op_sel:[0,1,0] returned a different weight gradient on every
+    launch while ANOTHER PROCESS kept the GPU busy (profiles/r06_multiprocess_determinism.txt); the scalar form must not.  A second
+    process runs bf16 training steps (tools/debug_victim.py aggressor); this one launches the kernel on fixed inputs and compares bits."""
+    import os
+    import subprocess
+    import sys
+    import time
+    from im2im_uq_amd import nn_ops
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    log = open(os.devnull, "w")
+    aggressor = subprocess.Popen([sys.executable, os.path.join(root, "tools", "debug_victim.py"), "aggressor", "28"], stdout=log, stderr=log)
+    try:
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(10, 1, 320, 320, generator=g).to(DEV)
+        cases = {dt: (torch.randn(10, 320, 320, 64, generator=g) * 1e-6).to(DEV).to(dt) for dt in (torch.bfloat16, torch.float32)}
+        first = {dt: nn_ops.smallconv_wgrad(x, dz, True, False)[0].clone() for dt, dz in cases.items()}
+        torch.cuda.synchronize()
+        time.sleep(14)                                          # the other process has imported torch and is stepping
+        assert aggressor.poll() is None, "the aggressor process ended early"
+        bad = 0
+        t0 = time.time()
+        while time.time() - t0 < 8:
+            for dt, dz in cases.items():
+                bad += int(not torch.equal(nn_ops.smallconv_wgrad(x, dz, True, False)[0], first[dt]))
+            torch.cuda.synchronize()
+        assert bad == 0, f"{bad} launches differ from the first"
+    finally:
+        aggressor.wait(timeout=120)
+        log.close()
