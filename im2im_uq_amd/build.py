@@ -44,7 +44,8 @@ EXPERIMENTAL = os.environ.get("IM2IM_BUILD_EXPERIMENTAL", "0") == "1"
 EXPERIMENTAL_SOURCES = {
     "conv_roll.hip": ["-ffp-contract=off"],   # same rounding rule for its lazy BatchNorm+ReLU staging
 }
-EXPERIMENTAL_USERS = ("conv_mfma.hip", "conv_wgrad.hip")     # translation units that test the macro
+EXPERIMENTAL_USERS = ("conv_mfma.hip", "conv_wgrad.hip", "smallconv.hip")     # translation units that test the macro
+#   smallconv.hip: the multiply-add forms 0, 2..5 of smallconv_wgrad_vec_kernel (the record of the v_pk_fma_f32 op_sel bisect, IM2IM_SWG_DBG)
 
 
 def active_sources() -> dict:

@@ -730,7 +730,8 @@ __global__ __launch_bounds__(256) void smallconv_wgrad_kernel(SWArgs a) {
 //   5  small side stored twice in LDS, v_pk_fma_f32 without modifiers               0 / 200
 // The register prefetch and the shuffles were excluded the same way.  Alone on the GPU the forms cost 0.296 (0) / 0.311 (1) / 0.316 (2) /
 // 0.323 ms (5) at batch 78: the sums are not what limits the kernel, so the plain scalar form is the one kept.  Forms 2..5 need LF (the
-// wide side as fp32 pairs in LDS; a bf16 tile is widened when it is written to LDS).  IM2IM_SWG_DBG=<form> selects one (CS = 1, CL = 64).
+// wide side as fp32 pairs in LDS; a bf16 tile is widened when it is written to LDS).  IM2IM_SWG_DBG=<form> selects one (CS = 1, CL = 64) in a
+// library built with IM2IM_BUILD_EXPERIMENTAL=1; the default library holds form 1 only.
 template <typename T, int CL, int CSB, int VL, bool LF = false, int FM = 1>
 __global__ __launch_bounds__(256) void smallconv_wgrad_vec_kernel(SWArgs a) {
   constexpr int N = Vec16<T>::N;
@@ -1367,12 +1368,16 @@ extern "C" int im2im_smallconv_wgrad(const float* S, const void* L, float* dw, f
       }
       hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), smem, stream, a);
     }
+#ifdef IM2IM_BUILD_EXPERIMENTAL
     else if (CS == 1 && CLv == 64 && swg_form() >= 0 && !(valu_mask() & 8)) {      // the record of the bisect (tools/debug_victim2.sh)
 #define IM2IM_SWG_CASE(F) if (swg_form() == F) hipLaunchKernelGGL((smallconv_wgrad_vec_kernel<T, 64, 1, 4, true, F>), dim3((unsigned)nblk), dim3(256), 0, stream, a); else
       IM2IM_SWG_CASE(0) IM2IM_SWG_CASE(1) IM2IM_SWG_CASE(2) IM2IM_SWG_CASE(3) IM2IM_SWG_CASE(4) IM2IM_SWG_CASE(5)
       return fail_invalid("IM2IM_SWG_DBG: forms 0..5");
 #undef IM2IM_SWG_CASE
     }
+#else
+    else if (swg_form() >= 0) return fail_invalid("IM2IM_SWG_DBG needs a library built with IM2IM_BUILD_EXPERIMENTAL=1");
+#endif
     else if (CS <= 2 && !(valu_mask() & 8) && (valu_mask() & 128)) {      // A/B: the wide side widened to fp32 when it is written to LDS
       if (CS == 1) hipLaunchKernelGGL((smallconv_wgrad_vec_kernel<T, CLv, 1, CLv / 16, true>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
       else hipLaunchKernelGGL((smallconv_wgrad_vec_kernel<T, CLv, 2, CLv / 16, true>), dim3((unsigned)nblk), dim3(256), 0, stream, a);
