@@ -47,6 +47,27 @@ def worker(rank, reps, batch, hw, depth):
             return a, c[1]
         nn_ops.smallconv_wgrad = thrice
     first, bad = None, {}
+    if os.environ.get("EVAL") == "1":                  # the eval-mode forward (folded BatchNorm, fused pool / OutConv tails) instead of the step
+        model.eval()
+        with torch.no_grad():
+            for it in range(reps):
+                out = model(x)
+                outs = out if isinstance(out, (tuple, list)) else (out,)
+                cur = {f"eval out {i}": o.detach().clone() for i, o in enumerate(outs)}
+                torch.cuda.synchronize()
+                if first is None:
+                    first = cur
+                    continue
+                for k, v in cur.items():
+                    if not torch.equal(v, first[k]):
+                        e = bad.setdefault(k, [0, 0.0, 0, [], ""])
+                        e[0] += 1
+                        e[1] = max(e[1], float((v.float() - first[k].float()).abs().max()))
+                        e[2] = max(e[2], int((v != first[k]).sum()))
+        reps_done = reps
+        print(f"[det rank {rank}] EVAL {reps} forwards B={batch} {hw}x{hw} depth={depth}: " +
+              ("all bits equal" if not bad else "; ".join(f"{k}: {v[0]}x max|d| {v[1]:.3e} ({v[2]} elements)" for k, v in bad.items())), flush=True)
+        return
     for it in range(reps):
         for p in model.parameters():
             p.grad = None
