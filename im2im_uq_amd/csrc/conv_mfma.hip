@@ -488,7 +488,11 @@ __global__ __launch_bounds__(256, (igemm_wgs_per_cu<T, TB * TH * TW / (32 * WM) 
           const T tv = from_float<T>(v);
           *reinterpret_cast<T*>(wbuf + row * WP + (nt * 32 + l31) * (int)sizeof(T)) = tv;
           if constexpr (want_stats) {
-            float d = to_float(tv) - K;
+            float d;
+            // fp32: the compiler paired these subtractions into v_pk_add_f32 op_sel:[0,1] (K broadcast from the high register of a pair),
+            // a form whose low lane is not reliable beside other processes (profiles/r06_multiprocess_determinism.txt): one scalar v_sub each
+            if constexpr (sizeof(T) == 4) asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(to_float(tv)), "v"(K));
+            else d = to_float(tv) - K;
             if constexpr (!FULL) d = ((okmask >> (mt * 16 + r)) & 1ull) ? d : 0.f;
             s += d; sq += d * d;
           }

@@ -1051,7 +1051,7 @@ __device__ __forceinline__ void bilinear_src(int dst, int in_size, int out_size,
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ deep, const float* __restrict__ deep_ss,
+IM2IM_NO_PACKED_FP32 __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ deep, const float* __restrict__ deep_ss,
                                                          const T* __restrict__ skip, const float* __restrict__ skip_ss,
                                                          T* __restrict__ out, int B, int h, int w, int Cd, int H, int W,
                                                          int Cs, RowVec rvs, RowVec rvd) {
@@ -1214,7 +1214,7 @@ constexpr int UPF_TR = IM2IM_UPF_TR, UPF_TC = IM2IM_UPF_TC, UPF_SR = UPF_TR / 2 
 constexpr int UPB_TR = IM2IM_UPB_TR, UPB_TC = 16, UPB_HC = 2 * UPB_TC + 4;       // hi-res columns a tile's sums can touch (ux in [2*x0-2, 2*x0+2*TC+1])
 
 template <typename T>
-__global__ __launch_bounds__(256) void up2x_fwd_tiled_kernel(const T* __restrict__ deep, const float* __restrict__ deep_ss,
+IM2IM_NO_PACKED_FP32 __global__ __launch_bounds__(256) void up2x_fwd_tiled_kernel(const T* __restrict__ deep, const float* __restrict__ deep_ss,
                                                               T* __restrict__ out, int B, int h, int w, int Cd, int H, int W,
                                                               int Ct, int c_off, int tilesY, int tilesX) {
   // out: [B][H][W][Ct], the upsampled channels at [c_off, c_off + Cd) (Ct = Cd, c_off = 0 without a skip half)

@@ -72,3 +72,25 @@ def test_every_source_file_is_built():
     on_disk = sorted(f for f in os.listdir(build.CSRC) if f.endswith((".hip", ".cpp")) and not f.startswith("_"))
     assert on_disk == sorted(list(build.SOURCES) + list(build.EXPERIMENTAL_SOURCES))      # [r6] conv_roll.hip: IM2IM_BUILD_EXPERIMENTAL=1 only
     assert not set(build.SOURCES) & set(build.EXPERIMENTAL_SOURCES)
+
+
+def test_no_unreliable_packed_fp32_forms():
+    """[r6] v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 whose op_sel feeds the HIGH register of the second or third source to the low lane
+    drop that lane's write when another process shares the GPU (profiles/r06_multiprocess_determinism.txt, tools/hwprobe/pkfma_probe.hip).
+    The compiler chooses these forms on its own, so the built library is disassembled and checked (tools/check_packed_opsel.py)."""
+    import importlib.util
+    import os
+    import pytest
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    spec = importlib.util.spec_from_file_location("check_packed_opsel", os.path.join(root, "tools", "check_packed_opsel.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not mod.objdump():
+        pytest.skip("llvm-objdump not available")
+    from im2im_uq_amd import _lib, build
+    stamp = _lib.LIB_PATH + ".objs"
+    if build.EXPERIMENTAL or (os.path.exists(stamp) and ".exp." in open(stamp).read()):
+        pytest.skip("an IM2IM_BUILD_EXPERIMENTAL=1 library holds the bisect forms on purpose")
+    n, found = mod.scan(_lib.LIB_PATH)
+    assert n >= 5, "device code objects not found in the library"
+    assert not found, {k: dict(v) for k, v in found.items()}

@@ -10,6 +10,8 @@
 //   2  v_pk_fma_f32 op_sel:[1,0,0] with the operands swapped (the small-side pair as src0)
 //   3  v_pk_mul_f32 op_sel:[0,1] + v_pk_add_f32                                            (not fused: compared with v_mul + v_add)
 //   4  v_pk_fma_f32 op_sel:[0,1,0] with operands held in registers for the whole loop (no LDS reads inside the loop)
+//   5  v_pk_fma_f32 op_sel:[0,0,1]: the THIRD source's high register into the low lane (sum = pair.hi + a*b, compared with v_fma)
+//   6  v_pk_add_f32 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]  (a - b.hi: the fp32 conv's statistics epilogue) feeding a v_pk_fma
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -61,7 +63,16 @@ __global__ __launch_bounds__(256) void probe_kernel(const float* __restrict__ in
 #pragma unroll
         for (int kp = 0; kp < VL / 2; ++kp) {
           // reference: scalar
-          if (FORM == 3 && hi) {
+          if (FORM == 5 && hi) {          // acc = fma(lv, lv, w.hi)  -- the addend comes from the pair, the sum is NOT accumulated
+            asm volatile("v_fma_f32 %0, %1, %1, %2" : "=v"(accs[tp][2 * kp]) : "v"(lv2[kp].x), "v"(wv));
+            asm volatile("v_fma_f32 %0, %1, %1, %2" : "=v"(accs[tp][2 * kp + 1]) : "v"(lv2[kp].y), "v"(wv));
+          } else if (FORM == 6 && hi) {   // acc += (lv - w.hi)
+            float m0, m1;
+            asm volatile("v_sub_f32 %0, %1, %2" : "=v"(m0) : "v"(lv2[kp].x), "v"(wv));
+            asm volatile("v_sub_f32 %0, %1, %2" : "=v"(m1) : "v"(lv2[kp].y), "v"(wv));
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(accs[tp][2 * kp]) : "v"(m0));
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(accs[tp][2 * kp + 1]) : "v"(m1));
+          } else if (FORM == 3 && hi) {
             float m0, m1;
             asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m0) : "v"(lv2[kp].x), "v"(wv));
             asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m1) : "v"(lv2[kp].y), "v"(wv));
@@ -79,6 +90,12 @@ __global__ __launch_bounds__(256) void probe_kernel(const float* __restrict__ in
           else if (FORM == 3) {
             f2 m;
             asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(m) : "v"(lv2[kp]), "v"(wp));
+            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(av) : "v"(m));
+          } else if (FORM == 5) {
+            asm volatile("v_pk_fma_f32 %0, %1, %1, %2 op_sel:[0,0,1]" : "=v"(av) : "v"(lv2[kp]), "v"(wp));
+          } else if (FORM == 6) {
+            f2 m;
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(m) : "v"(lv2[kp]), "v"(wp));
             asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(av) : "v"(m));
           } else {
             float a0 = av.x, a1 = av.y;
@@ -175,6 +192,8 @@ int main(int argc, char** argv) {
   run<4>("the same, small side held in registers (no LDS reads of it in the loop)", d_in, d_mis, launches, iters);
   run<2>("odd columns v_pk_fma_f32 op_sel:[1,0,0] (small-side pair as src0)", d_in, d_mis, launches, iters);
   run<3>("odd columns v_pk_mul_f32 op_sel:[0,1] + v_pk_add_f32", d_in, d_mis, launches, iters);
+  run<5>("odd columns v_pk_fma_f32 op_sel:[0,0,1] (third source)", d_in, d_mis, launches, iters);
+  run<6>("odd columns v_pk_add_f32 op_sel:[0,1] neg (a - b.hi) + v_pk_add_f32", d_in, d_mis, launches, iters);
   {
     unsigned* d_cnt; CK(hipMalloc(&d_cnt, 6 * sizeof(unsigned))); CK(hipMemset(d_cnt, 0, 6 * sizeof(unsigned)));
     for (int l = 0; l < launches; ++l) hipLaunchKernelGGL(classify_kernel, dim3(2048), dim3(256), 0, 0, d_in, d_cnt, 256);
